@@ -1,0 +1,278 @@
+"""ctypes binding of the product library libag2hip.so (C-ABI: include/ag2_c.h).
+
+Harness side only (tests, bench.py, smoke()).  There is no fallback of any kind: if the HIP
+library is missing, or no GPU is usable, loading / creating a context raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libag2hip.so")
+
+SYMBOLS = [
+    "ag2_abi_version", "ag2_default_params", "ag2_create", "ag2_destroy", "ag2_last_error",
+    "ag2_set_stream", "ag2_set_cloud", "ag2_set_cloud_device", "ag2_compute_normals",
+    "ag2_get_normals", "ag2_get_grid_perm", "ag2_local_frames", "ag2_generate_hypotheses",
+    "ag2_hyp_points", "ag2_prune", "ag2_render_images", "ag2_render_images_from_points",
+    "ag2_lenet_load", "ag2_lenet_forward", "ag2_detect", "ag2_export_candidates_device",
+    "ag2_get_counters", "ag2_get_stage_times",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("finger_width", C.c_double), ("hand_outer_diameter", C.c_double),
+        ("hand_depth", C.c_double), ("hand_height", C.c_double), ("init_bite", C.c_double),
+        ("nn_radius_taubin", C.c_double), ("nn_radius_hands", C.c_double),
+        ("normals_radius", C.c_double), ("grid_cell", C.c_double),
+        ("num_orientations", C.c_int32), ("num_threads", C.c_int32), ("n_cams", C.c_int32),
+        ("filter_half_grasps", C.c_int32),
+        ("cam_origin", (C.c_double * 3) * 2),
+        ("workspace", C.c_double * 6),
+        ("min_aperture", C.c_double), ("max_aperture", C.c_double),
+        ("min_score_diff", C.c_double),
+        ("num_selected", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "n_points", "n_valid_points", "n_samples", "n_frames", "n_hypotheses", "n_pruned",
+        "n_scored", "n_selected", "sum_k1", "sum_k2", "sum_kcrop", "sum_p", "n_overflow_samples",
+        "reserved")]
+
+
+class Times(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "grid_ms", "normals_ms", "hands_ms", "images_ms", "lenet_ms", "select_ms", "total_ms",
+        "reserved")]
+
+
+HYP_DTYPE = np.dtype([
+    ("axis", "<f8", 3), ("approach", "<f8", 3), ("binormal", "<f8", 3),
+    ("surface", "<f8", 3), ("bottom", "<f8", 3), ("top", "<f8", 3),
+    ("width", "<f8"), ("score", "<f8"),
+    ("sample_slot", "<i4"), ("orientation", "<i4"),
+    ("half_antipodal", "u1"), ("full_antipodal", "u1"), ("reserved", "<u2"), ("n_points", "<i4"),
+])
+assert HYP_DTYPE.itemsize == 176
+
+_lib = None
+
+
+def load():
+    """Load libag2hip.so.  Raises if the extension was not built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+            "(make -C agile_grasp2_amd/csrc). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.ag2_create.restype = C.c_void_p
+    L.ag2_create.argtypes = [C.POINTER(Params), C.c_int]
+    L.ag2_destroy.argtypes = [C.c_void_p]
+    L.ag2_last_error.restype = C.c_char_p
+    L.ag2_last_error.argtypes = [C.c_void_p]
+    L.ag2_default_params.argtypes = [C.POINTER(Params)]
+    _lib = L
+    return L
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    load().ag2_default_params(C.byref(p))
+    return apply_params(p, **kw)
+
+
+def apply_params(p, **kw):
+    for k, v in kw.items():
+        if k == "cam_origin":
+            a = np.asarray(v, dtype=np.float64).reshape(-1, 3)
+            for i in range(a.shape[0]):
+                for j in range(3):
+                    p.cam_origin[i][j] = float(a[i, j])
+        elif k == "workspace":
+            for i in range(6):
+                p.workspace[i] = float(v[i])
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Detector:
+    """One context on one GPU.  Method names follow the C-ABI."""
+
+    def __init__(self, params: Params | None = None, device: int = 0, **kw):
+        self.L = load()
+        self.params = params if params is not None else default_params(**kw)
+        h = self.L.ag2_create(C.byref(self.params), C.c_int(device))
+        if not h:
+            raise RuntimeError("ag2_create failed: no usable HIP device or bad parameters "
+                               "(libag2hip.so has no CPU fallback)")
+        self.h = C.c_void_p(h)
+        self.n = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ag2_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libag2hip (rc={rc}): " + self.L.ag2_last_error(self.h).decode())
+
+    def set_stream(self, stream_ptr: int):
+        self._ck(self.L.ag2_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_cloud(self, xyz, cam_source=None, normals=None):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        assert xyz.ndim == 2 and xyz.shape[1] >= 3
+        self.n = xyz.shape[0]
+        ncam, cs = 1, None
+        if cam_source is not None:
+            cs = np.asfortranarray(np.asarray(cam_source, dtype=np.int32))
+            ncam = cs.shape[0]
+        nr = None
+        if normals is not None:
+            nr = np.asfortranarray(np.asarray(normals, dtype=np.float64))
+            assert nr.shape == (3, self.n)
+        self._ck(self.L.ag2_set_cloud(self.h, _ptr(xyz), C.c_size_t(self.n),
+                                      C.c_size_t(xyz.strides[0] if self.n else 12), _ptr(cs),
+                                      C.c_int(ncam), _ptr(nr)))
+
+    def set_cloud_device(self, dptr: int, n: int, stride_bytes: int = 12):
+        self.n = n
+        self._ck(self.L.ag2_set_cloud_device(self.h, C.c_void_p(dptr), C.c_size_t(n),
+                                             C.c_size_t(stride_bytes)))
+
+    def compute_normals(self):
+        self._ck(self.L.ag2_compute_normals(self.h))
+
+    def get_normals(self):
+        out = np.zeros((3, self.n), dtype=np.float64, order="F")
+        self._ck(self.L.ag2_get_normals(self.h, _ptr(out)))
+        return out
+
+    def get_grid_perm(self):
+        out = np.zeros(max(self.n, 1), dtype=np.int32)
+        nv = C.c_size_t(0)
+        self._ck(self.L.ag2_get_grid_perm(self.h, _ptr(out), C.c_size_t(out.shape[0]), C.byref(nv)))
+        return out[: nv.value].copy()
+
+    @staticmethod
+    def _samples(sample_idx, sample_xyz):
+        si = sx = None
+        if sample_idx is not None:
+            si = np.ascontiguousarray(sample_idx, dtype=np.int32)
+            s = si.shape[0]
+        else:
+            sx = np.asfortranarray(np.asarray(sample_xyz, dtype=np.float64))
+            assert sx.shape[0] == 3
+            s = sx.shape[1]
+        return si, sx, s
+
+    def local_frames(self, sample_idx=None, sample_xyz=None, slot_base=0, seed=0):
+        si, sx, s = self._samples(sample_idx, sample_xyz)
+        fr = np.zeros((s, 12), dtype=np.float64)
+        valid = np.zeros(s, dtype=np.int32)
+        self._ck(self.L.ag2_local_frames(self.h, _ptr(si), _ptr(sx), C.c_size_t(s),
+                                         C.c_uint64(slot_base), C.c_uint64(seed), _ptr(fr), _ptr(valid)))
+        return fr, valid
+
+    def generate_hypotheses(self, sample_idx=None, sample_xyz=None, slot_base=0, seed=0):
+        si, sx, s = self._samples(sample_idx, sample_xyz)
+        cap = max(1, s * int(self.params.num_orientations))
+        out = np.zeros(cap, dtype=HYP_DTYPE)
+        n = C.c_size_t(0)
+        self._ck(self.L.ag2_generate_hypotheses(self.h, _ptr(si), _ptr(sx), C.c_size_t(s),
+                                                C.c_uint64(slot_base), C.c_uint64(seed), _ptr(out),
+                                                C.c_size_t(cap), C.byref(n)))
+        return out[: n.value].copy()
+
+    def hyp_points(self, h, p):
+        pts = np.zeros((3, p), dtype=np.float64, order="F")
+        nrm = np.zeros((3, p), dtype=np.float64, order="F")
+        self._ck(self.L.ag2_hyp_points(self.h, C.c_size_t(h), _ptr(pts), _ptr(nrm)))
+        return pts, nrm
+
+    def prune(self, n):
+        keep = np.zeros(n, dtype=np.uint8)
+        self._ck(self.L.ag2_prune(self.h, _ptr(keep), C.c_size_t(n)))
+        return keep
+
+    def render_images(self, first, count):
+        out = np.zeros((count, 60, 60, 3), dtype=np.uint8)
+        self._ck(self.L.ag2_render_images(self.h, C.c_size_t(first), C.c_size_t(count), _ptr(out)))
+        return out
+
+    def render_images_from_points(self, pts_list, nrm_list):
+        n = len(pts_list)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        for i, p in enumerate(pts_list):
+            offs[i + 1] = offs[i] + np.asarray(p).shape[1]
+        tot = int(offs[-1])
+        pts = np.zeros((3, max(tot, 1)), dtype=np.float64, order="F")
+        nrm = np.zeros((3, max(tot, 1)), dtype=np.float64, order="F")
+        for i in range(n):
+            pts[:, offs[i]:offs[i + 1]] = pts_list[i]
+            nrm[:, offs[i]:offs[i + 1]] = nrm_list[i]
+        out = np.zeros((n, 60, 60, 3), dtype=np.uint8)
+        self._ck(self.L.ag2_render_images_from_points(self.h, C.c_size_t(n), _ptr(offs), _ptr(pts),
+                                                      _ptr(nrm), _ptr(out)))
+        return out
+
+    def lenet_load(self, w):
+        arrs = [np.ascontiguousarray(w[k], dtype=np.float32) for k in (
+            "conv1_w", "conv1_b", "conv2_w", "conv2_b", "ip1_w", "ip1_b", "ip2_w", "ip2_b")]
+        self._ck(self.L.ag2_lenet_load(self.h, *[_ptr(a) for a in arrs]))
+
+    def lenet_forward(self, images):
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        n = images.shape[0]
+        out = np.zeros((n, 2), dtype=np.float32)
+        self._ck(self.L.ag2_lenet_forward(self.h, _ptr(images), C.c_size_t(n), _ptr(out)))
+        return out
+
+    def detect(self, sample_idx=None, sample_xyz=None, slot_base=0, seed=0, do_prune=True,
+               want_all=True):
+        si, sx, s = self._samples(sample_idx, sample_xyz)
+        cap = max(1, s * int(self.params.num_orientations))
+        sel = np.zeros(cap, dtype=HYP_DTYPE)
+        allh = np.zeros(cap if want_all else 1, dtype=HYP_DTYPE)
+        ns, na = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self.L.ag2_detect(self.h, _ptr(si), _ptr(sx), C.c_size_t(s), C.c_uint64(slot_base),
+                                   C.c_uint64(seed), C.c_int(1 if do_prune else 0), _ptr(sel),
+                                   C.c_size_t(cap), C.byref(ns),
+                                   _ptr(allh) if want_all else None,
+                                   C.c_size_t(cap if want_all else 0), C.byref(na)))
+        return sel[: ns.value].copy(), (allh[: na.value].copy() if want_all else na.value)
+
+    def export_candidates_device(self, dptr: int, nbytes: int):
+        self._ck(self.L.ag2_export_candidates_device(self.h, C.c_void_p(dptr), C.c_size_t(nbytes)))
+
+    def counters(self) -> Counters:
+        c = Counters()
+        self._ck(self.L.ag2_get_counters(self.h, C.byref(c)))
+        return c
+
+    def times(self) -> Times:
+        t = Times()
+        self._ck(self.L.ag2_get_stage_times(self.h, C.byref(t)))
+        return t

@@ -1,0 +1,172 @@
+// ag2_device.h -- device-side helpers shared by the HIP kernels of libag2hip.so (gfx950 only).
+//
+// Arithmetic contract: everything that feeds a comparison or an index on the geometric path uses
+// IEEE-754 + - * / sqrt with the parenthesisation written here; the translation units are compiled
+// with -ffp-contract=off so hipcc forms no FMAs.  The same contract is stated (independently) in
+// oracle/ag2_oracle.cpp; parity tests require bit-identical labels/indices from the two.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ag2 {
+
+constexpr int kWave = 64;
+constexpr int kMaxOrient = 32;
+constexpr int kMaxDepths = 32;
+constexpr int kMaxRows = 1024;   // stencil rows (y,z pairs) of one hand-radius query
+constexpr int kImg = 60;         // Learning(60, ...) grasp_detector.cpp:56
+
+struct GridDesc {
+  float o[3];
+  float inv;
+  int dims[3];
+  int ncells;
+  int n_valid;
+};
+
+// Per-context constants, built on the host (ag2_context.hip derive_constants) and read through a
+// uniform pointer.
+struct HandConst {
+  double fs[20];                 // finger_spacing_(i), finger_hand.cpp:9-12
+  double fsr[20];                // finger_spacing_(i) + finger_width_
+  double cos_t[kMaxOrient];      // hand_search.cpp:179-180, :356
+  double sin_t[kMaxOrient];
+  double depths[kMaxDepths];     // deepenHand depth sequence, finger_hand.cpp:118-122
+  double cam_origin[2][3];
+  double finger_width, hand_outer_diameter, hand_depth, hand_height, init_bite;
+  double cos_fc;                 // cos(30 deg), antipodal.cpp:11,23
+  double min_aperture, max_aperture;
+  float ws_min_x, ws_max_x, ws_min_y, ws_max_y;  // float bounds, grasp_detector.cpp:363-364
+  float r2_taubin, r2_hands, r2_normals;         // (float)(r*r)
+  float rq_taubin, rq_hands, rq_normals;         // conservative per-axis reach
+  int R, n_depths, n_cams, filter_half;
+};
+
+struct V3 {
+  double x, y, z;
+};
+__device__ __forceinline__ double dot3(const V3& a, const V3& b) {
+  return (a.x * b.x + a.y * b.y) + a.z * b.z;
+}
+__device__ __forceinline__ V3 cross3(const V3& a, const V3& b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ V3 neg3(const V3& a) { return V3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ double norm3(const V3& a) { return __builtin_sqrt(dot3(a, a)); }
+
+__device__ __forceinline__ int cell_of(float v, float o, float inv) {
+  return (int)__builtin_floorf((v - o) * inv);
+}
+__device__ __forceinline__ bool finite3(float a, float b, float c) {
+  return __builtin_isfinite(a) && __builtin_isfinite(b) && __builtin_isfinite(c);
+}
+
+// Cyclic Jacobi for a symmetric 3x3, written on scalars so everything stays in registers.
+// Stands in for Eigen::EigenSolver (local_frame.cpp:30-32) and pcl::eigen33 (inside
+// pcl::NormalEstimationOMP, hand_search.cpp:85-92).  Rotation order (0,1), (0,2), (1,2); at most 12
+// sweeps; a pair with an exactly-zero off-diagonal is skipped.
+struct Sym3 {
+  double a00, a01, a02, a11, a12, a22;
+};
+struct Eig3 {
+  double d[3];
+  double v[3][3];  // columns = eigenvectors
+};
+
+#define AG2_JACOBI_ROT(APP, AQQ, APQ, ARP, ARQ, VP, VQ)                          \
+  if (APQ != 0.0) {                                                              \
+    const double theta = (AQQ - APP) / (2.0 * APQ);                              \
+    double t = 1.0 / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0)); \
+    if (theta < 0.0) t = -t;                                                     \
+    const double c = 1.0 / __builtin_sqrt(t * t + 1.0);                          \
+    const double s = t * c;                                                      \
+    APP = APP - t * APQ;                                                         \
+    AQQ = AQQ + t * APQ;                                                         \
+    APQ = 0.0;                                                                   \
+    const double arp = ARP, arq = ARQ;                                           \
+    ARP = c * arp - s * arq;                                                     \
+    ARQ = s * arp + c * arq;                                                     \
+    _Pragma("unroll") for (int k = 0; k < 3; k++) {                              \
+      const double vkp = e.v[k][VP], vkq = e.v[k][VQ];                           \
+      e.v[k][VP] = c * vkp - s * vkq;                                            \
+      e.v[k][VQ] = s * vkp + c * vkq;                                            \
+    }                                                                            \
+  }
+
+__device__ inline Eig3 jacobi3(Sym3 m) {
+  Eig3 e;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) e.v[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 12; sweep++) {
+    if (m.a01 == 0.0 && m.a02 == 0.0 && m.a12 == 0.0) break;
+    // (p,q,r) = (0,1,2): a[r][p] = a02, a[r][q] = a12
+    AG2_JACOBI_ROT(m.a00, m.a11, m.a01, m.a02, m.a12, 0, 1)
+    // (p,q,r) = (0,2,1): a[r][p] = a01, a[r][q] = a12
+    AG2_JACOBI_ROT(m.a00, m.a22, m.a02, m.a01, m.a12, 0, 2)
+    // (p,q,r) = (1,2,0): a[r][p] = a01, a[r][q] = a02
+    AG2_JACOBI_ROT(m.a11, m.a22, m.a12, m.a01, m.a02, 1, 2)
+  }
+  e.d[0] = m.a00;
+  e.d[1] = m.a11;
+  e.d[2] = m.a22;
+  return e;
+}
+
+__device__ __forceinline__ int argmin3(const double d[3]) {
+  int m = 0;
+  if (d[1] < d[m]) m = 1;
+  if (d[2] < d[m]) m = 2;
+  return m;
+}
+
+// Counter-based draw replacing rand() % size (hand_search.cpp:130), keyed (seed, slot, draw).
+__device__ __forceinline__ uint64_t draw_u64(uint64_t seed, uint64_t slot, uint64_t j) {
+  uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (slot + 1ull));
+  x += 0xD1B54A32D192ED03ull * (j + 1ull);
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+// ---- wave / block primitives (64-wide wavefronts) --------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned wave_or_u(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= (unsigned)__shfl_xor((int)v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double w = __shfl_xor(v, o, 64);
+    v = (w < v) ? w : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double w = __shfl_xor(v, o, 64);
+    v = (w > v) ? w : v;
+  }
+  return v;
+}
+
+}  // namespace ag2

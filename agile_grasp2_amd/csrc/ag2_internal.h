@@ -1,0 +1,141 @@
+// ag2_internal.h -- host-side context of libag2hip.so and the launchers of its kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "ag2_c.h"
+#include "ag2_device.h"
+
+namespace ag2 {
+
+// Grow-only device buffer.
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t need) {
+    if (need <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    size_t want = need + need / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) bytes = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T* as() const { return (T*)p; }
+};
+
+// Device-side counters / flags block (one per context, zeroed per call).
+struct DevStats {
+  unsigned long long sum_k1, sum_k2, sum_kcrop, sum_p;
+  unsigned long long arena_top;      // in-box points reserved in the arena
+  unsigned int n_frames, n_hyp, n_overflow, n_pruned_keep;
+  unsigned int err_flags;            // bit0 arena overflow, bit1 rows overflow, bit2 nb1 overflow,
+                                     // bit3 global sweep scratch overflow
+  unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
+  unsigned int pad;
+};
+
+struct LeNetDev {
+  bool loaded = false;
+  DevBuf w1p, b1, w2p, b2, w3p, b3, w4, b4;  // packed for the MFMA lane layout (k_lenet.hip)
+};
+
+}  // namespace ag2
+
+struct ag2_ctx {
+  ag2_params p;
+  int device = 0;
+  std::string err;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev[8] = {};
+
+  // cloud
+  size_t n = 0;           // points given
+  size_t n_valid = 0;     // finite points (grid-resident)
+  ag2::GridDesc grid{};
+  bool has_cloud = false, has_normals = false;
+  float min_z = 0.f;
+  ag2::DevBuf d_xyz_in;    // packed float4 (x,y,z, cam mask bits) in ORIGINAL order
+  ag2::DevBuf d_key;       // int32 cell key per original point (-1 invalid)
+  ag2::DevBuf d_cell;      // uint32 cell_start[ncells+1]
+  ag2::DevBuf d_fill;      // uint32 per-cell cursor / scan scratch
+  ag2::DevBuf d_perm;      // int32 sorted position -> original index
+  ag2::DevBuf d_sorted;    // float4 (x,y,z, cam mask bits) in sorted order
+  ag2::DevBuf d_nrm;       // float4 (nx,ny,nz,0) in sorted order
+  ag2::DevBuf d_scan;      // block sums for the scan
+  ag2::DevBuf d_stats;     // DevStats
+  ag2::DevBuf d_hc;        // HandConst
+  ag2::HandConst hc{};
+
+  // samples / hypotheses of the last generate call
+  size_t s = 0;
+  uint64_t slot_base = 0;
+  ag2::DevBuf d_sample_q;  // float4 per sample (query xyz, valid flag)
+  ag2::DevBuf d_frames;    // 12 doubles per sample + valid
+  ag2::DevBuf d_frame_ok;  // int per sample
+  ag2::DevBuf d_table;     // ag2_hypothesis[s*R] fixed-slot table
+  ag2::DevBuf d_tab_off;   // int64 arena offset per slot
+  ag2::DevBuf d_tab_keep;  // uint8 prune flag per slot
+  ag2::DevBuf d_arena;     // 6 doubles per in-box point (U.xyz, Y.xyz)
+  size_t arena_points = 0;
+  ag2::DevBuf d_overflow;  // int sample ids that need the global-memory sweep
+  ag2::DevBuf d_gscratch;  // global cropped-list scratch for the overflow path
+  ag2::DevBuf d_list;      // int compacted slot ids (hypotheses in order)
+  ag2::DevBuf d_list2;     // int compacted slot ids after prune / for scoring
+  ag2::DevBuf d_images;    // uint8 n_img x 10800 (HWC)
+  ag2::DevBuf d_logits;    // float n_img x 2
+  ag2::DevBuf d_act1;      // LeNet intermediates (pooled2: n x 7200 float)
+  ag2::DevBuf d_tmp;       // misc staging
+  std::vector<ag2_hypothesis> h_hyps;   // compacted hypotheses of the last generate call
+  std::vector<int32_t> h_slots;         // their slot ids
+  std::vector<int64_t> h_offsets;       // their arena offsets
+  size_t n_img = 0;
+
+  ag2::LeNetDev net;
+  ag2_counters cnt{};
+  ag2_times times{};
+};
+
+namespace ag2 {
+
+int set_err(ag2_ctx* c, int code, const std::string& msg);
+#define AG2_HIP(c, expr)                                                                  \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return ag2::set_err(c, AG2_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// k_grid.hip
+int build_grid(ag2_ctx* c);
+int gather_normals(ag2_ctx* c);  // d_tmp (float4, original order) -> d_nrm (sorted order)
+int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes);
+int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n);
+// k_normals.hip
+int launch_normals(ag2_ctx* c);
+// k_sweep.hip
+int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed);
+int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists);
+// k_select.hip
+int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out);
+int launch_scatter_scores(ag2_ctx* c, size_t n_img);
+// k_image.hip
+int launch_render(ag2_ctx* c, const int* d_slot_list, size_t n_img, const double* d_arena,
+                  const long long* d_offsets, const int* d_counts, uint8_t* d_out);
+// k_lenet.hip
+int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const float* c2w,
+                       const float* c2b, const float* f1w, const float* f1b, const float* f2w,
+                       const float* f2b);
+int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits);
+
+}  // namespace ag2

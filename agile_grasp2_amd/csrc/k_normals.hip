@@ -1,0 +1,100 @@
+// k_normals.hip -- K1: per-point PCA plane normals.
+//
+// Replaces HandSearch::calculateNormalsOMP (src/agile_grasp2/hand_search.cpp:83-94), i.e.
+// pcl::NormalEstimationOMP with radius 0.01 and viewpoint (0,0,0): neighbours within the radius
+// (self included, strict float d2 < (float)(r*r)); fewer than 3 => NaN; raw moments accumulated in
+// float in canonical (sorted-position) order; covariance E[xx^T] - mm^T; eigenvector of the smallest
+// eigenvalue (Jacobi in f64); flipped towards the viewpoint.
+//
+// One thread per point in SORTED order: the 64 lanes of a wave are spatial neighbours, so their
+// 3x3 row spans overlap and the float4 point loads are served from L1/L2.  HBM-bound by design:
+// algorithmic bytes = N * (K1 * 12 + 12).
+#include "ag2_internal.h"
+
+namespace ag2 {
+
+__global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
+                                                 const unsigned* __restrict__ cell, GridDesc g,
+                                                 float r2f, float rq, float4* __restrict__ nrm,
+                                                 DevStats* st) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int cnt = 0;
+  if (i < g.n_valid) {
+    const float4 q = pts[i];
+    int lo[3], hi[3];
+    const float qq[3] = {q.x, q.y, q.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = max(cell_of(qq[a] - rq, g.o[a], g.inv), 0);
+      hi[a] = min(cell_of(qq[a] + rq, g.o[a], g.inv), g.dims[a] - 1);
+    }
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+    for (int cz = lo[2]; cz <= hi[2]; cz++)
+      for (int cy = lo[1]; cy <= hi[1]; cy++) {
+        const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
+        const int b = (int)cell[rowbase + lo[0]];
+        const int e = (int)cell[rowbase + hi[0] + 1];
+        for (int j = b; j < e; j++) {
+          const float4 p = pts[j];
+          const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+          const float d2 = (dx * dx + dy * dy) + dz * dz;
+          if (d2 < r2f) {
+            a0 = a0 + p.x * p.x;
+            a1 = a1 + p.x * p.y;
+            a2 = a2 + p.x * p.z;
+            a3 = a3 + p.y * p.y;
+            a4 = a4 + p.y * p.z;
+            a5 = a5 + p.z * p.z;
+            a6 = a6 + p.x;
+            a7 = a7 + p.y;
+            a8 = a8 + p.z;
+            cnt++;
+          }
+        }
+      }
+    float4 out;
+    if (cnt < 3) {
+      const float nanv = __builtin_nanf("");
+      out = make_float4(nanv, nanv, nanv, 0.f);
+    } else {
+      const float fc = (float)cnt;
+      a0 = a0 / fc; a1 = a1 / fc; a2 = a2 / fc; a3 = a3 / fc; a4 = a4 / fc;
+      a5 = a5 / fc; a6 = a6 / fc; a7 = a7 / fc; a8 = a8 / fc;
+      Sym3 m;
+      m.a00 = (double)(a0 - a6 * a6);
+      m.a01 = (double)(a1 - a6 * a7);
+      m.a02 = (double)(a2 - a6 * a8);
+      m.a11 = (double)(a3 - a7 * a7);
+      m.a12 = (double)(a4 - a7 * a8);
+      m.a22 = (double)(a5 - a8 * a8);
+      const Eig3 e = jacobi3(m);
+      const int mi = argmin3(e.d);
+      const V3 v{mi == 0 ? e.v[0][0] : (mi == 1 ? e.v[0][1] : e.v[0][2]),
+                 mi == 0 ? e.v[1][0] : (mi == 1 ? e.v[1][1] : e.v[1][2]),
+                 mi == 0 ? e.v[2][0] : (mi == 1 ? e.v[2][1] : e.v[2][2])};
+      const double nv = norm3(v);
+      float fx = (float)(v.x / nv), fy = (float)(v.y / nv), fz = (float)(v.z / nv);
+      const float vx = 0.0f - q.x, vy = 0.0f - q.y, vz = 0.0f - q.z;
+      const float ct = (vx * fx + vy * fy) + vz * fz;
+      if (ct < 0.0f) {
+        fx = -fx; fy = -fy; fz = -fz;
+      }
+      out = make_float4(fx, fy, fz, 0.f);
+    }
+    nrm[i] = out;
+  }
+  const int tot = wave_sum_i(cnt);
+  if (lane_id() == 0 && tot) atomicAdd(&st->sum_k1, (unsigned long long)tot);
+}
+
+int launch_normals(ag2_ctx* c) {
+  if (c->n_valid == 0) return 0;
+  const int nb = ((int)c->n_valid + 255) / 256;
+  hipLaunchKernelGGL(k_normals, dim3(nb), dim3(256), 0, c->stream, c->d_sorted.as<float4>(),
+                     c->d_cell.as<unsigned>(), c->grid, c->hc.r2_normals, c->hc.rq_normals,
+                     c->d_nrm.as<float4>(), c->d_stats.as<DevStats>());
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+}  // namespace ag2

@@ -1,0 +1,844 @@
+// k_sweep.hip -- K2 local frames and K3 the hand sweep.
+//
+// K2 k_frames replaces HandSearch::calculateLocalFrames (src/agile_grasp2/hand_search.cpp:97-170,
+// :238-317) + LocalFrame::findAverageNormalAxis (local_frame.cpp:26-59): one 64-lane wave per
+// sample; the <= 50 drawn normals live one per lane, the 50x50 Gram column sums are one column per
+// lane, the 3x3 eigen-problem is solved redundantly in every lane.
+//
+// K3 k_sweep replaces HandSearch::evaluateHands (hand_search.cpp:173-235), calculateHand
+// (:319-426), FingerHand (finger_hand.cpp:17-214, :313-325) and Antipodal::evaluateGrasp
+// (antipodal.cpp:8-84): persistent 256-thread workgroups, one sample at a time; the radius
+// neighbourhood is read as contiguous float4 row spans of the sorted cloud (coalesced), cropped to
+// the +-hand_height slab and staged in LDS (24 B / point); every orientation then runs as a few
+// passes over the LDS list with wavefront ballots / shuffles + one LDS hop for the block-wide
+// reductions (finger-slot occupancy mask, back-of-hand collision, deepen step, closing-region
+// extents, antipodal extents).  All geometry is f64 with the op order of ag2_device.h.
+#include "ag2_internal.h"
+
+namespace ag2 {
+
+constexpr int kSweepThreads = 256;
+constexpr int kSweepWaves = kSweepThreads / kWave;
+constexpr int kLdsCap = 2560;  // cropped points resident in LDS (24 B each); larger samples take
+                               // the global-scratch instantiation of the same kernel
+
+// ---------------------------------------------------------------------------------------------
+// sample queries: (x, y, z, valid) per sample
+// ---------------------------------------------------------------------------------------------
+__global__ void k_sample_queries_idx(const int* __restrict__ idx, int s,
+                                     const float4* __restrict__ xyz_in, int n,
+                                     float4* __restrict__ q) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s) return;
+  const int id = idx[i];
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (id >= 0 && id < n) {
+    const float4 p = xyz_in[id];
+    if (finite3(p.x, p.y, p.z)) o = make_float4(p.x, p.y, p.z, 1.f);
+  }
+  q[i] = o;
+}
+
+struct QueryRange {
+  int lo[3], hi[3];
+  bool empty;
+};
+__device__ __forceinline__ QueryRange query_range(const GridDesc& g, float qx, float qy, float qz,
+                                                  float rq) {
+  QueryRange r;
+  const float qq[3] = {qx, qy, qz};
+  r.empty = (g.n_valid == 0);
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    r.lo[a] = max(cell_of(qq[a] - rq, g.o[a], g.inv), 0);
+    r.hi[a] = min(cell_of(qq[a] + rq, g.o[a], g.inv), g.dims[a] - 1);
+    if (r.lo[a] > r.hi[a]) r.empty = true;
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: local frames, one wave per sample
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_frames(const float4* __restrict__ pts,
+                                               const float4* __restrict__ nrm,
+                                               const unsigned* __restrict__ cell, GridDesc g,
+                                               const HandConst* __restrict__ hc,
+                                               const float4* __restrict__ sample_q, int s,
+                                               unsigned long long slot_base,
+                                               unsigned long long seed, double* __restrict__ frames,
+                                               int* __restrict__ frame_ok, DevStats* st) {
+  __shared__ int buf[64];
+  __shared__ double Nsh[50][3];
+  __shared__ double Msh[6];
+  const int t = blockIdx.x;
+  if (t >= s) return;
+  const int lane = lane_id();
+  const float4 q = sample_q[t];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  QueryRange qr = query_range(g, q.x, q.y, q.z, hc->rq_taubin);
+  const bool usable = (q.w != 0.f) && !qr.empty;
+  const float r2 = hc->r2_taubin;
+  // pass 1: count neighbours with a finite normal (NaN-normal neighbours never enter the draw)
+  int k1f = 0;
+  if (usable) {
+    for (int cz = qr.lo[2]; cz <= qr.hi[2]; cz++)
+      for (int cy = qr.lo[1]; cy <= qr.hi[1]; cy++) {
+        const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
+        const int b = (int)cell[rowbase + qr.lo[0]], e = (int)cell[rowbase + qr.hi[0] + 1];
+        for (int j0 = b; j0 < e; j0 += 64) {
+          const int j = j0 + lane;
+          bool pred = false;
+          if (j < e) {
+            const float4 p = pts[j];
+            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < r2) {
+              const float4 nn = nrm[j];
+              pred = finite3(nn.x, nn.y, nn.z);
+            }
+          }
+          k1f += __popcll(__ballot(pred));
+        }
+      }
+  }
+  if (k1f == 0) {  // hand_search.cpp:122 (no neighbours => no frame)
+    if (lane == 0) frame_ok[t] = 0;
+    return;
+  }
+  const int m = min(50, k1f);                                        // :124-125
+  unsigned long long rj = 0;
+  if (lane < m) rj = draw_u64(seed, slot_base + (unsigned long long)t, (unsigned long long)lane) %
+                     (unsigned long long)k1f;                        // :130
+  // pass 2: resolve the drawn ranks to sorted positions
+  int pick = -1;
+  int base = 0;
+  for (int cz = qr.lo[2]; cz <= qr.hi[2]; cz++)
+    for (int cy = qr.lo[1]; cy <= qr.hi[1]; cy++) {
+      const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
+      const int b = (int)cell[rowbase + qr.lo[0]], e = (int)cell[rowbase + qr.hi[0] + 1];
+      for (int j0 = b; j0 < e; j0 += 64) {
+        const int j = j0 + lane;
+        bool pred = false;
+        if (j < e) {
+          const float4 p = pts[j];
+          const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+          const float d2 = (dx * dx + dy * dy) + dz * dz;
+          if (d2 < r2) {
+            const float4 nn = nrm[j];
+            pred = finite3(nn.x, nn.y, nn.z);
+          }
+        }
+        const unsigned long long mask = __ballot(pred);
+        const int cnt = __popcll(mask);
+        if (cnt) {
+          __syncthreads();
+          if (pred) buf[__popcll(mask & lt_mask)] = j;
+          __syncthreads();
+          if (lane < m && (long long)rj >= base && (long long)rj < base + cnt)
+            pick = buf[(int)rj - base];
+          base += cnt;
+        }
+      }
+    }
+  // drawn normals, one per lane; camera votes (:137-146)
+  double nx = 0.0, ny = 0.0, nz = 0.0;
+  int cam_bits = 0;
+  if (lane < m) {
+    const float4 nn = nrm[pick];
+    const double vx = (double)nn.x, vy = (double)nn.y, vz = (double)nn.z;
+    const double mag = __builtin_sqrt((vx * vx + vy * vy) + vz * vz);  // :148-149
+    nx = vx / mag;
+    ny = vy / mag;
+    nz = vz / mag;
+    cam_bits = __float_as_int(pts[pick].w);
+    Nsh[lane][0] = nx;
+    Nsh[lane][1] = ny;
+    Nsh[lane][2] = nz;
+  }
+  const int votes0 = __popcll(__ballot(lane < m && (cam_bits & 1)));
+  const int votes1 = __popcll(__ballot(lane < m && (cam_bits & 2)));
+  const int majority = (hc->n_cams > 1 && votes1 > votes0) ? 1 : 0;
+  __syncthreads();
+  // local_frame.cpp:29 M = N N^T, each entry summed over the draws in order
+  if (lane < 6) {
+    const int a = (lane < 3) ? 0 : (lane < 5 ? 1 : 2);
+    const int b = (lane < 3) ? lane : (lane < 5 ? lane - 2 : 2);
+    double acc = 0.0;
+    for (int j = 0; j < m; j++) acc = acc + Nsh[j][a] * Nsh[j][b];
+    Msh[lane] = acc;
+  }
+  // :42 column sums of (N^T N)^6
+  double colsum = -2.0;
+  if (lane < m) {
+    double acc = 0.0;
+    for (int i = 0; i < m; i++) {
+      const double gij = (Nsh[i][0] * nx + Nsh[i][1] * ny) + Nsh[i][2] * nz;
+      const double g2 = gij * gij;
+      acc = acc + (g2 * g2) * g2;
+    }
+    colsum = (acc == acc) ? acc : -2.0;  // NaN never wins (oracle: "acc > best" is false)
+  }
+  int best_i = (lane < m) ? lane : 0x7fffffff;
+  double best_v = colsum;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(best_v, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64);
+    if (ov > best_v || (ov == best_v && oi < best_i)) {
+      best_v = ov;
+      best_i = oi;
+    }
+  }
+  if (!(best_v > -1.0)) best_i = 0;
+  __syncthreads();
+  Sym3 M;
+  M.a00 = Msh[0]; M.a01 = Msh[1]; M.a02 = Msh[2]; M.a11 = Msh[3]; M.a12 = Msh[4]; M.a22 = Msh[5];
+  const Eig3 e = jacobi3(M);
+  const int mi = argmin3(e.d);                                        // :36-38
+  V3 cv{mi == 0 ? e.v[0][0] : (mi == 1 ? e.v[0][1] : e.v[0][2]),
+        mi == 0 ? e.v[1][0] : (mi == 1 ? e.v[1][1] : e.v[1][2]),
+        mi == 0 ? e.v[2][0] : (mi == 1 ? e.v[2][1] : e.v[2][2])};
+  const double ncv = norm3(cv);
+  cv = V3{cv.x / ncv, cv.y / ncv, cv.z / ncv};
+  const double nm0 = Nsh[best_i][0], nm1 = Nsh[best_i][1], nm2 = Nsh[best_i][2];
+  // :43-45 normal = normalize((I - c c^T) n_max)
+  const double cc[3] = {cv.x, cv.y, cv.z};
+  double np_[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const double p0 = ((a == 0) ? 1.0 : 0.0) - cc[a] * cc[0];
+    const double p1 = ((a == 1) ? 1.0 : 0.0) - cc[a] * cc[1];
+    const double p2 = ((a == 2) ? 1.0 : 0.0) - cc[a] * cc[2];
+    np_[a] = (p0 * nm0 + p1 * nm1) + p2 * nm2;
+  }
+  const V3 npv{np_[0], np_[1], np_[2]};
+  const double nn_ = norm3(npv);
+  V3 normal{npv.x / nn_, npv.y / nn_, npv.z / nn_};
+  V3 binormal = cross3(cv, normal);                                   // :48
+  const V3 sample{(double)q.x, (double)q.y, (double)q.z};
+  const V3 v{sample.x - hc->cam_origin[majority][0], sample.y - hc->cam_origin[majority][1],
+             sample.z - hc->cam_origin[majority][2]};                 // :51
+  if (dot3(normal, v) > 0.0) normal = neg3(normal);                   // :52-53
+  if (dot3(binormal, v) > 0.0) binormal = neg3(binormal);             // :54-55
+  const V3 curv = cross3(normal, binormal);                           // :58
+  if (lane == 0) {
+    double* f = frames + (size_t)t * 12;
+    f[0] = sample.x; f[1] = sample.y; f[2] = sample.z;
+    f[3] = normal.x; f[4] = normal.y; f[5] = normal.z;
+    f[6] = binormal.x; f[7] = binormal.y; f[8] = binormal.z;
+    f[9] = curv.x; f[10] = curv.y; f[11] = curv.z;
+    frame_ok[t] = 1;
+    atomicAdd(&st->n_frames, 1u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: hand sweep
+// ---------------------------------------------------------------------------------------------
+struct SweepArgs {
+  const float4* pts;
+  const float4* nrm;
+  const unsigned* cell;
+  GridDesc g;
+  const HandConst* hc;
+  const float4* sample_q;
+  const double* frames;
+  const int* frame_ok;
+  int n_samples;
+  int slot_base;
+  ag2_hypothesis* table;     // [n_samples * R]
+  long long* tab_off;        // arena offset per slot (-1: no list)
+  unsigned char* tab_keep;   // prune flag per slot
+  double* arena;             // 6 doubles per in-box point
+  long long arena_cap;       // points
+  int emit_lists;
+  DevStats* st;
+  int* overflow;             // LDS variant: appended; global variant: the work list
+  int n_overflow;            // global variant: list length
+  float* gscratch;           // global variant: 6 * gcap floats per block
+  int gcap;
+  float min_z;
+};
+
+struct Red {
+  double d[2][kSweepWaves][12];
+  unsigned u[2][kSweepWaves][4];
+  int i[2][kSweepWaves][2];
+};
+
+struct SweepShared {
+  int row_start[kMaxRows];
+  int row_pref[kMaxRows + 1];
+  Red red;
+  int wave_cnt[kSweepWaves + 1];
+  long long arena_off;
+  int flag;
+};
+
+template <bool LDS_STORE>
+__global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  SweepShared& S = *reinterpret_cast<SweepShared*>(smem_raw);
+  const int CAP = LDS_STORE ? kLdsCap : A.gcap;
+  float* pbase;
+  unsigned short* box16 = nullptr;
+  int* box32 = nullptr;
+  if (LDS_STORE) {
+    pbase = reinterpret_cast<float*>(smem_raw + ((sizeof(SweepShared) + 15) & ~size_t(15)));
+    box16 = reinterpret_cast<unsigned short*>(pbase + 6 * kLdsCap);
+  } else {
+    pbase = A.gscratch + (size_t)blockIdx.x * 7 * (size_t)A.gcap;
+    box32 = reinterpret_cast<int*>(pbase + 6 * (size_t)A.gcap);
+  }
+  float* PX = pbase;
+  float* PY = pbase + CAP;
+  float* PZ = pbase + 2 * (size_t)CAP;
+  float* NX = pbase + 3 * (size_t)CAP;
+  float* NY = pbase + 4 * (size_t)CAP;
+  float* NZ = pbase + 5 * (size_t)CAP;
+
+  const HandConst& hc = *A.hc;
+  const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int R = hc.R;
+  const double hh = hc.hand_height;
+  int red_sel = 0;
+  const int n_work = LDS_STORE ? A.n_samples : A.n_overflow;
+
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const int t = LDS_STORE ? w : A.overflow[w];
+    if (!A.frame_ok[t]) continue;  // uniform
+    const float4 q = A.sample_q[t];
+    const double* fr = A.frames + (size_t)t * 12;
+    const double smp[3] = {fr[0], fr[1], fr[2]};
+    // frame = [normal binormal curvature_axis] as columns, hand_search.cpp:325-326
+    const double F[3][3] = {{fr[3], fr[6], fr[9]}, {fr[4], fr[7], fr[10]}, {fr[5], fr[8], fr[11]}};
+
+    // ---- row table: one contiguous span of the sorted cloud per (cy, cz) -------------------
+    const QueryRange qr = query_range(A.g, q.x, q.y, q.z, hc.rq_hands);
+    const int ny = qr.empty ? 0 : (qr.hi[1] - qr.lo[1] + 1);
+    const int nz = qr.empty ? 0 : (qr.hi[2] - qr.lo[2] + 1);
+    const int nrows = ny * nz;  // <= kMaxRows by check_params
+    __syncthreads();            // previous sample's readers of S are done
+    {
+      int len[4], tot = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int r = tid * 4 + k;
+        len[k] = 0;
+        if (r < nrows) {
+          const int cz = qr.lo[2] + r / ny, cy = qr.lo[1] + r % ny;
+          const int rowbase = (cz * A.g.dims[1] + cy) * A.g.dims[0];
+          const int b = (int)A.cell[rowbase + qr.lo[0]], e = (int)A.cell[rowbase + qr.hi[0] + 1];
+          S.row_start[r] = b;
+          len[k] = e - b;
+        }
+        tot += len[k];
+      }
+      int inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+      }
+      if (lane == 63) S.wave_cnt[wid] = inc;
+      __syncthreads();
+      int woff = 0;
+      for (int k = 0; k < wid; k++) woff += S.wave_cnt[k];
+      int run = woff + inc - tot;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int r = tid * 4 + k;
+        if (r < nrows) S.row_pref[r] = run;
+        run += len[k];
+      }
+      if (tid == kSweepThreads - 1) S.row_pref[nrows] = run;  // rows beyond nrows have len 0
+      __syncthreads();
+    }
+    const int kcand = S.row_pref[nrows];
+
+    // ---- crop to the +-hand_height slab, ordered compaction (two passes, no barriers inside) ---
+    // each wave owns a contiguous quarter of the candidate sequence
+    const int seg = (((kcand + kSweepWaves - 1) / kSweepWaves) + 63) & ~63;
+    const int cbeg = min(wid * seg, kcand), cend = min(cbeg + seg, kcand);
+    auto test = [&](int gidx, float4& pout) -> int {  // 0: miss, 1: in radius, 3: in radius + slab
+      int lo = 0, hi = nrows;  // last row with row_pref <= gidx
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (S.row_pref[mid] <= gidx) lo = mid; else hi = mid;
+      }
+      const int pos = S.row_start[lo] + (gidx - S.row_pref[lo]);
+      const float4 p = A.pts[pos];
+      pout = make_float4(p.x - q.x, p.y - q.y, p.z - q.z, __int_as_float(pos));
+      const float d2 = (pout.x * pout.x + pout.y * pout.y) + pout.z * pout.z;
+      if (!(d2 < hc.r2_hands)) return 0;
+      // hand_search.cpp:209-210 centred in float then widened; :329-339 crop on row 2 of frame^T p
+      const double p0 = (double)pout.x, p1 = (double)pout.y, p2 = (double)pout.z;
+      const double zf = (F[0][2] * p0 + F[1][2] * p1) + F[2][2] * p2;
+      return (zf > -1.0 * hh && zf < hh) ? 3 : 1;
+    };
+    int my_keep = 0, my_k2 = 0;
+    for (int g0 = cbeg; g0 < cend; g0 += 64) {
+      const int gi = g0 + lane;
+      int r = 0;
+      float4 pp;
+      if (gi < cend) r = test(gi, pp);
+      my_k2 += __popcll(__ballot(r != 0));
+      my_keep += __popcll(__ballot(r == 3));
+    }
+    if (lane == 0) {
+      S.wave_cnt[wid] = my_keep;
+      S.red.i[0][wid][0] = my_k2;
+    }
+    __syncthreads();
+    int kbase = 0, K = 0, k2 = 0;
+    for (int k = 0; k < kSweepWaves; k++) {
+      if (k < wid) kbase += S.wave_cnt[k];
+      K += S.wave_cnt[k];
+      k2 += S.red.i[0][k][0];
+    }
+    const bool too_big = K > CAP;
+    if (too_big) {  // uniform
+      if (tid == 0) {
+        if (LDS_STORE) {
+          const unsigned at = atomicAdd(&A.st->n_overflow, 1u);
+          A.overflow[at] = t;
+        } else {
+          atomicOr(&A.st->err_flags, 8u);
+        }
+      }
+      continue;
+    }
+    if (tid == 0) {
+      atomicAdd(&A.st->sum_k2, (unsigned long long)k2);
+      atomicAdd(&A.st->sum_kcrop, (unsigned long long)K);
+    }
+    if (k2 == 0 || K == 0) continue;  // hand_search.cpp:201 / no cropped points => no fingers
+    {
+      int run = kbase;
+      for (int g0 = cbeg; g0 < cend; g0 += 64) {
+        const int gi = g0 + lane;
+        int r = 0;
+        float4 pp;
+        if (gi < cend) r = test(gi, pp);
+        const unsigned long long mask = __ballot(r == 3);
+        if (r == 3) {
+          const int dst = run + __popcll(mask & lt_mask);
+          const float4 nn = A.nrm[__float_as_int(pp.w)];
+          PX[dst] = pp.x; PY[dst] = pp.y; PZ[dst] = pp.z;
+          NX[dst] = nn.x; NY[dst] = nn.y; NZ[dst] = nn.z;
+        }
+        run += __popcll(mask);
+      }
+    }
+    __syncthreads();
+
+    // ---- orientations -----------------------------------------------------------------------
+    for (int oi = 0; oi < R; oi++) {
+      const double cs = hc.cos_t[oi], sn = hc.sin_t[oi];
+      // rot = [c -s 0; s c 0; 0 0 1], frame_rot = frame * rot, hand_search.cpp:356-357
+      double Fr[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        Fr[a][0] = (F[a][0] * cs + F[a][1] * sn) + F[a][2] * 0.0;
+        Fr[a][1] = (F[a][0] * (-1.0 * sn) + F[a][1] * cs) + F[a][2] * 0.0;
+        Fr[a][2] = (F[a][0] * 0.0 + F[a][1] * 0.0) + F[a][2] * 1.0;
+      }
+      // pass A: evaluateFingers(points_rot, init_bite), finger_hand.cpp:17-72, for all 20 slots
+      const double top0 = hc.init_bite, bottom0 = hc.init_bite - hc.hand_depth;
+      unsigned blocked = 0, flags = 0;  // flags bit0: some point has y < top, bit1: y < bottom
+      double miny = __builtin_inf();
+      for (int j = tid; j < K; j += kSweepThreads) {
+        const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
+        const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
+        const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
+        miny = (y < miny) ? y : miny;
+        if (y < top0) {
+          flags |= 1u;
+          if (y < bottom0) flags |= 2u;
+#pragma unroll
+          for (int k = 0; k < 20; k++)
+            if (x > hc.fs[k] && x < hc.fsr[k]) blocked |= (1u << k);
+        }
+      }
+      blocked = wave_or_u(blocked);
+      flags = wave_or_u(flags);
+      miny = wave_min_d(miny);
+      red_sel ^= 1;
+      if (lane == 0) {
+        S.red.u[red_sel][wid][0] = blocked;
+        S.red.u[red_sel][wid][1] = flags;
+        S.red.d[red_sel][wid][0] = miny;
+      }
+      __syncthreads();
+      blocked = 0;
+      flags = 0;
+      double surface = __builtin_inf();
+#pragma unroll
+      for (int k = 0; k < kSweepWaves; k++) {
+        blocked |= S.red.u[red_sel][k][0];
+        flags |= S.red.u[red_sel][k][1];
+        const double v = S.red.d[red_sel][k][0];
+        surface = (v < surface) ? v : surface;  // finger_hand.cpp:158 min over ALL rotated points
+      }
+      if ((flags & 2u) || !(flags & 1u)) continue;                  // finger_hand.cpp:35-36, :41-42
+      const unsigned free_ = (~blocked) & 0xFFFFFu;
+      if (!(__popc(free_) > 2)) continue;                           // hand_search.cpp:366
+      const unsigned hand = free_ & (free_ >> 10) & 0x3FFu;         // finger_hand.cpp:313-325
+      const int nvalid = __popc(hand);
+      if (!(nvalid > 0)) continue;                                  // hand_search.cpp:370
+      // deepenHand, finger_hand.cpp:96-134: middle valid hand = valid[ceil(n/2) - 1]
+      int idx = 0;
+      {
+        const int want = (nvalid + 1) / 2 - 1;
+        int seen = 0;
+        for (int k = 0; k < 10; k++)
+          if (hand & (1u << k)) {
+            if (seen == want) idx = k;
+            seen++;
+          }
+      }
+      const double fl0 = hc.fs[idx], fl1 = hc.fsr[idx], fr0 = hc.fs[10 + idx], fr1 = hc.fsr[10 + idx];
+      // pass B: first depth step that fails (some point under the finger pads or behind the hand)
+      int kfail = hc.n_depths;
+      for (int j = tid; j < K; j += kSweepThreads) {
+        const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
+        const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
+        const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
+        const bool zone = (x > fl0 && x < fl1) || (x > fr0 && x < fr1);
+        for (int di = 0; di < kfail; di++) {
+          const double d = hc.depths[di];
+          if (y < d && (zone || y < d - hc.hand_depth)) {
+            kfail = di;
+            break;
+          }
+        }
+      }
+      kfail = wave_min_i(kfail);
+      red_sel ^= 1;
+      if (lane == 0) S.red.i[red_sel][wid][0] = kfail;
+      __syncthreads();
+      kfail = hc.n_depths;
+#pragma unroll
+      for (int k = 0; k < kSweepWaves; k++) kfail = min(kfail, S.red.i[red_sel][k][0]);
+      double top = top0, bottom = bottom0;
+      if (kfail > 0) {  // last successful step, finger_hand.cpp:128-129
+        top = hc.depths[kfail - 1];
+        bottom = top - hc.hand_depth;
+      }
+      // closing region, finger_hand.cpp:137-180
+      const double left = hc.fs[idx] + hc.finger_width;
+      const double right = hc.fs[10 + idx];
+      const double center = 0.5 * (left + right);
+      // pass C: in-box points, ordered compaction (each wave a contiguous quarter of the list)
+      const int segk = (((K + kSweepWaves - 1) / kSweepWaves) + 63) & ~63;
+      const int jb = min(wid * segk, K), je = min(jb + segk, K);
+      int cnt = 0;
+      double mnx = __builtin_inf(), mxx = -__builtin_inf();
+      for (int j0 = jb; j0 < je; j0 += 64) {
+        const int j = j0 + lane;
+        bool in = false;
+        if (j < je) {
+          const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
+          const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
+          const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
+          in = (y < top && x > left && x < right);
+          if (in) {
+            mnx = (x < mnx) ? x : mnx;
+            mxx = (x > mxx) ? x : mxx;
+          }
+        }
+        cnt += __popcll(__ballot(in));
+      }
+      mnx = wave_min_d(mnx);
+      mxx = wave_max_d(mxx);
+      red_sel ^= 1;
+      if (lane == 0) {
+        S.red.i[red_sel][wid][0] = cnt;
+        S.red.d[red_sel][wid][0] = mnx;
+        S.red.d[red_sel][wid][1] = mxx;
+      }
+      __syncthreads();
+      int P = 0, pbase_w = 0;
+      mnx = __builtin_inf();
+      mxx = -__builtin_inf();
+#pragma unroll
+      for (int k = 0; k < kSweepWaves; k++) {
+        const int ck = S.red.i[red_sel][k][0];
+        if (k < wid) pbase_w += ck;
+        P += ck;
+        const double a = S.red.d[red_sel][k][0], b = S.red.d[red_sel][k][1];
+        mnx = (a < mnx) ? a : mnx;
+        mxx = (b > mxx) ? b : mxx;
+      }
+      if (P == 0) continue;                                         // hand_search.cpp:377-381
+      {
+        int run = pbase_w;
+        for (int j0 = jb; j0 < je; j0 += 64) {
+          const int j = j0 + lane;
+          bool in = false;
+          if (j < je) {
+            const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
+            const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
+            const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
+            in = (y < top && x > left && x < right);
+          }
+          const unsigned long long mask = __ballot(in);
+          if (in) {
+            const int dst = run + __popcll(mask & lt_mask);
+            if (LDS_STORE) box16[dst] = (unsigned short)j; else box32[dst] = j;
+          }
+          run += __popcll(mask);
+        }
+      }
+      const int slot = t * R + oi;
+      if (tid == 0) {
+        long long off = -1;
+        if (A.emit_lists) {
+          off = (long long)atomicAdd(&A.st->arena_top, (unsigned long long)P);
+          if (off + P > A.arena_cap) {
+            atomicOr(&A.st->err_flags, 1u);
+            off = -1;
+          }
+        }
+        S.arena_off = off;
+      }
+      __syncthreads();
+      const long long off = S.arena_off;
+      // pass D: unit-box scaling (hand_search.cpp:399-409), list emission, antipodal extents
+      const double baseline = 0.1;
+      const double left_const = left - 0.5 * (baseline - (right - left));
+      const double lower[3] = {left_const, bottom, -1.0 * hh};
+      const double scales[3] = {1.0 / baseline, 1.0 / (top - bottom), 1.0 / (2.0 * hh)};
+      const double lt = scales[0] * (mnx - lower[0]) + 0.003;       // antipodal.cpp:16
+      const double rt = scales[0] * (mxx - lower[0]) - 0.003;       // antipodal.cpp:17
+      int nl = 0, nr = 0;
+      double e[8] = {-__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf(),
+                     -__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf()};
+      // e: lmaxy lminy lmaxz lminz rmaxy rminy rmaxz rminz
+      for (int b = tid; b < P; b += kSweepThreads) {
+        const int j = LDS_STORE ? (int)box16[b] : box32[b];
+        const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
+        const double q0 = (double)NX[j], q1 = (double)NY[j], q2 = (double)NZ[j];
+        double X[3], Y[3], U[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          X[a] = (Fr[0][a] * p0 + Fr[1][a] * p1) + Fr[2][a] * p2;
+          Y[a] = (Fr[0][a] * q0 + Fr[1][a] * q1) + Fr[2][a] * q2;
+          U[a] = scales[a] * (X[a] - lower[a]);
+        }
+        if (off >= 0) {
+          double* dst = A.arena + (size_t)(off + b) * 6;
+          dst[0] = U[0]; dst[1] = U[1]; dst[2] = U[2];
+          dst[3] = Y[0]; dst[4] = Y[1]; dst[5] = Y[2];
+        }
+        const double ldot = (-1.0 * Y[0] + 0.0 * Y[1]) + 0.0 * Y[2];  // antipodal.cpp:20-25
+        const double rdot = (1.0 * Y[0] + 0.0 * Y[1]) + 0.0 * Y[2];
+        if (ldot > hc.cos_fc && U[0] < lt) {
+          nl++;
+          e[0] = (U[1] > e[0]) ? U[1] : e[0]; e[1] = (U[1] < e[1]) ? U[1] : e[1];
+          e[2] = (U[2] > e[2]) ? U[2] : e[2]; e[3] = (U[2] < e[3]) ? U[2] : e[3];
+        }
+        if (rdot > hc.cos_fc && U[0] > rt) {
+          nr++;
+          e[4] = (U[1] > e[4]) ? U[1] : e[4]; e[5] = (U[1] < e[5]) ? U[1] : e[5];
+          e[6] = (U[2] > e[6]) ? U[2] : e[6]; e[7] = (U[2] < e[7]) ? U[2] : e[7];
+        }
+      }
+      nl = wave_sum_i(nl);
+      nr = wave_sum_i(nr);
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        e[k] = wave_max_d(e[k]);
+        e[k + 1] = wave_min_d(e[k + 1]);
+      }
+      red_sel ^= 1;
+      if (lane == 0) {
+        S.red.i[red_sel][wid][0] = nl;
+        S.red.i[red_sel][wid][1] = nr;
+#pragma unroll
+        for (int k = 0; k < 8; k++) S.red.d[red_sel][wid][k] = e[k];
+      }
+      __syncthreads();
+      if (tid == 0) {
+        nl = nr = 0;
+        for (int k = 0; k < 8; k += 2) {
+          e[k] = -__builtin_inf();
+          e[k + 1] = __builtin_inf();
+        }
+        for (int wv = 0; wv < kSweepWaves; wv++) {
+          nl += S.red.i[red_sel][wv][0];
+          nr += S.red.i[red_sel][wv][1];
+          for (int k = 0; k < 8; k += 2) {
+            const double a = S.red.d[red_sel][wv][k], b = S.red.d[red_sel][wv][k + 1];
+            e[k] = (a > e[k]) ? a : e[k];
+            e[k + 1] = (b < e[k + 1]) ? b : e[k + 1];
+          }
+        }
+        int label = 0;
+        if (nl > 0 || nr > 0) label = 1;                              // antipodal.cpp:48-51
+        if (nl > 0 && nr > 0) {                                       // :54-81
+          const double top_y = (e[0] < e[4]) ? e[0] : e[4], bot_y = (e[1] > e[5]) ? e[1] : e[5];
+          const double top_z = (e[2] < e[6]) ? e[2] : e[6], bot_z = (e[3] > e[7]) ? e[3] : e[7];
+          if (top_y > bot_y && top_z > bot_z) label = 2;
+        }
+        ag2_hypothesis h;
+        const double ys[3] = {surface, bottom, top};
+        double* dstv[3] = {h.surface, h.bottom, h.top};
+        for (int k = 0; k < 3; k++)                                   // finger_hand.cpp:189-199
+          for (int a = 0; a < 3; a++)
+            dstv[k][a] = ((Fr[a][0] * center + Fr[a][1] * ys[k]) + Fr[a][2] * 0.0) + smp[a];
+        for (int a = 0; a < 3; a++) {                                 // hand_search.cpp:383-385
+          h.binormal[a] = Fr[a][0];
+          h.approach[a] = Fr[a][1];
+          h.axis[a] = Fr[a][2];
+        }
+        h.width = mxx - mnx;                                          // hand_search.cpp:397
+        h.score = 0.0;
+        h.sample_slot = A.slot_base + t;
+        h.orientation = oi;
+        h.half_antipodal = (label >= 1) ? 1 : 0;                      // hand_search.cpp:417-418
+        h.full_antipodal = (label == 2) ? 1 : 0;
+        h.reserved = 0;
+        h.n_points = P;
+        // pruneGraspsOnHandParameters, grasp_detector.cpp:363-395
+        bool keep = !(hc.filter_half && !h.half_antipodal);
+        if (keep) {
+          const double hw = 0.5 * hc.hand_outer_diameter;
+          double mn[3], mx[3];
+          for (int a = 0; a < 3; a++) {
+            const double c5[5] = {h.bottom[a] + hw * h.binormal[a], h.bottom[a] - hw * h.binormal[a],
+                                  h.top[a] + hw * h.binormal[a], h.top[a] - hw * h.binormal[a],
+                                  h.bottom[a] - 0.10 * h.approach[a]};
+            mn[a] = mx[a] = c5[0];
+            for (int k = 1; k < 5; k++) {
+              mn[a] = (c5[k] < mn[a]) ? c5[k] : mn[a];
+              mx[a] = (c5[k] > mx[a]) ? c5[k] : mx[a];
+            }
+          }
+          keep = h.width >= hc.min_aperture && h.width <= hc.max_aperture &&
+                 mn[2] >= (double)A.min_z && mn[1] >= (double)hc.ws_min_y &&
+                 mx[1] <= (double)hc.ws_max_y && mn[0] >= (double)hc.ws_min_x &&
+                 mx[0] <= (double)hc.ws_max_x;
+        }
+        A.table[slot] = h;
+        A.tab_off[slot] = off;
+        A.tab_keep[slot] = keep ? 1 : 0;
+        atomicAdd(&A.st->n_hyp, 1u);
+        atomicAdd(&A.st->sum_p, (unsigned long long)P);
+      }
+    }
+  }
+}
+
+static size_t sweep_lds_bytes(bool lds_store) {
+  size_t b = (sizeof(SweepShared) + 15) & ~size_t(15);
+  if (lds_store) b += (size_t)kLdsCap * 6 * 4 + (size_t)kLdsCap * 2;
+  return b;
+}
+
+int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed) {
+  if (s == 0) return 0;
+  hipLaunchKernelGGL(k_frames, dim3((unsigned)s), dim3(64), 0, c->stream, c->d_sorted.as<float4>(),
+                     c->d_nrm.as<float4>(), c->d_cell.as<unsigned>(), c->grid,
+                     c->d_hc.as<HandConst>(), c->d_sample_q.as<float4>(), (int)s,
+                     (unsigned long long)slot_base, (unsigned long long)seed,
+                     c->d_frames.as<double>(), c->d_frame_ok.as<int>(), c->d_stats.as<DevStats>());
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s) {
+  AG2_HIP(c, c->d_sample_q.reserve(std::max<size_t>(s, 1) * 16));
+  AG2_HIP(c, c->d_frames.reserve(std::max<size_t>(s, 1) * 12 * 8));
+  AG2_HIP(c, c->d_frame_ok.reserve(std::max<size_t>(s, 1) * 4));
+  if (s == 0) return 0;
+  AG2_HIP(c, hipMemsetAsync(c->d_frame_ok.p, 0, s * 4, c->stream));
+  if (sample_idx) {
+    AG2_HIP(c, c->d_tmp.reserve(s * 4));
+    AG2_HIP(c, hipMemcpyAsync(c->d_tmp.p, sample_idx, s * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_sample_queries_idx, dim3(((unsigned)s + 255) / 256), dim3(256), 0, c->stream,
+                       c->d_tmp.as<int>(), (int)s, c->d_xyz_in.as<float4>(), (int)c->n,
+                       c->d_sample_q.as<float4>());
+    AG2_HIP(c, hipGetLastError());
+    // the index buffer is consumed before d_tmp can be reused: same stream
+  } else {
+    std::vector<float> q(s * 4);
+    for (size_t i = 0; i < s; i++) {
+      // hand_search.cpp:261-263: sample.x = samples(0,i)  (double -> float)
+      const float x = (float)sample_xyz[3 * i], y = (float)sample_xyz[3 * i + 1],
+                  z = (float)sample_xyz[3 * i + 2];
+      const bool ok = std::isfinite(x) && std::isfinite(y) && std::isfinite(z);
+      q[4 * i] = x; q[4 * i + 1] = y; q[4 * i + 2] = z; q[4 * i + 3] = ok ? 1.f : 0.f;
+    }
+    AG2_HIP(c, hipMemcpyAsync(c->d_sample_q.p, q.data(), s * 16, hipMemcpyHostToDevice, c->stream));
+    AG2_HIP(c, hipStreamSynchronize(c->stream));  // q goes out of scope
+  }
+  return 0;
+}
+
+int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
+  const int R = c->p.num_orientations;
+  const size_t n_slots = s * (size_t)R;
+  AG2_HIP(c, c->d_table.reserve(std::max<size_t>(n_slots, 1) * sizeof(ag2_hypothesis)));
+  AG2_HIP(c, c->d_tab_off.reserve(std::max<size_t>(n_slots, 1) * 8));
+  AG2_HIP(c, c->d_tab_keep.reserve(std::max<size_t>(n_slots, 1)));
+  AG2_HIP(c, c->d_overflow.reserve(std::max<size_t>(s, 1) * 4));
+  if (s == 0) return 0;
+  if (emit_lists && c->arena_points == 0) {
+    c->arena_points = (size_t)16 << 20;  // 16 Mi points = 768 MiB; grown on AG2_ERR_CAPACITY
+  }
+  if (emit_lists) AG2_HIP(c, c->d_arena.reserve(c->arena_points * 48));
+  AG2_HIP(c, hipMemsetAsync(c->d_table.p, 0, n_slots * sizeof(ag2_hypothesis), c->stream));
+  AG2_HIP(c, hipMemsetAsync(c->d_tab_keep.p, 0, n_slots, c->stream));
+  SweepArgs A{};
+  A.pts = c->d_sorted.as<float4>();
+  A.nrm = c->d_nrm.as<float4>();
+  A.cell = c->d_cell.as<unsigned>();
+  A.g = c->grid;
+  A.hc = c->d_hc.as<HandConst>();
+  A.sample_q = c->d_sample_q.as<float4>();
+  A.frames = c->d_frames.as<double>();
+  A.frame_ok = c->d_frame_ok.as<int>();
+  A.n_samples = (int)s;
+  A.slot_base = (int)slot_base;
+  A.table = c->d_table.as<ag2_hypothesis>();
+  A.tab_off = c->d_tab_off.as<long long>();
+  A.tab_keep = c->d_tab_keep.as<unsigned char>();
+  A.arena = c->d_arena.as<double>();
+  A.arena_cap = emit_lists ? (long long)c->arena_points : 0;
+  A.emit_lists = emit_lists ? 1 : 0;
+  A.st = c->d_stats.as<DevStats>();
+  A.overflow = c->d_overflow.as<int>();
+  A.min_z = c->min_z;
+  const size_t lds = sweep_lds_bytes(true);
+  static bool attr_set = false;
+  if (!attr_set) {
+    AG2_HIP(c, hipFuncSetAttribute((const void*)k_sweep<true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int grid = (int)std::min<size_t>(s, 256 * 2);
+  hipLaunchKernelGGL(k_sweep<true>, dim3(grid), dim3(kSweepThreads), lds, c->stream, A);
+  AG2_HIP(c, hipGetLastError());
+  // overflow samples (cropped neighbourhood larger than the LDS stage): global-scratch variant
+  DevStats hs;
+  AG2_HIP(c, hipMemcpyAsync(&hs, c->d_stats.p, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  c->cnt.n_overflow_samples = hs.n_overflow;
+  if (hs.n_overflow > 0) {
+    const int gcap = 1 << 16;
+    const int g2 = (int)std::min<unsigned>(hs.n_overflow, 512u);
+    AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 7 * gcap * 4));
+    A.n_overflow = (int)hs.n_overflow;
+    A.gscratch = c->d_gscratch.as<float>();
+    A.gcap = gcap;
+    hipLaunchKernelGGL(k_sweep<false>, dim3(g2), dim3(kSweepThreads), sweep_lds_bytes(false),
+                       c->stream, A);
+    AG2_HIP(c, hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace ag2

@@ -1,0 +1,164 @@
+/*
+ * ag2_c.h -- C-ABI of libag2hip.so: the MI355X (gfx950) implementation of the agile_grasp2 hot
+ * path  sample -> normals -> local frames -> hand search -> grasp image -> LeNet score -> select.
+ *
+ * The reference (gwding/agile_grasp2) has NO plugin/FFI layer: its ROS node links the C++ classes
+ * directly (CMakeLists.txt:154-157).  This ABI is therefore the seam the C++ host mirror
+ * (the headers under include/agile_grasp2/) sits on; each entry point names the reference code it replaces
+ * (paths relative to the reference root).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - return 0 on success, a negative AG2_ERR_* otherwise; ag2_last_error() gives the message.
+ *     Nothing aborts (the reference aborts through glog CHECK, caffe_classifier.cpp:16-34).
+ *   - the caller owns every host buffer; the context owns all device memory.
+ *   - a context is single-threaded (the reference's HandSearch is not re-entrant either,
+ *     hand_search.cpp:14-15); distinct contexts, one per GPU, may run concurrently.
+ *   - matrices are column-major like Eigen's: "3 x n" means element (r, c) at [c*3 + r].
+ *   - there is no CPU fallback: without a usable HIP device ag2_create returns NULL.
+ */
+#ifndef AG2_C_H
+#define AG2_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AG2_ABI_VERSION 1
+
+enum {
+  AG2_OK = 0,
+  AG2_ERR_ARG = -1,       /* bad argument / call order */
+  AG2_ERR_HIP = -2,       /* HIP runtime error */
+  AG2_ERR_CAPACITY = -3,  /* an output or internal buffer is too small (message says which) */
+  AG2_ERR_STATE = -4      /* missing cloud / normals / weights */
+};
+
+typedef struct ag2_ctx ag2_ctx;
+
+/* Parameters: names and defaults of GraspDetector's ROS params (grasp_detector.cpp:19-80) and
+ * HandSearch::Parameters (include/agile_grasp2/hand_search.h:72-91). */
+typedef struct ag2_params {
+  double finger_width;        /* 0.01  */
+  double hand_outer_diameter; /* 0.09  */
+  double hand_depth;          /* 0.06  */
+  double hand_height;         /* 0.02  */
+  double init_bite;           /* 0.015 (launch files use 0.01) */
+  double nn_radius_taubin;    /* 0.01  */
+  double nn_radius_hands;     /* 0.1   */
+  double normals_radius;      /* 0.01, hard-coded at hand_search.cpp:91 */
+  double grid_cell;           /* 0.01, edge of the uniform search grid (replaces the FLANN kd-tree) */
+  int32_t num_orientations;   /* 8     */
+  int32_t num_threads;        /* kept for API parity; ignored on the GPU */
+  int32_t n_cams;             /* 1 or 2 */
+  int32_t filter_half_grasps; /* 1     */
+  double cam_origin[2][3];    /* translation column of cam_tf_left / cam_tf_right */
+  double workspace[6];        /* [minX maxX minY maxY minZ maxZ] */
+  double min_aperture;        /* 0.03 */
+  double max_aperture;        /* 0.07 */
+  double min_score_diff;      /* 500  */
+  int32_t num_selected;       /* 50   */
+  int32_t reserved;
+} ag2_params;
+
+/* One grasp hypothesis = the fixed part of GraspHypothesis
+ * (include/agile_grasp2/grasp_hypothesis.h:297-312).  176 bytes; this is also the slot of the
+ * fixed-slot candidate table exchanged between GPUs. */
+typedef struct ag2_hypothesis {
+  double axis[3], approach[3], binormal[3];
+  double surface[3], bottom[3], top[3];
+  double width;
+  double score;
+  int32_t sample_slot;  /* global sample slot = slot_base + position in the sample list */
+  int32_t orientation;  /* 0 .. num_orientations-1 */
+  uint8_t half_antipodal, full_antipodal;
+  uint16_t reserved;
+  int32_t n_points;     /* points in the closing region; 0 marks an empty table slot */
+} ag2_hypothesis;
+
+typedef struct ag2_counters {
+  int64_t n_points, n_valid_points, n_samples, n_frames, n_hypotheses, n_pruned, n_scored, n_selected;
+  int64_t sum_k1, sum_k2, sum_kcrop, sum_p;  /* measured neighbourhood sizes (roofline bytes) */
+  int64_t n_overflow_samples;                /* samples that took the global-memory sweep path */
+  int64_t reserved;
+} ag2_counters;
+
+/* Device time of the last call per stage, milliseconds (HIP events on the context's stream).
+ * Stage names follow the reference's own probes (hand_search.cpp:30,58,167,232;
+ * grasp_detector.cpp:210,254). */
+typedef struct ag2_times {
+  float grid_ms, normals_ms, hands_ms, images_ms, lenet_ms, select_ms, total_ms, reserved;
+} ag2_times;
+
+int ag2_abi_version(void);
+void ag2_default_params(ag2_params* p);
+
+/* Replaces the constructors of GraspDetector (grasp_detector.cpp:15-81) / HandSearch::setParameters
+ * (hand_search.cpp:64-80).  NULL when no HIP device is usable. */
+ag2_ctx* ag2_create(const ag2_params* p, int device_id);
+void ag2_destroy(ag2_ctx* c);
+const char* ag2_last_error(const ag2_ctx* c);
+/* Run on an existing HIP stream (hipStream_t), e.g. torch's current stream; NULL = own stream. */
+int ag2_set_stream(ag2_ctx* c, void* hip_stream);
+
+/* Replaces CloudCamera's data members (include/agile_grasp2/cloud_camera.h:178-183) and the kd-tree
+ * build (hand_search.cpp:11-12).  xyz: n points, stride_bytes apart (12 packed, 32 for
+ * pcl::PointXYZRGBA).  cam_source: n_cams x n int32 or NULL (= ones, cloud_camera.cpp:59).
+ * normals: 3 x n double or NULL. */
+int ag2_set_cloud(ag2_ctx* c, const float* xyz, size_t n, size_t stride_bytes,
+                  const int32_t* cam_source, int n_cams, const double* normals);
+/* Same, but xyz already lives in device memory (HBM-resident input for benchmarks/streams). */
+int ag2_set_cloud_device(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes);
+/* HandSearch::calculateNormalsOMP, hand_search.cpp:83-94. */
+int ag2_compute_normals(ag2_ctx* c);
+int ag2_get_normals(ag2_ctx* c, double* out3xn);
+/* sorted position -> original index for the n_valid finite points (tests / debugging). */
+int ag2_get_grid_perm(ag2_ctx* c, int32_t* perm, size_t cap, size_t* n_valid);
+/* HandSearch::calculateLocalFrames, hand_search.cpp:97-170 / :238-317 (tests / debugging):
+ * frames s x 12 doubles (sample, normal, binormal, curvature axis), valid[s]. */
+int ag2_local_frames(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
+                     uint64_t slot_base, uint64_t seed, double* frames_sx12, int32_t* valid);
+/* HandSearch::generateHypotheses, hand_search.cpp:4-61 (frames + evaluateHands + calculateHand).
+ * Exactly one of sample_idx (indices into the cloud, CloudCamera::getSampleIndices) and
+ * sample_xyz (3 x s, CloudCamera::getSamples) is non-NULL.  Output in sample order. */
+int ag2_generate_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz,
+                            size_t s, uint64_t slot_base, uint64_t seed, ag2_hypothesis* out,
+                            size_t cap, size_t* n_out);
+/* GraspHypothesis::getPointsForLearning / getNormalsForLearning of hypothesis h of the last
+ * generate call: 3 x n_points each. */
+int ag2_hyp_points(ag2_ctx* c, size_t h, double* pts3xp, double* nrm3xp);
+/* GraspDetector::pruneGraspsOnHandParameters, grasp_detector.cpp:363-395, on the last generate
+ * call's hypotheses. */
+int ag2_prune(ag2_ctx* c, uint8_t* keep, size_t n);
+/* Learning::createGraspImages, learning.cpp:4-33, for hypotheses [first, first+count) of the last
+ * generate call: count x 60 x 60 x 3 uint8 (HWC, channel order after the BGR2RGB swap). */
+int ag2_render_images(ag2_ctx* c, size_t first, size_t count, uint8_t* out_hwc);
+/* Same for caller-supplied point lists: hypothesis i owns columns [offsets[i], offsets[i+1]). */
+int ag2_render_images_from_points(ag2_ctx* c, size_t n, const int64_t* offsets_np1,
+                                  const double* pts3xp, const double* nrm3xp, uint8_t* out_hwc);
+/* Classifier ctor's CopyTrainedLayersFrom, caffe_classifier.cpp:13-14.  Caffe blob order. */
+int ag2_lenet_load(ag2_ctx* c, const float* conv1_w, const float* conv1_b, const float* conv2_w,
+                   const float* conv2_b, const float* ip1_w, const float* ip1_b,
+                   const float* ip2_w, const float* ip2_b);
+/* Classifier::ClassifyBatch / PredictBatch, caffe_classifier.cpp:70-127: n x 2 raw ip2 logits. */
+int ag2_lenet_forward(ag2_ctx* c, const uint8_t* images_hwc, size_t n, float* ip2_out);
+/* GraspDetector::detectGraspPoses, grasp_detector.cpp:84-282 (antipodal_mode PREDICTION, no
+ * clustering): hypotheses -> [prune] -> images -> LeNet -> score >= min_score_diff -> top
+ * num_selected by score.  scored_all (optional) receives every scored hypothesis in order. */
+int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
+               uint64_t slot_base, uint64_t seed, int do_prune, ag2_hypothesis* selected,
+               size_t cap, size_t* n_selected, ag2_hypothesis* scored_all, size_t cap_all,
+               size_t* n_scored);
+/* Fixed-slot candidate table of the last detect call: s * num_orientations records, slot
+ * (i * R + orientation), n_points == 0 where empty, score filled where scored.  Copied
+ * device-to-device into d_dst (e.g. a torch tensor) for the RCCL all-gather. */
+int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes);
+int ag2_get_counters(ag2_ctx* c, ag2_counters* out);
+int ag2_get_stage_times(ag2_ctx* c, ag2_times* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AG2_C_H */
