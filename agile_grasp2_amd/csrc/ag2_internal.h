@@ -96,9 +96,12 @@ struct ag2_ctx {
   ag2::DevBuf d_logits;    // float n_img x 2
   ag2::DevBuf d_act1;      // LeNet intermediates (pooled2: n x 7200 float)
   ag2::DevBuf d_tmp;       // misc staging
+  ag2::DevBuf d_flags;     // uint32 flags / prefix for slot compaction
+  ag2::DevBuf d_desc;      // image descriptors: int64 arena offset[n] then int32 count[n]
   std::vector<ag2_hypothesis> h_hyps;   // compacted hypotheses of the last generate call
   std::vector<int32_t> h_slots;         // their slot ids
   std::vector<int64_t> h_offsets;       // their arena offsets
+  std::vector<uint8_t> h_keep;          // their prune flags
   size_t n_img = 0;
 
   ag2::LeNetDev net;
@@ -124,14 +127,18 @@ int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n);
 // k_normals.hip
 int launch_normals(ag2_ctx* c);
 // k_sweep.hip
+int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s);
 int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed);
 int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists);
 // k_select.hip
 int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out);
-int launch_scatter_scores(ag2_ctx* c, size_t n_img);
+int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypothesis>& recs,
+                   std::vector<int64_t>* offs, std::vector<uint8_t>* keep);
+int make_image_descs(ag2_ctx* c, const int* d_list, size_t n);
+int launch_scatter_scores(ag2_ctx* c, const int* d_list, size_t n_img);
 // k_image.hip
-int launch_render(ag2_ctx* c, const int* d_slot_list, size_t n_img, const double* d_arena,
-                  const long long* d_offsets, const int* d_counts, uint8_t* d_out);
+int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, const int* d_cnt,
+                  size_t n_img, uint8_t* d_out);
 // k_lenet.hip
 int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const float* c2w,
                        const float* c2b, const float* f1w, const float* f1b, const float* f2w,

@@ -1,0 +1,206 @@
+// ag2_pipeline.hip -- C-ABI entry points of the hypothesis path: frames, hand sweep, prune,
+// images, LeNet scoring, selection.  Orchestration only; the kernels live in k_*.hip.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "ag2_internal.h"
+
+using namespace ag2;
+
+namespace {
+
+int check_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz) {
+  if (!c->has_cloud) return set_err(c, AG2_ERR_STATE, "no cloud set");
+  if (!c->has_normals)
+    return set_err(c, AG2_ERR_STATE, "normals missing: call ag2_compute_normals or pass normals");
+  if ((sample_idx == nullptr) == (sample_xyz == nullptr))
+    return set_err(c, AG2_ERR_ARG, "exactly one of sample_idx / sample_xyz must be given");
+  return 0;
+}
+
+int reset_stats(ag2_ctx* c) {
+  // keep bounds (grid) intact: zero everything before them
+  AG2_HIP(c, hipMemsetAsync(c->d_stats.p, 0, offsetof(DevStats, bounds), c->stream));
+  return 0;
+}
+
+int read_stats(ag2_ctx* c, DevStats* hs) {
+  AG2_HIP(c, hipMemcpyAsync(hs, c->d_stats.p, sizeof(DevStats), hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// frames + sweep for s samples; fills the slot table (and the arena when emit_lists).
+int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
+                   uint64_t slot_base, uint64_t seed, bool emit_lists) {
+  if (s * (size_t)c->p.num_orientations > ((size_t)1 << 30))
+    return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 table slots");
+  c->s = s;
+  c->slot_base = slot_base;
+  for (int attempt = 0; attempt < 6; attempt++) {
+    int rc = reset_stats(c);
+    if (rc) return rc;
+    rc = upload_samples(c, sample_idx, sample_xyz, s);
+    if (rc) return rc;
+    rc = launch_frames(c, s, slot_base, seed);
+    if (rc) return rc;
+    rc = launch_sweep(c, s, slot_base, emit_lists);
+    if (rc) return rc;
+    DevStats hs;
+    rc = read_stats(c, &hs);
+    if (rc) return rc;
+    if (hs.err_flags & 8u)
+      return set_err(c, AG2_ERR_CAPACITY,
+                     "a cropped neighbourhood exceeds the global sweep scratch (65536 points)");
+    if (hs.err_flags & 1u) {  // arena too small: grow to what this run asked for, retry
+      c->arena_points = std::max<size_t>((size_t)hs.arena_top + ((size_t)hs.arena_top >> 3), c->arena_points * 2);
+      continue;
+    }
+    c->cnt.n_samples = (int64_t)s;
+    c->cnt.n_frames = hs.n_frames;
+    c->cnt.n_hypotheses = hs.n_hyp;
+    c->cnt.sum_k2 = (int64_t)hs.sum_k2;
+    c->cnt.sum_kcrop = (int64_t)hs.sum_kcrop;
+    c->cnt.sum_p = (int64_t)hs.sum_p;
+    return 0;
+  }
+  return set_err(c, AG2_ERR_CAPACITY, "point-list arena could not be sized");
+}
+
+}  // namespace
+
+extern "C" {
+
+int ag2_local_frames(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
+                     uint64_t slot_base, uint64_t seed, double* frames, int32_t* valid) {
+  if (!c) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  int rc = check_samples(c, sample_idx, sample_xyz);
+  if (rc) return rc;
+  rc = reset_stats(c);
+  if (rc) return rc;
+  rc = upload_samples(c, sample_idx, sample_xyz, s);
+  if (rc) return rc;
+  rc = launch_frames(c, s, slot_base, seed);
+  if (rc) return rc;
+  if (s) {
+    AG2_HIP(c, hipMemcpyAsync(frames, c->d_frames.p, s * 96, hipMemcpyDeviceToHost, c->stream));
+    AG2_HIP(c, hipMemcpyAsync(valid, c->d_frame_ok.p, s * 4, hipMemcpyDeviceToHost, c->stream));
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < s; i++)
+      if (!valid[i])
+        for (int k = 0; k < 12; k++) frames[12 * i + k] = 0.0;
+  }
+  return 0;
+}
+
+int ag2_generate_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz,
+                            size_t s, uint64_t slot_base, uint64_t seed, ag2_hypothesis* out,
+                            size_t cap, size_t* n_out) {
+  if (!c || !n_out) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  int rc = check_samples(c, sample_idx, sample_xyz);
+  if (rc) return rc;
+  AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
+  rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true);
+  if (rc) return rc;
+  AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
+  size_t nh = 0;
+  rc = compact_slots(c, s * (size_t)c->p.num_orientations, 0, c->d_list, &nh);
+  if (rc) return rc;
+  std::vector<uint8_t> keep;
+  rc = gather_records(c, c->d_list.as<int>(), nh, c->h_hyps, &c->h_offsets, &keep);
+  if (rc) return rc;
+  c->h_keep = keep;
+  c->h_slots.resize(nh);
+  if (nh) {
+    AG2_HIP(c, hipMemcpy(c->h_slots.data(), c->d_list.p, nh * 4, hipMemcpyDeviceToHost));
+  }
+  (void)hipEventElapsedTime(&c->times.hands_ms, c->ev[0], c->ev[1]);
+  *n_out = nh;
+  if (nh > cap) return set_err(c, AG2_ERR_CAPACITY, "generate_hypotheses: output capacity too small");
+  if (nh) memcpy(out, c->h_hyps.data(), nh * sizeof(ag2_hypothesis));
+  return 0;
+}
+
+int ag2_hyp_points(ag2_ctx* c, size_t h, double* pts, double* nrm) {
+  if (!c || !pts || !nrm) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (h >= c->h_hyps.size()) return set_err(c, AG2_ERR_ARG, "hypothesis index out of range");
+  const int P = c->h_hyps[h].n_points;
+  const int64_t off = c->h_offsets[h];
+  if (off < 0) return set_err(c, AG2_ERR_STATE, "no point list stored for this hypothesis");
+  std::vector<double> buf((size_t)P * 6);
+  AG2_HIP(c, hipMemcpy(buf.data(), c->d_arena.as<double>() + (size_t)off * 6, (size_t)P * 48,
+                       hipMemcpyDeviceToHost));
+  for (int b = 0; b < P; b++)
+    for (int k = 0; k < 3; k++) {
+      pts[3 * b + k] = buf[6 * (size_t)b + k];
+      nrm[3 * b + k] = buf[6 * (size_t)b + 3 + k];
+    }
+  return 0;
+}
+
+int ag2_prune(ag2_ctx* c, uint8_t* keep, size_t n) {
+  if (!c || !keep) return AG2_ERR_ARG;
+  if (n != c->h_hyps.size()) return set_err(c, AG2_ERR_ARG, "prune: size mismatch");
+  for (size_t i = 0; i < n; i++) keep[i] = c->h_keep[i] ? 1 : 0;
+  return 0;
+}
+
+int ag2_render_images(ag2_ctx* c, size_t first, size_t count, uint8_t* out) {
+  if (!c || !out) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (first + count > c->h_hyps.size()) return set_err(c, AG2_ERR_ARG, "render: range");
+  if (count == 0) return 0;
+  AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
+  int rc = make_image_descs(c, c->d_list.as<int>() + first, count);
+  if (rc) return rc;
+  AG2_HIP(c, c->d_images.reserve(count * 10800));
+  rc = launch_render(c, c->d_arena.as<double>(), c->d_desc.as<long long>(),
+                     (const int*)(c->d_desc.as<long long>() + count), count,
+                     c->d_images.as<uint8_t>());
+  if (rc) return rc;
+  AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
+  AG2_HIP(c, hipMemcpyAsync(out, c->d_images.p, count * 10800, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  (void)hipEventElapsedTime(&c->times.images_ms, c->ev[0], c->ev[1]);
+  return 0;
+}
+
+int ag2_render_images_from_points(ag2_ctx* c, size_t n, const int64_t* offsets, const double* pts,
+                                  const double* nrm, uint8_t* out) {
+  if (!c || !offsets || !out) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (n == 0) return 0;
+  const size_t tot = (size_t)offsets[n];
+  std::vector<double> inter(std::max<size_t>(tot, 1) * 6);
+  for (size_t b = 0; b < tot; b++)
+    for (int k = 0; k < 3; k++) {
+      inter[6 * b + k] = pts[3 * b + k];
+      inter[6 * b + 3 + k] = nrm[3 * b + k];
+    }
+  std::vector<long long> off(n);
+  std::vector<int> cnt(n);
+  for (size_t i = 0; i < n; i++) {
+    off[i] = offsets[i];
+    cnt[i] = (int)(offsets[i + 1] - offsets[i]);
+  }
+  AG2_HIP(c, c->d_tmp.reserve(inter.size() * 8));
+  AG2_HIP(c, c->d_desc.reserve(n * 12));
+  AG2_HIP(c, c->d_images.reserve(n * 10800));
+  long long* d_off = c->d_desc.as<long long>();
+  int* d_cnt = (int*)(d_off + n);
+  AG2_HIP(c, hipMemcpyAsync(c->d_tmp.p, inter.data(), inter.size() * 8, hipMemcpyHostToDevice, c->stream));
+  AG2_HIP(c, hipMemcpyAsync(d_off, off.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+  AG2_HIP(c, hipMemcpyAsync(d_cnt, cnt.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  const int rc = launch_render(c, c->d_tmp.as<double>(), d_off, d_cnt, n, c->d_images.as<uint8_t>());
+  if (rc) return rc;
+  AG2_HIP(c, hipMemcpyAsync(out, c->d_images.p, n * 10800, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// k_select.hip -- K6: order-preserving compaction of the fixed-slot candidate table, score
+// scatter and the score threshold.
+//
+// Replaces the list concatenation of HandSearch::evaluateHands (src/agile_grasp2/
+// hand_search.cpp:223-228), the survivor list of GraspDetector::pruneGraspsOnHandParameters
+// (grasp_detector.cpp:363-395; the predicate itself is evaluated inside k_sweep) and the
+// score >= min_score_diff filter (grasp_detector.cpp:198-207).  Slot order (sample, orientation)
+// IS the reference's output order, so a flag + exclusive scan + scatter keeps it.
+#include "ag2_internal.h"
+
+namespace ag2 {
+
+// mode 0: slot holds a hypothesis; 1: hypothesis that survives the prune; 2: scored hypothesis
+// with score >= thr
+__global__ void k_slot_flags(const ag2_hypothesis* __restrict__ table,
+                             const unsigned char* __restrict__ keep, int n_slots, int mode,
+                             double thr, unsigned* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_slots) return;
+  unsigned f = 0;
+  if (i < n_slots) {
+    const bool valid = table[i].n_points > 0;
+    if (mode == 0) f = valid;
+    else if (mode == 1) f = valid && keep[i];
+    else f = valid && keep[i] == 2 && table[i].score >= thr;
+  }
+  flags[i] = f;
+}
+
+__global__ void k_slot_scatter(const unsigned* __restrict__ pref, int n_slots,
+                               int* __restrict__ list) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  if (pref[i + 1] != pref[i]) list[pref[i]] = i;
+}
+
+int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out) {
+  *n_out = 0;
+  if (n_slots == 0) return 0;
+  AG2_HIP(c, c->d_flags.reserve((n_slots + 1) * 4));
+  AG2_HIP(c, out_list.reserve(n_slots * 4));
+  unsigned* fl = c->d_flags.as<unsigned>();
+  const int nb = ((int)n_slots + 1 + 255) / 256;
+  hipLaunchKernelGGL(k_slot_flags, dim3(nb), dim3(256), 0, c->stream,
+                     c->d_table.as<ag2_hypothesis>(), c->d_tab_keep.as<unsigned char>(),
+                     (int)n_slots, mode, c->p.min_score_diff, fl);
+  const int rc = scan_exclusive_u32(c, fl, (int)n_slots + 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_slot_scatter, dim3(nb), dim3(256), 0, c->stream, fl, (int)n_slots,
+                     out_list.as<int>());
+  unsigned total = 0;
+  AG2_HIP(c, hipMemcpyAsync(&total, fl + n_slots, 4, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  *n_out = total;
+  return 0;
+}
+
+// image descriptors (arena offset, point count) of the listed slots
+__global__ void k_image_descs(const ag2_hypothesis* __restrict__ table,
+                              const long long* __restrict__ tab_off, const int* __restrict__ list,
+                              int n, long long* __restrict__ desc_off, int* __restrict__ desc_cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = list[i];
+  desc_off[i] = tab_off[s];
+  desc_cnt[i] = table[s].n_points;
+}
+
+// score = ip2[1] - ip2[0] (grasp_detector.cpp:200), written back into the table slot; keep := 2
+// marks "scored".
+__global__ void k_scatter_scores(const float* __restrict__ logits, const int* __restrict__ list,
+                                 int n, ag2_hypothesis* __restrict__ table,
+                                 unsigned char* __restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = list[i];
+  const float sc = logits[2 * i + 1] - logits[2 * i];
+  table[s].score = (double)sc;
+  keep[s] = 2;
+}
+
+__global__ void k_gather_records(const ag2_hypothesis* __restrict__ table,
+                                 const long long* __restrict__ tab_off,
+                                 const unsigned char* __restrict__ keep,
+                                 const int* __restrict__ list, int n,
+                                 ag2_hypothesis* __restrict__ out, long long* __restrict__ out_off,
+                                 unsigned char* __restrict__ out_keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = list[i];
+  out[i] = table[s];
+  if (out_off) out_off[i] = tab_off[s];
+  if (out_keep) out_keep[i] = keep[s];
+}
+
+int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypothesis>& recs,
+                   std::vector<int64_t>* offs, std::vector<uint8_t>* keep) {
+  recs.resize(n);
+  if (offs) offs->resize(n);
+  if (keep) keep->resize(n);
+  if (n == 0) return 0;
+  const size_t bytes = n * (sizeof(ag2_hypothesis) + 8 + 1) + 64;
+  AG2_HIP(c, c->d_tmp.reserve(bytes));
+  ag2_hypothesis* d_rec = c->d_tmp.as<ag2_hypothesis>();
+  long long* d_off = (long long*)(d_rec + n);
+  unsigned char* d_keep = (unsigned char*)(d_off + n);
+  hipLaunchKernelGGL(k_gather_records, dim3(((int)n + 255) / 256), dim3(256), 0, c->stream,
+                     c->d_table.as<ag2_hypothesis>(), c->d_tab_off.as<long long>(),
+                     c->d_tab_keep.as<unsigned char>(), d_list, (int)n, d_rec, d_off, d_keep);
+  AG2_HIP(c, hipMemcpyAsync(recs.data(), d_rec, n * sizeof(ag2_hypothesis), hipMemcpyDeviceToHost, c->stream));
+  if (offs) AG2_HIP(c, hipMemcpyAsync(offs->data(), d_off, n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (keep) AG2_HIP(c, hipMemcpyAsync(keep->data(), d_keep, n, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int make_image_descs(ag2_ctx* c, const int* d_list, size_t n) {
+  AG2_HIP(c, c->d_desc.reserve(std::max<size_t>(n, 1) * 12));
+  if (n == 0) return 0;
+  long long* d_off = c->d_desc.as<long long>();
+  int* d_cnt = (int*)(d_off + n);
+  hipLaunchKernelGGL(k_image_descs, dim3(((int)n + 255) / 256), dim3(256), 0, c->stream,
+                     c->d_table.as<ag2_hypothesis>(), c->d_tab_off.as<long long>(), d_list, (int)n,
+                     d_off, d_cnt);
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+int launch_scatter_scores(ag2_ctx* c, const int* d_list, size_t n_img) {
+  if (n_img == 0) return 0;
+  hipLaunchKernelGGL(k_scatter_scores, dim3(((int)n_img + 255) / 256), dim3(256), 0, c->stream,
+                     c->d_logits.as<float>(), d_list, (int)n_img, c->d_table.as<ag2_hypothesis>(),
+                     c->d_tab_keep.as<unsigned char>());
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+}  // namespace ag2

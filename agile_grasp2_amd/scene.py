@@ -85,14 +85,15 @@ def _sphere(rng, centre, radius, density):
 
 
 def make_scene(seed: int, n_target: int, kind: str = "tabletop", voxel: float | None = VOXEL,
-               noise: float = 0.001):
+               noise: float = 0.001, spacing: float = 0.001):
     """Return (xyz float32 [N,3], workspace[6]).  N is within about 1 % of n_target.
 
     kind: "tabletop" (table + clutter), "objects" (no table), "plane" (table only).
-    voxel=None skips voxelisation (BASELINE config 3: dense un-voxelised clutter).
+    voxel=None skips voxelisation (BASELINE config 3: dense un-voxelised clutter); the raw
+    samples then have a mean spacing of `spacing` metres.
     """
     rng = np.random.default_rng(seed)
-    cell = VOXEL if voxel is None else voxel
+    cell = spacing if voxel is None else voxel
     per_pt = cell * cell  # surface area per voxelised point
     density = (4.0 if voxel is not None else 1.05) / per_pt  # raw samples per m^2
     table_frac = {"tabletop": 0.55, "objects": 0.0, "plane": 1.0}[kind]

@@ -1,0 +1,178 @@
+"""GPU parity, K2 + K3 + K4 + prune: local frames, hand sweep, point lists, prune flags and grasp
+images, HIP (through the C-ABI) vs the oracle on the same seeded inputs.
+
+Bars: labels / indices / counts / image bytes bit-exact.  Poses: the north-star tolerance is 1e-4;
+because both sides execute the same IEEE op sequence the tests demand bit equality and would
+report the max deviation if that ever failed.
+"""
+import numpy as np
+import pytest
+
+from conftest import scene_params
+from agile_grasp2_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+VEC = ("axis", "approach", "binormal", "surface", "bottom", "top")
+
+
+def make_pair(xyz, ws, cam_source=None, normals=None, **kw):
+    from agile_grasp2_amd import capi
+    from oracle import api
+    prm = scene_params(ws, **kw)
+    o = api.Oracle(**dict(prm, num_threads=8))
+    d = capi.Detector(**prm)
+    for x in (o, d):
+        x.set_cloud(xyz, cam_source=cam_source, normals=normals)
+        if normals is None:
+            x.compute_normals()
+    return o, d
+
+
+def assert_hyps_equal(got, want):
+    assert len(got) == len(want)
+    for f in ("sample_slot", "orientation", "half_antipodal", "full_antipodal", "n_points"):
+        assert np.array_equal(got[f], want[f]), f
+    for f in VEC + ("width",):
+        if not np.array_equal(got[f], want[f]):
+            dev = np.abs(got[f] - want[f]).max()
+            raise AssertionError(f"{f}: not bit-identical, max |diff| = {dev:g} (north-star tol 1e-4)")
+
+
+def check_lists_and_images(o, d, hyps, stride=1):
+    n = len(hyps)
+    for k in range(0, n, stride):
+        p = int(hyps[k]["n_points"])
+        gp, gn = d.hyp_points(k, p)
+        wp, wn = o.hyp_points(k, p)
+        assert np.array_equal(gp, wp) and np.array_equal(gn, wn, equal_nan=True), k
+    gi = d.render_images(0, n)
+    wi = o.render_images(0, n)
+    assert np.array_equal(gi, wi)
+    assert np.array_equal(d.prune(n), o.prune(n))
+    return gi
+
+
+def test_frames_bit_exact(small_scene):
+    xyz, ws, idx = small_scene
+    o, d = make_pair(xyz, ws)
+    gf, gv = d.local_frames(sample_idx=idx, slot_base=5, seed=77)
+    wf, wv = o.local_frames(sample_idx=idx, slot_base=5, seed=77)
+    assert np.array_equal(gv, wv)
+    assert np.array_equal(gf.view(np.uint64), wf.view(np.uint64))
+    d.close()
+
+
+def test_hypotheses_small_scene(small_scene):
+    xyz, ws, idx = small_scene
+    o, d = make_pair(xyz, ws)
+    got = d.generate_hypotheses(sample_idx=idx, seed=5)
+    want = o.generate_hypotheses(sample_idx=idx, seed=5)
+    assert len(want) > 20
+    assert_hyps_equal(got, want)
+    imgs = check_lists_and_images(o, d, want)
+    assert imgs.max() > 0
+    gc, wc = d.counters(), o.counters()
+    for f in ("n_frames", "n_hypotheses", "sum_k2", "sum_kcrop", "sum_p"):
+        assert getattr(gc, f) == getattr(wc, f), f
+    d.close()
+
+
+def test_hypotheses_xyz_samples_and_slot_base(small_scene):
+    xyz, ws, idx = small_scene
+    o, d = make_pair(xyz, ws)
+    rng = np.random.default_rng(8)
+    sx = (xyz[idx[:40]].astype(np.float64) + rng.normal(scale=0.004, size=(40, 3))).T
+    sx[:, 3] = [10.0, 10.0, 10.0]   # far outside the grid: no neighbours
+    sx[:, 4] = np.nan               # invalid sample
+    got = d.generate_hypotheses(sample_xyz=sx, slot_base=1000, seed=6)
+    want = o.generate_hypotheses(sample_xyz=sx, slot_base=1000, seed=6)
+    assert len(want) > 3
+    assert want["sample_slot"].min() >= 1000
+    assert_hyps_equal(got, want)
+    check_lists_and_images(o, d, want)
+    d.close()
+
+
+def test_two_cameras_and_given_normals():
+    xyz, ws = scene.make_scene(seed=12, n_target=5000, kind="objects")
+    n = xyz.shape[0]
+    cam = np.zeros((2, n), dtype=np.int32)
+    cam[0, : n // 3] = 1
+    cam[1, n // 3:] = 1
+    cams = [scene.CAMERA, scene.CAMERA + np.array([0.0, 0.6, 0.1])]
+    o, d = make_pair(xyz, ws, cam_source=cam, n_cams=2, cam_origin=cams)
+    idx = scene.draw_samples(2, n, 100)
+    got = d.generate_hypotheses(sample_idx=idx, seed=1)
+    want = o.generate_hypotheses(sample_idx=idx, seed=1)
+    assert_hyps_equal(got, want)
+    # externally supplied normals (CloudCamera with normals, cloud_camera.cpp:4-32)
+    nrm = o.get_normals()
+    o2, d2 = make_pair(xyz, ws, cam_source=cam, normals=nrm, n_cams=2, cam_origin=cams)
+    got2 = d2.generate_hypotheses(sample_idx=idx, seed=1)
+    want2 = o2.generate_hypotheses(sample_idx=idx, seed=1)
+    assert_hyps_equal(got2, want2)
+    assert_hyps_equal(got2, want)
+    d.close()
+    d2.close()
+
+
+def test_sixteen_orientations_filter_half(small_scene):
+    xyz, ws, idx = small_scene
+    o, d = make_pair(xyz, ws, num_orientations=16, filter_half_grasps=1, init_bite=0.015)
+    got = d.generate_hypotheses(sample_idx=idx[:80], seed=3)
+    want = o.generate_hypotheses(sample_idx=idx[:80], seed=3)
+    assert want["orientation"].max() > 8
+    assert_hyps_equal(got, want)
+    check_lists_and_images(o, d, want, stride=2)
+    d.close()
+
+
+def test_config1_scene_500_samples():
+    """BASELINE config 1 size: ~50k points, 500 samples, 8 orientations."""
+    xyz, ws = scene.make_scene(seed=21, n_target=50000)
+    idx = scene.draw_samples(21, xyz.shape[0], 500)
+    o, d = make_pair(xyz, ws)
+    got = d.generate_hypotheses(sample_idx=idx, seed=21)
+    want = o.generate_hypotheses(sample_idx=idx, seed=21)
+    assert len(want) > 100
+    assert_hyps_equal(got, want)
+    check_lists_and_images(o, d, want, stride=7)
+    d.close()
+
+
+def test_dense_unvoxelised_cloud_overflow_path():
+    """Un-voxelised dense clutter (config 3 style): cropped neighbourhoods exceed the LDS stage,
+    so the global-scratch instantiation of the sweep must give the same answers."""
+    xyz, ws = scene.make_scene(seed=4, n_target=120000, kind="objects", voxel=None)
+    idx = scene.draw_samples(4, xyz.shape[0], 60)
+    o, d = make_pair(xyz, ws, num_orientations=16)
+    got = d.generate_hypotheses(sample_idx=idx, seed=9)
+    want = o.generate_hypotheses(sample_idx=idx, seed=9)
+    assert_hyps_equal(got, want)
+    assert d.counters().n_overflow_samples > 0
+    check_lists_and_images(o, d, want, stride=5)
+    d.close()
+
+
+def test_images_from_points_edge_cases():
+    from agile_grasp2_amd import capi
+    from oracle import api
+    o = api.Oracle()
+    d = capi.Detector()
+    rng = np.random.default_rng(3)
+    lists = []
+    # empty list, single NaN normal, aliasing x-cell >= 60, dense collisions, out-of-range cells
+    lists.append((np.zeros((3, 0)), np.zeros((3, 0))))
+    lists.append((np.array([[0.5], [0.0], [0.5]]), np.array([[np.nan], [0.0], [1.0]])))
+    lists.append((np.array([[1.0 + 1e-9, 0.2], [0.0, 0.5], [0.5, 0.5]]), np.array([[1.0, 0.0], [0.0, 0.0], [0.0, 1.0]])))
+    u = rng.uniform(0.15, 0.85, size=(3, 5000))
+    u[:, :2000] = np.round(u[:, :2000] * 20) / 20.0
+    lists.append((u, rng.normal(size=(3, 5000))))
+    u2 = rng.uniform(-0.5, 1.5, size=(3, 300))
+    lists.append((u2, rng.normal(size=(3, 300))))
+    got = d.render_images_from_points([a for a, _ in lists], [b for _, b in lists])
+    for k, (a, b) in enumerate(lists):
+        want = o.render_image_from_points(a, b) if a.shape[1] else np.zeros((60, 60, 3), np.uint8)
+        assert np.array_equal(got[k], want), k
+    d.close()
