@@ -204,3 +204,110 @@ int ag2_render_images_from_points(ag2_ctx* c, size_t n, const int64_t* offsets, 
 }
 
 }  // extern "C"
+
+extern "C" {
+
+int ag2_lenet_load(ag2_ctx* c, const float* c1w, const float* c1b, const float* c2w,
+                   const float* c2b, const float* f1w, const float* f1b, const float* f2w,
+                   const float* f2b) {
+  if (!c || !c1w || !c1b || !c2w || !c2b || !f1w || !f1b || !f2w || !f2b) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  return lenet_pack_weights(c, c1w, c1b, c2w, c2b, f1w, f1b, f2w, f2b);
+}
+
+int ag2_lenet_forward(ag2_ctx* c, const uint8_t* images, size_t n, float* out) {
+  if (!c || (n && (!images || !out))) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (!c->net.loaded) return set_err(c, AG2_ERR_STATE, "lenet weights not loaded");
+  if (n == 0) return 0;
+  AG2_HIP(c, c->d_images.reserve(n * 10800));
+  AG2_HIP(c, c->d_logits.reserve(n * 8));
+  AG2_HIP(c, hipMemcpyAsync(c->d_images.p, images, n * 10800, hipMemcpyHostToDevice, c->stream));
+  AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
+  const int rc = launch_lenet(c, c->d_images.as<uint8_t>(), n, c->d_logits.as<float>());
+  if (rc) return rc;
+  AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
+  AG2_HIP(c, hipMemcpyAsync(out, c->d_logits.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  (void)hipEventElapsedTime(&c->times.lenet_ms, c->ev[0], c->ev[1]);
+  return 0;
+}
+
+int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
+               uint64_t slot_base, uint64_t seed, int do_prune, ag2_hypothesis* selected,
+               size_t cap, size_t* n_selected, ag2_hypothesis* scored_all, size_t cap_all,
+               size_t* n_scored) {
+  if (!c || !n_selected) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  int rc = check_samples(c, sample_idx, sample_xyz);
+  if (rc) return rc;
+  if (!c->net.loaded) return set_err(c, AG2_ERR_STATE, "lenet weights not loaded");
+  const size_t n_slots = s * (size_t)c->p.num_orientations;
+  AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
+  rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true);   // 1. hypotheses
+  if (rc) return rc;
+  AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
+  size_t n_img = 0;                                                            // 2. prune
+  rc = compact_slots(c, n_slots, do_prune ? 1 : 0, c->d_list2, &n_img);
+  if (rc) return rc;
+  c->n_img = n_img;
+  c->cnt.n_pruned = (int64_t)n_img;
+  AG2_HIP(c, c->d_images.reserve(std::max<size_t>(n_img, 1) * 10800));
+  AG2_HIP(c, c->d_logits.reserve(std::max<size_t>(n_img, 1) * 8));
+  rc = make_image_descs(c, c->d_list2.as<int>(), n_img);                       // 3a. images
+  if (rc) return rc;
+  rc = launch_render(c, c->d_arena.as<double>(), c->d_desc.as<long long>(),
+                     (const int*)(c->d_desc.as<long long>() + n_img), n_img,
+                     c->d_images.as<uint8_t>());
+  if (rc) return rc;
+  AG2_HIP(c, hipEventRecord(c->ev[2], c->stream));
+  rc = launch_lenet(c, c->d_images.as<uint8_t>(), n_img, c->d_logits.as<float>());  // 3b. LeNet
+  if (rc) return rc;
+  AG2_HIP(c, hipEventRecord(c->ev[3], c->stream));
+  rc = launch_scatter_scores(c, c->d_list2.as<int>(), n_img);
+  if (rc) return rc;
+  size_t n_anti = 0;                                                           // score >= thr
+  rc = compact_slots(c, n_slots, 2, c->d_list, &n_anti);
+  if (rc) return rc;
+  std::vector<ag2_hypothesis> anti;
+  rc = gather_records(c, c->d_list.as<int>(), n_anti, anti, nullptr, nullptr);
+  if (rc) return rc;
+  AG2_HIP(c, hipEventRecord(c->ev[4], c->stream));
+  for (auto& h : anti) h.full_antipodal = 1;                                   // :205
+  // 5. top num_selected by score, descending (grasp_detector.cpp:239-252); ties by position
+  std::stable_sort(anti.begin(), anti.end(),
+                   [](const ag2_hypothesis& a, const ag2_hypothesis& b) { return a.score > b.score; });
+  size_t k = anti.size();
+  if (c->p.num_selected >= 0 && k > (size_t)c->p.num_selected) k = (size_t)c->p.num_selected;
+  *n_selected = k;
+  c->cnt.n_scored = (int64_t)n_img;
+  c->cnt.n_selected = (int64_t)k;
+  if (n_scored) *n_scored = n_img;
+  if (scored_all && cap_all) {
+    if (n_img > cap_all) return set_err(c, AG2_ERR_CAPACITY, "detect: scored_all capacity too small");
+    std::vector<ag2_hypothesis> all;
+    rc = gather_records(c, c->d_list2.as<int>(), n_img, all, nullptr, nullptr);
+    if (rc) return rc;
+    if (n_img) memcpy(scored_all, all.data(), n_img * sizeof(ag2_hypothesis));
+  }
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  (void)hipEventElapsedTime(&c->times.hands_ms, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&c->times.images_ms, c->ev[1], c->ev[2]);
+  (void)hipEventElapsedTime(&c->times.lenet_ms, c->ev[2], c->ev[3]);
+  (void)hipEventElapsedTime(&c->times.select_ms, c->ev[3], c->ev[4]);
+  (void)hipEventElapsedTime(&c->times.total_ms, c->ev[0], c->ev[4]);
+  if (k > cap) return set_err(c, AG2_ERR_CAPACITY, "detect: output capacity too small");
+  if (k) memcpy(selected, anti.data(), k * sizeof(ag2_hypothesis));
+  return 0;
+}
+
+int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes) {
+  if (!c || !d_dst) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  const size_t need = c->s * (size_t)c->p.num_orientations * sizeof(ag2_hypothesis);
+  if (bytes < need) return set_err(c, AG2_ERR_CAPACITY, "export: destination too small");
+  if (need) AG2_HIP(c, hipMemcpyAsync(d_dst, c->d_table.p, need, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""GPU parity, K5 + K6 + the fused detect entry: LeNet logits and the selected grasps, HIP (through
+the C-ABI) vs the oracle (fp32 CPU restatement of the Caffe layers) and vs torch-CPU.
+
+LeNet bar: floating point, different summation order (MFMA k-ordered fma chain vs the oracle's
+separate mul/add, K permuted for the LDS layout): |diff| <= 1e-4 * max|logit| + 1e-3, the same
+tolerance the oracle itself is pinned to torch with.  Selection: the set and order of selected
+hypotheses must be identical; scores within the same tolerance.
+"""
+import numpy as np
+import pytest
+
+import np_reference as ref
+from conftest import scene_params
+from agile_grasp2_amd import scene
+from agile_grasp2_amd.weights import make_lenet_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def random_images(rng, n, density=0.1):
+    m = rng.uniform(0, 1, size=(n, 60, 60, 3)) < density
+    return (m * rng.integers(0, 256, size=(n, 60, 60, 3))).astype(np.uint8)
+
+
+def tol(want):
+    return 1e-4 * np.abs(want).max() + 1e-3
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 130])
+def test_lenet_matches_oracle_and_torch(n):
+    from agile_grasp2_amd import capi
+    from oracle import api
+    w = make_lenet_weights(11)
+    rng = np.random.default_rng(n)
+    imgs = random_images(rng, n)
+    if n >= 5:
+        imgs[1] = 0
+        imgs[2] = 255
+    d = capi.Detector()
+    d.lenet_load(w)
+    got = d.lenet_forward(imgs)
+    o = api.Oracle(num_threads=8)
+    o.lenet_load(w)
+    want = o.lenet_forward(imgs)
+    wt = ref.lenet_torch(w, imgs)
+    assert np.abs(got - want).max() <= tol(want)
+    assert np.abs(got - wt).max() <= tol(wt)
+    d.close()
+
+
+def test_lenet_structured_weights_catch_layout_bugs():
+    """Asymmetric, position-dependent weights: a transposed tile, a swapped channel pair or a
+    mis-ordered ip1 column would change the answer by O(1)."""
+    from agile_grasp2_amd import capi
+    w = make_lenet_weights(3)
+    rng = np.random.default_rng(0)
+    w["conv1_w"] = (np.arange(20 * 3 * 25).reshape(20, 3, 5, 5) % 17 - 8).astype(np.float32) * 1e-3
+    w["conv2_w"] = (np.arange(50 * 20 * 25).reshape(50, 20, 5, 5) % 23 - 11).astype(np.float32) * 1e-3
+    w["ip1_w"] = ((np.arange(500 * 7200).reshape(500, 7200) % 31) - 15).astype(np.float32) * 1e-4
+    w["ip2_w"] = np.stack([np.linspace(-1, 1, 500), np.linspace(1, -0.5, 500)]).astype(np.float32)
+    imgs = random_images(rng, 9, density=0.5)
+    d = capi.Detector()
+    d.lenet_load(w)
+    got = d.lenet_forward(imgs)
+    wt = ref.lenet_torch(w, imgs)
+    assert np.abs(got - wt).max() <= tol(wt)
+    d.close()
+
+
+def _detect_pair(xyz, ws, idx, seed, do_prune, **kw):
+    from agile_grasp2_amd import capi
+    from oracle import api
+    prm = scene_params(ws, **kw)
+    w = make_lenet_weights(7)
+    o = api.Oracle(**dict(prm, num_threads=8))
+    d = capi.Detector(**prm)
+    for x in (o, d):
+        x.set_cloud(xyz)
+        x.compute_normals()
+        x.lenet_load(w)
+    gs, ga = d.detect(sample_idx=idx, seed=seed, do_prune=do_prune)
+    ws_, wa = o.detect(sample_idx=idx, seed=seed, do_prune=do_prune)
+    return d, o, gs, ga, ws_, wa
+
+
+def _check_scored(ga, wa):
+    assert len(ga) == len(wa)
+    for f in ("sample_slot", "orientation", "half_antipodal", "full_antipodal", "n_points"):
+        assert np.array_equal(ga[f], wa[f]), f
+    for f in ("axis", "approach", "binormal", "surface", "bottom", "top", "width"):
+        assert np.array_equal(ga[f], wa[f]), f
+    if len(wa):
+        assert np.abs(ga["score"] - wa["score"]).max() <= 2 * tol(wa["score"])
+
+
+def test_detect_small_scene(small_scene):
+    xyz, ws, idx = small_scene
+    med = None
+    d, o, gs, ga, ws_, wa = _detect_pair(xyz, ws, idx, 5, True, min_score_diff=-1e30, num_selected=1000)
+    _check_scored(ga, wa)
+    assert len(wa) > 5
+    # with everything selected the order is by score: identical unless two scores are closer than
+    # the float tolerance
+    assert len(gs) == len(ws_) == len(wa)
+    key_g = list(zip(gs["sample_slot"], gs["orientation"]))
+    key_w = list(zip(ws_["sample_slot"], ws_["orientation"]))
+    gaps = np.abs(np.diff(np.sort(wa["score"])))
+    if len(gaps) == 0 or gaps.min() > 4 * tol(wa["score"]):
+        assert key_g == key_w
+    else:
+        assert sorted(key_g) == sorted(key_w)
+    assert gs["full_antipodal"].all()
+    d.close()
+
+
+def test_detect_threshold_and_topk(small_scene):
+    xyz, ws, idx = small_scene
+    d, o, gs, ga, ws_, wa = _detect_pair(xyz, ws, idx, 6, False, min_score_diff=-1e30, num_selected=1000)
+    thr = float(np.median(wa["score"]))
+    margin = np.abs(wa["score"] - thr).min()
+    d.close()
+    d, o, gs, ga, ws_, wa = _detect_pair(xyz, ws, idx, 6, False, min_score_diff=thr, num_selected=10)
+    _check_scored(ga, wa)
+    assert len(ws_) == min(10, int((wa["score"] >= thr).sum()))
+    if margin > 4 * tol(wa["score"]):
+        assert len(gs) == len(ws_)
+        assert sorted(zip(gs["sample_slot"], gs["orientation"])) == sorted(zip(ws_["sample_slot"], ws_["orientation"]))
+    c = d.counters()
+    assert c.n_scored == len(wa) and c.n_selected == len(gs)
+    t = d.times()
+    assert t.total_ms > 0 and t.lenet_ms > 0
+    d.close()
+
+
+def test_detect_no_hypotheses():
+    """A bare plane yields no hand placements: every stage must cope with zero work."""
+    from agile_grasp2_amd import capi
+    xyz, ws = scene.make_scene(seed=2, n_target=4000, kind="plane")
+    d = capi.Detector(**scene_params(ws))
+    d.set_cloud(xyz)
+    d.compute_normals()
+    d.lenet_load(make_lenet_weights(1))
+    idx = scene.draw_samples(1, xyz.shape[0], 50)
+    sel, allh = d.detect(sample_idx=idx, seed=1)
+    assert len(sel) == 0 and len(allh) == 0
+    sel, allh = d.detect(sample_idx=idx[:0], seed=1)
+    assert len(sel) == 0
+    d.close()
+
+
+def test_missing_state_errors():
+    from agile_grasp2_amd import capi
+    d = capi.Detector()
+    with pytest.raises(RuntimeError):
+        d.compute_normals()                      # no cloud
+    d.set_cloud(np.random.default_rng(0).uniform(0, 0.1, size=(100, 3)).astype(np.float32))
+    with pytest.raises(RuntimeError):
+        d.generate_hypotheses(sample_idx=np.arange(5, dtype=np.int32))  # no normals
+    d.compute_normals()
+    with pytest.raises(RuntimeError):
+        d.detect(sample_idx=np.arange(5, dtype=np.int32))               # no weights
+    d.close()
