@@ -181,11 +181,7 @@ int ag2_set_stream(ag2_ctx* c, void* hip_stream) {
   if (c->stream) AG2_HIP(c, hipStreamSynchronize(c->stream));
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   c->own_stream = false;
-  c->stream = (hipStream_t)hip_stream;
-  if (!hip_stream) {
-    AG2_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->own_stream = true;
-  }
+  c->stream = (hipStream_t)hip_stream;  // NULL = the HIP default (null) stream, torch's default
   return 0;
 }
 

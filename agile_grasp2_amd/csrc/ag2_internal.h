@@ -57,7 +57,7 @@ struct ag2_ctx {
   std::string err;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipEvent_t ev[8] = {};
+  hipEvent_t ev[12] = {};
 
   // cloud
   size_t n = 0;           // points given
@@ -143,6 +143,6 @@ int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, con
 int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const float* c2w,
                        const float* c2b, const float* f1w, const float* f1b, const float* f2w,
                        const float* f2b);
-int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits);
+int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits, hipEvent_t ev_mid);
 
 }  // namespace ag2

@@ -44,10 +44,13 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     if (rc) return rc;
     rc = upload_samples(c, sample_idx, sample_xyz, s);
     if (rc) return rc;
+    AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_frames(c, s, slot_base, seed);
     if (rc) return rc;
+    AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
     rc = launch_sweep(c, s, slot_base, emit_lists);
     if (rc) return rc;
+    AG2_HIP(c, hipEventRecord(c->ev[2], c->stream));
     DevStats hs;
     rc = read_stats(c, &hs);
     if (rc) return rc;
@@ -64,6 +67,8 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     c->cnt.sum_k2 = (int64_t)hs.sum_k2;
     c->cnt.sum_kcrop = (int64_t)hs.sum_kcrop;
     c->cnt.sum_p = (int64_t)hs.sum_p;
+    (void)hipEventElapsedTime(&c->times.frames_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->times.sweep_ms, c->ev[1], c->ev[2]);
     return 0;
   }
   return set_err(c, AG2_ERR_CAPACITY, "point-list arena could not be sized");
@@ -103,10 +108,8 @@ int ag2_generate_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double*
   (void)hipSetDevice(c->device);
   int rc = check_samples(c, sample_idx, sample_xyz);
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
   rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true);
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
   size_t nh = 0;
   rc = compact_slots(c, s * (size_t)c->p.num_orientations, 0, c->d_list, &nh);
   if (rc) return rc;
@@ -118,7 +121,6 @@ int ag2_generate_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double*
   if (nh) {
     AG2_HIP(c, hipMemcpy(c->h_slots.data(), c->d_list.p, nh * 4, hipMemcpyDeviceToHost));
   }
-  (void)hipEventElapsedTime(&c->times.hands_ms, c->ev[0], c->ev[1]);
   *n_out = nh;
   if (nh > cap) return set_err(c, AG2_ERR_CAPACITY, "generate_hypotheses: output capacity too small");
   if (nh) memcpy(out, c->h_hyps.data(), nh * sizeof(ag2_hypothesis));
@@ -155,7 +157,7 @@ int ag2_render_images(ag2_ctx* c, size_t first, size_t count, uint8_t* out) {
   (void)hipSetDevice(c->device);
   if (first + count > c->h_hyps.size()) return set_err(c, AG2_ERR_ARG, "render: range");
   if (count == 0) return 0;
-  AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
+  AG2_HIP(c, hipEventRecord(c->ev[3], c->stream));
   int rc = make_image_descs(c, c->d_list.as<int>() + first, count);
   if (rc) return rc;
   AG2_HIP(c, c->d_images.reserve(count * 10800));
@@ -163,10 +165,10 @@ int ag2_render_images(ag2_ctx* c, size_t first, size_t count, uint8_t* out) {
                      (const int*)(c->d_desc.as<long long>() + count), count,
                      c->d_images.as<uint8_t>());
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
+  AG2_HIP(c, hipEventRecord(c->ev[4], c->stream));
   AG2_HIP(c, hipMemcpyAsync(out, c->d_images.p, count * 10800, hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipEventElapsedTime(&c->times.images_ms, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&c->times.render_ms, c->ev[3], c->ev[4]);
   return 0;
 }
 
@@ -223,13 +225,14 @@ int ag2_lenet_forward(ag2_ctx* c, const uint8_t* images, size_t n, float* out) {
   AG2_HIP(c, c->d_images.reserve(n * 10800));
   AG2_HIP(c, c->d_logits.reserve(n * 8));
   AG2_HIP(c, hipMemcpyAsync(c->d_images.p, images, n * 10800, hipMemcpyHostToDevice, c->stream));
-  AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
-  const int rc = launch_lenet(c, c->d_images.as<uint8_t>(), n, c->d_logits.as<float>());
+  AG2_HIP(c, hipEventRecord(c->ev[4], c->stream));
+  const int rc = launch_lenet(c, c->d_images.as<uint8_t>(), n, c->d_logits.as<float>(), c->ev[5]);
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
+  AG2_HIP(c, hipEventRecord(c->ev[6], c->stream));
   AG2_HIP(c, hipMemcpyAsync(out, c->d_logits.p, n * 8, hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipEventElapsedTime(&c->times.lenet_ms, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&c->times.lenet_conv_ms, c->ev[4], c->ev[5]);
+  (void)hipEventElapsedTime(&c->times.lenet_fc_ms, c->ev[5], c->ev[6]);
   return 0;
 }
 
@@ -243,10 +246,9 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   if (rc) return rc;
   if (!c->net.loaded) return set_err(c, AG2_ERR_STATE, "lenet weights not loaded");
   const size_t n_slots = s * (size_t)c->p.num_orientations;
-  AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
+  AG2_HIP(c, hipEventRecord(c->ev[8], c->stream));
   rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true);   // 1. hypotheses
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
   size_t n_img = 0;                                                            // 2. prune
   rc = compact_slots(c, n_slots, do_prune ? 1 : 0, c->d_list2, &n_img);
   if (rc) return rc;
@@ -256,14 +258,15 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   AG2_HIP(c, c->d_logits.reserve(std::max<size_t>(n_img, 1) * 8));
   rc = make_image_descs(c, c->d_list2.as<int>(), n_img);                       // 3a. images
   if (rc) return rc;
+  AG2_HIP(c, hipEventRecord(c->ev[3], c->stream));
   rc = launch_render(c, c->d_arena.as<double>(), c->d_desc.as<long long>(),
                      (const int*)(c->d_desc.as<long long>() + n_img), n_img,
                      c->d_images.as<uint8_t>());
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[2], c->stream));
-  rc = launch_lenet(c, c->d_images.as<uint8_t>(), n_img, c->d_logits.as<float>());  // 3b. LeNet
+  AG2_HIP(c, hipEventRecord(c->ev[4], c->stream));
+  rc = launch_lenet(c, c->d_images.as<uint8_t>(), n_img, c->d_logits.as<float>(), c->ev[5]);  // 3b.
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[3], c->stream));
+  AG2_HIP(c, hipEventRecord(c->ev[6], c->stream));
   rc = launch_scatter_scores(c, c->d_list2.as<int>(), n_img);
   if (rc) return rc;
   size_t n_anti = 0;                                                           // score >= thr
@@ -272,7 +275,7 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   std::vector<ag2_hypothesis> anti;
   rc = gather_records(c, c->d_list.as<int>(), n_anti, anti, nullptr, nullptr);
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[4], c->stream));
+  AG2_HIP(c, hipEventRecord(c->ev[7], c->stream));
   for (auto& h : anti) h.full_antipodal = 1;                                   // :205
   // 5. top num_selected by score, descending (grasp_detector.cpp:239-252); ties by position
   std::stable_sort(anti.begin(), anti.end(),
@@ -291,11 +294,12 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
     if (n_img) memcpy(scored_all, all.data(), n_img * sizeof(ag2_hypothesis));
   }
   AG2_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipEventElapsedTime(&c->times.hands_ms, c->ev[0], c->ev[1]);
-  (void)hipEventElapsedTime(&c->times.images_ms, c->ev[1], c->ev[2]);
-  (void)hipEventElapsedTime(&c->times.lenet_ms, c->ev[2], c->ev[3]);
-  (void)hipEventElapsedTime(&c->times.select_ms, c->ev[3], c->ev[4]);
-  (void)hipEventElapsedTime(&c->times.total_ms, c->ev[0], c->ev[4]);
+  (void)hipEventElapsedTime(&c->times.compact_ms, c->ev[2], c->ev[3]);
+  (void)hipEventElapsedTime(&c->times.render_ms, c->ev[3], c->ev[4]);
+  (void)hipEventElapsedTime(&c->times.lenet_conv_ms, c->ev[4], c->ev[5]);
+  (void)hipEventElapsedTime(&c->times.lenet_fc_ms, c->ev[5], c->ev[6]);
+  (void)hipEventElapsedTime(&c->times.select_ms, c->ev[6], c->ev[7]);
+  (void)hipEventElapsedTime(&c->times.total_ms, c->ev[8], c->ev[7]);
   if (k > cap) return set_err(c, AG2_ERR_CAPACITY, "detect: output capacity too small");
   if (k) memcpy(selected, anti.data(), k * sizeof(ag2_hypothesis));
   return 0;

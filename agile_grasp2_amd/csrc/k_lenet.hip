@@ -317,8 +317,11 @@ int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const flo
   return 0;
 }
 
-int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits) {
-  if (n == 0) return 0;
+int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits, hipEvent_t ev_mid) {
+  if (n == 0) {
+    if (ev_mid) AG2_HIP(c, hipEventRecord(ev_mid, c->stream));
+    return 0;
+  }
   LeNetDev& d = c->net;
   AG2_HIP(c, c->d_act1.reserve(n * (size_t)kFcK * 4));
   const size_t lds = sizeof(ConvShared);
@@ -332,6 +335,7 @@ int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits)
   hipLaunchKernelGGL(k_lenet_conv, dim3(grid), dim3(kConvThreads), lds, c->stream, d_images, (int)n,
                      d.w1p.as<float>(), d.b1.as<float>(), d.w2p.as<float>(), d.b2.as<float>(),
                      c->d_act1.as<float>());
+  if (ev_mid) AG2_HIP(c, hipEventRecord(ev_mid, c->stream));
   const int gfc = (int)((n + kFcBM - 1) / kFcBM);
   hipLaunchKernelGGL(k_lenet_fc, dim3(gfc), dim3(256), 0, c->stream, c->d_act1.as<float>(), (int)n,
                      d.w3p.as<float>(), d.b3.as<float>(), d.w4.as<float>(), d.b4.as<float>(),

@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the agile_grasp2 hot path on MI355X.
+
+Metric (BASELINE.json): grasp hypotheses scored per second on a 300k-point voxelised cloud
+(config 2: num_samples=5000, 8 orientations, one GPU), end to end:
+    search grid -> PCA normals -> local frames -> hand sweep -> prune -> grasp images -> LeNet ->
+    score threshold / top-k
+with the raw xyz cloud already resident in HBM when the timed region starts.  One "step" is one
+full pass over one cloud.  value = hypotheses scored by all ranks / max-over-ranks wall time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg1|cfg3] [--no-cpu]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the cloud is replicated, every rank
+sweeps its own num_samples samples (weak scaling) and the fixed-slot candidate tables are
+exchanged with one RCCL all-gather.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (live HIP-event
+durations on the launch stream; algorithmic bytes/flops per SURVEY.md section 8d with the measured
+K1, K2, P, H of the run) and "cpu_baseline" (the CPU oracle -- a restatement of the reference
+algorithm, not PCL/FLANN/Caffe -- on a bounded sample of the same workload, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (n_points, num_samples, orientations, voxelised, scene kind)
+    "cfg1": (50_000, 500, 8, True, "tabletop"),
+    "cfg2": (300_000, 5000, 8, True, "tabletop"),
+    "cfg3": (1_000_000, 20000, 16, False, "tabletop"),
+}
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+CONV_FLOP = 2.0 * (20 * 56 * 56 * 75 + 50 * 24 * 24 * 500)   # 38.208 MFLOP / image
+FC_FLOP = 2.0 * (500 * 7200 + 2 * 500)                        # 7.202 MFLOP / image
+
+
+def launch_params(ws, R):
+    """launch/file_detect_grasps.launch:16-48 values."""
+    from agile_grasp2_amd import scene
+    return dict(finger_width=0.01, hand_outer_diameter=0.09, hand_depth=0.06, hand_height=0.02,
+                init_bite=0.01, nn_radius_taubin=0.01, nn_radius_hands=0.1, num_orientations=R,
+                filter_half_grasps=0, min_aperture=0.03, max_aperture=0.08, min_score_diff=300.0,
+                num_selected=30, cam_origin=[scene.CAMERA, scene.CAMERA], workspace=list(ws))
+
+
+def cpu_baseline(xyz, ws, idx, R, weights, n_sub=2500):
+    """Oracle (CPU restatement) on a bounded sample: all points for normals, the first n_sub samples
+    for the rest; normals time is charged pro rata so the rate is comparable to the full job.
+    Threads: the box's CPU share for one GPU (16), or fewer if the host has fewer cores."""
+    from oracle import api
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
+    prm = launch_params(ws, R)
+    o = api.Oracle(**dict(prm, num_threads=cores))
+    o.set_cloud(xyz)
+    o.compute_normals()
+    o.lenet_load(weights)
+    sub = idx[:n_sub]
+    t0 = time.perf_counter()
+    _, scored = o.detect(sample_idx=sub, seed=1, do_prune=True)
+    t_rest = time.perf_counter() - t0
+    c = o.counters()
+    t_norm = c.t_normals * (len(sub) / max(1, len(idx)))
+    t = t_rest + t_norm
+    return {
+        "value": len(scored) / t if t > 0 else 0.0, "unit": "hypotheses/s", "cores": cores,
+        "kind": "port",
+        "sample": (f"oracle (CPU restatement, grid NN + own LeNet, -O3 -fopenmp) on the same cloud: "
+                   f"normals for all {xyz.shape[0]} points ({c.t_normals:.2f} s, charged pro rata "
+                   f"{len(sub)}/{len(idx)}), then {len(sub)} of {len(idx)} samples through frames, hand "
+                   f"search, images, LeNet ({t_rest:.2f} s); {len(scored)} hypotheses scored"),
+        "stage_s": {"normals_full": c.t_normals, "frames": c.t_frames, "hands": c.t_hands,
+                    "images": c.t_images, "lenet": c.t_lenet},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # started by hand without torch.distributed.run: start it as a child process
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", "29517",
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch  # plumbing only: device memory, stream, torch.distributed (RCCL)
+    import torch.distributed as dist
+    from agile_grasp2_amd import capi, scene
+    from agile_grasp2_amd.weights import make_lenet_weights
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_points, S, R, voxelised, kind = CONFIGS[args.config]
+    xyz, ws = scene.make_scene(args.seed, n_points, kind=kind, voxel=scene.VOXEL if voxelised else None)
+    idx = scene.draw_samples(args.seed + 1000 * rank, xyz.shape[0], S)
+    weights = make_lenet_weights(7)
+    d = capi.Detector(device=local_rank, **launch_params(ws, R))
+    d.set_stream(torch.cuda.current_stream().cuda_stream)
+    d.lenet_load(weights)
+    xyz_dev = torch.from_numpy(xyz).cuda()          # HBM-resident input
+    torch.cuda.synchronize()
+    slot_bytes = S * R * 176
+    local_tab = torch.empty(slot_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+    gathered = torch.empty(slot_bytes * world, dtype=torch.uint8, device="cuda") if world > 1 else None
+
+    acc = {}
+
+    def step():
+        d.set_cloud_device(xyz_dev.data_ptr(), xyz.shape[0], 12)
+        d.compute_normals()
+        sel, n_scored = d.detect(sample_idx=idx, slot_base=rank * S, seed=args.seed, do_prune=True,
+                                 want_all=False)
+        if world > 1:
+            d.export_candidates_device(local_tab.data_ptr(), slot_bytes)
+            dist.all_gather_into_tensor(gathered, local_tab)
+        return n_scored
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    scored = 0
+    for _ in range(args.steps):
+        scored += step()
+        t = d.times()
+        for name, _ty in t._fields_:
+            acc[name] = acc.get(name, 0.0) + getattr(t, name)
+    sync()
+    elapsed = time.perf_counter() - t0
+    c = d.counters()
+
+    tt = torch.tensor([elapsed, float(scored), float(c.n_hypotheses)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+    total_scored = float(tt[1])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    K = args.steps
+    ms = {k: v / K for k, v in acc.items() if not k.startswith("reserved")}
+    n_img = c.n_scored
+    # algorithmic work per launch, measured neighbourhood sizes of this run
+    kernels = {
+        "k_normals": dict(bound="hbm", work=c.sum_k1 * 12 + c.n_valid_points * 12, ms=ms["normals_ms"]),
+        "k_sweep": dict(bound="hbm", work=c.sum_k2 * 24 + c.n_hypotheses * 176 + c.sum_p * 24, ms=ms["sweep_ms"]),
+        "k_render": dict(bound="hbm", work=c.sum_p * 24 * (n_img / max(1, c.n_hypotheses)) + n_img * 10800,
+                         ms=ms["render_ms"]),
+        "k_lenet_conv": dict(bound="mfma", work=n_img * CONV_FLOP, ms=ms["lenet_conv_ms"]),
+        "k_lenet_fc": dict(bound="mfma", work=n_img * FC_FLOP, ms=ms["lenet_fc_ms"]),
+    }
+    for k in kernels.values():
+        if k["bound"] == "hbm":
+            k["achieved"] = k["work"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+            k["peak"], k["unit"] = PEAK_HBM_GBS, "GB/s"
+        else:
+            k["achieved"] = k["work"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+            k["peak"], k["unit"] = PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+        k["frac"] = k["achieved"] / k["peak"]
+    dom = max(kernels, key=lambda n: kernels[n]["ms"])
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get(args.config, {}).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
+                "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
+                "traffic": traffic, "launch_ms": kernels[dom]["ms"],
+                "algorithmic_work_per_launch": kernels[dom]["work"],
+                "all_kernels": {n: {"ms": round(k["ms"], 4), "achieved": round(k["achieved"], 3),
+                                    "unit": k["unit"], "frac": round(k["frac"], 4)}
+                                for n, k in kernels.items()}}
+    out = {
+        "metric": "grasp hypotheses scored/sec on 300k-pt cloud; end-to-end detect latency",
+        "value": total_scored / elapsed, "unit": "hypotheses/s",
+        "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64 geometry + f32 LeNet (fp32 MFMA)", "data": "synthetic",
+        "config": {
+            "workload": (f"{args.config}: {xyz.shape[0]}-pt {'voxelised (3 mm)' if voxelised else 'un-voxelised'} "
+                         f"synthetic tabletop cloud, num_samples={S}/GPU, {R} orientations, launch-file hand "
+                         f"geometry, seeded LeNet weights"),
+            "n_points": int(xyz.shape[0]), "num_samples_per_gpu": S, "num_orientations": R,
+            "hypotheses_per_step_per_gpu": int(c.n_hypotheses), "scored_per_step_per_gpu": int(n_img),
+            "slots_swept_per_s": S * R * world / (elapsed / K),
+            "mean_K1": c.sum_k1 / max(1, c.n_valid_points), "mean_K2": c.sum_k2 / max(1, c.n_frames),
+            "mean_Kcrop": c.sum_kcrop / max(1, c.n_frames), "mean_P": c.sum_p / max(1, c.n_hypotheses),
+            "overflow_samples": int(c.n_overflow_samples),
+            "parallelism": ("single GPU" if world == 1 else
+                            f"cloud replicated, sample-range sharding x{world}, one RCCL all-gather of the "
+                            f"{S * R}-slot x 176 B candidate table per rank"),
+        },
+        "stage_ms": {k: round(v, 4) for k, v in ms.items()},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(xyz, ws, idx, R, weights)
+    print(json.dumps(out))
+    d.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

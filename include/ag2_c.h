@@ -89,7 +89,17 @@ typedef struct ag2_counters {
  * Stage names follow the reference's own probes (hand_search.cpp:30,58,167,232;
  * grasp_detector.cpp:210,254). */
 typedef struct ag2_times {
-  float grid_ms, normals_ms, hands_ms, images_ms, lenet_ms, select_ms, total_ms, reserved;
+  float grid_ms;        /* K0 search grid (ag2_set_cloud*) */
+  float normals_ms;     /* K1 k_normals */
+  float frames_ms;      /* K2 k_frames */
+  float sweep_ms;       /* K3 k_sweep (both instantiations) */
+  float compact_ms;     /* prune-flag compaction + image descriptors */
+  float render_ms;      /* K4 k_render */
+  float lenet_conv_ms;  /* K5 k_lenet_conv */
+  float lenet_fc_ms;    /* K5 k_lenet_fc */
+  float select_ms;      /* K6 score scatter, threshold compaction, record gather */
+  float total_ms;       /* first to last event of the call */
+  float reserved[2];
 } ag2_times;
 
 int ag2_abi_version(void);
@@ -100,7 +110,8 @@ void ag2_default_params(ag2_params* p);
 ag2_ctx* ag2_create(const ag2_params* p, int device_id);
 void ag2_destroy(ag2_ctx* c);
 const char* ag2_last_error(const ag2_ctx* c);
-/* Run on an existing HIP stream (hipStream_t), e.g. torch's current stream; NULL = own stream. */
+/* Run on the caller's HIP stream (hipStream_t), e.g. torch's current stream; NULL = the HIP
+ * default (null) stream.  Without this call the context uses a private non-blocking stream. */
 int ag2_set_stream(ag2_ctx* c, void* hip_stream);
 
 /* Replaces CloudCamera's data members (include/agile_grasp2/cloud_camera.h:178-183) and the kd-tree

@@ -128,7 +128,7 @@ def test_detect_threshold_and_topk(small_scene):
     c = d.counters()
     assert c.n_scored == len(wa) and c.n_selected == len(gs)
     t = d.times()
-    assert t.total_ms > 0 and t.lenet_ms > 0
+    assert t.total_ms > 0 and t.lenet_conv_ms > 0 and t.sweep_ms > 0
     d.close()
 
 
