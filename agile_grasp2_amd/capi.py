@@ -35,7 +35,7 @@ class Params(C.Structure):
         ("workspace", C.c_double * 6),
         ("min_aperture", C.c_double), ("max_aperture", C.c_double),
         ("min_score_diff", C.c_double),
-        ("num_selected", C.c_int32), ("reserved", C.c_int32),
+        ("num_selected", C.c_int32), ("debug_flags", C.c_int32),
     ]
 
 

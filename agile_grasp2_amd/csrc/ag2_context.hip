@@ -29,6 +29,10 @@ static void derive_constants(ag2_ctx* c) {
     h.fs[n + i] = fh;
   }
   for (int i = 0; i < 2 * n; i++) h.fsr[i] = h.fs[i] + p.finger_width;
+  h.slot_step = step;
+  h.slot_inv_step = (step > 0.0) ? 1.0 / step : 0.0;
+  // 2 <=> finger narrower than two spacings less a hair: three exact candidates suffice
+  h.slot_span = (step > 0.0 && p.finger_width / step < 2.0 - 1e-6) ? 2 : 20;
   // hand_search.cpp:179-180
   const int R = p.num_orientations;
   const double low = -1.0 * M_PI / 2.0, hi = M_PI / 2.0;
@@ -82,9 +86,12 @@ static int check_params(ag2_ctx* c) {
   if (!(p.grid_cell > 0) || !(p.nn_radius_hands > 0) || !(p.nn_radius_taubin > 0) ||
       !(p.normals_radius > 0))
     return set_err(c, AG2_ERR_ARG, "radii and grid_cell must be positive");
-  const double span = 2.0 * ceil(p.nn_radius_hands * 1.001 / p.grid_cell) + 2.0;
+  // cells spanned per axis by [q - r', q + r'] with r' = 1.001 r: at most floor(2 r' / cell) + 2
+  const double span = floor(2.0 * p.nn_radius_hands * 1.002 / p.grid_cell) + 2.0;
   if (span * span > (double)kMaxRows)
-    return set_err(c, AG2_ERR_ARG, "nn_radius_hands / grid_cell too large for the row table");
+    return set_err(c, AG2_ERR_ARG,
+                   "nn_radius_hands / grid_cell too large for the 512-row stencil table "
+                   "(need (floor(2r/cell)+2)^2 <= 512)");
   if (!(p.hand_depth > 0) || !(p.hand_height > 0))
     return set_err(c, AG2_ERR_ARG, "hand_depth and hand_height must be positive");
   return 0;
@@ -164,7 +171,7 @@ void ag2_destroy(ag2_ctx* c) {
                     &c->d_nrm, &c->d_scan, &c->d_stats, &c->d_hc, &c->d_sample_q, &c->d_frames,
                     &c->d_frame_ok, &c->d_table, &c->d_tab_off, &c->d_tab_keep, &c->d_arena,
                     &c->d_overflow, &c->d_gscratch, &c->d_list, &c->d_list2, &c->d_images,
-                    &c->d_logits, &c->d_act1, &c->d_tmp, &c->d_flags, &c->d_desc, &c->net.w1p, &c->net.b1, &c->net.w2p,
+                    &c->d_logits, &c->d_act1, &c->d_fcpart, &c->d_tmp, &c->d_flags, &c->d_desc, &c->net.w1p, &c->net.b1, &c->net.w2p,
                     &c->net.b2, &c->net.w3p, &c->net.b3, &c->net.w4, &c->net.b4};
   for (DevBuf* b : bufs) b->release();
   for (auto& e : c->ev)

@@ -13,7 +13,7 @@ namespace ag2 {
 constexpr int kWave = 64;
 constexpr int kMaxOrient = 32;
 constexpr int kMaxDepths = 32;
-constexpr int kMaxRows = 1024;   // stencil rows (y,z pairs) of one hand-radius query
+constexpr int kMaxRows = 512;    // stencil rows (y,z pairs) of one hand-radius query
 constexpr int kImg = 60;         // Learning(60, ...) grasp_detector.cpp:56
 
 struct GridDesc {
@@ -35,11 +35,14 @@ struct HandConst {
   double cam_origin[2][3];
   double finger_width, hand_outer_diameter, hand_depth, hand_height, init_bite;
   double cos_fc;                 // cos(30 deg), antipodal.cpp:11,23
+  double slot_inv_step;          // 1 / finger-slot spacing (candidate selection only)
+  double slot_step;              // (od - fw) / 9: the LinSpaced step, finger_hand.cpp:10
   double min_aperture, max_aperture;
   float ws_min_x, ws_max_x, ws_min_y, ws_max_y;  // float bounds, grasp_detector.cpp:363-364
   float r2_taubin, r2_hands, r2_normals;         // (float)(r*r)
   float rq_taubin, rq_hands, rq_normals;         // conservative per-axis reach
   int R, n_depths, n_cams, filter_half;
+  int slot_span, pad0;           // floor(finger_width / spacing) + 1
 };
 
 struct V3 {
@@ -137,36 +140,73 @@ __device__ __forceinline__ uint64_t draw_u64(uint64_t seed, uint64_t slot, uint6
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 
+// Wave-wide reductions on the DPP cross-lane path (no LDS round trips, unlike __shfl's
+// ds_bpermute): quad swaps, row half-mirror / mirror, then row_bcast:15 / row_bcast:31 leave the
+// full result in lane 63, which is broadcast with v_readlane.  A lane whose DPP source is masked off
+// keeps `old` (bound_ctrl = 0), so `old` is the operation's identity for that lane.
+#define AG2_DPP(old, v, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rmask), 0xF, false)
+#define AG2_DPP_STEPS(OP, ID)                         \
+  v = OP(v, AG2_DPP(ID, v, 0xB1, 0xF));  /* quad_perm [1,0,3,2] */ \
+  v = OP(v, AG2_DPP(ID, v, 0x4E, 0xF));  /* quad_perm [2,3,0,1] */ \
+  v = OP(v, AG2_DPP(ID, v, 0x141, 0xF)); /* row_half_mirror */     \
+  v = OP(v, AG2_DPP(ID, v, 0x140, 0xF)); /* row_mirror */          \
+  v = OP(v, AG2_DPP(ID, v, 0x142, 0xA)); /* row_bcast:15 */        \
+  v = OP(v, AG2_DPP(ID, v, 0x143, 0xC)); /* row_bcast:31 */
+
+__device__ __forceinline__ int ag2_op_add(int a, int b) { return a + b; }
+__device__ __forceinline__ int ag2_op_or(int a, int b) { return a | b; }
+__device__ __forceinline__ int ag2_op_min(int a, int b) { return a < b ? a : b; }
+
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  AG2_DPP_STEPS(ag2_op_add, 0)
+  return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ unsigned wave_or_u(unsigned v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v |= (unsigned)__shfl_xor((int)v, o, 64);
-  return v;
+__device__ __forceinline__ unsigned wave_or_u(unsigned u) {
+  int v = (int)u;
+  AG2_DPP_STEPS(ag2_op_or, 0)
+  return (unsigned)__builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-  return v;
+  AG2_DPP_STEPS(ag2_op_min, 0x7fffffff)
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// f64 min / max: both dwords travel together through the same DPP pattern
+__device__ __forceinline__ double ag2_dpp_d(double idv, double v, const int which, const int rmask) {
+  const long long iv = __double_as_longlong(v), ii = __double_as_longlong(idv);
+  int lo = (int)iv, hi = (int)(iv >> 32);
+  const int ilo = (int)ii, ihi = (int)(ii >> 32);
+  switch (which) {
+    case 0: lo = AG2_DPP(ilo, lo, 0xB1, 0xF); hi = AG2_DPP(ihi, hi, 0xB1, 0xF); break;
+    case 1: lo = AG2_DPP(ilo, lo, 0x4E, 0xF); hi = AG2_DPP(ihi, hi, 0x4E, 0xF); break;
+    case 2: lo = AG2_DPP(ilo, lo, 0x141, 0xF); hi = AG2_DPP(ihi, hi, 0x141, 0xF); break;
+    case 3: lo = AG2_DPP(ilo, lo, 0x140, 0xF); hi = AG2_DPP(ihi, hi, 0x140, 0xF); break;
+    case 4: lo = AG2_DPP(ilo, lo, 0x142, 0xA); hi = AG2_DPP(ihi, hi, 0x142, 0xA); break;
+    default: lo = AG2_DPP(ilo, lo, 0x143, 0xC); hi = AG2_DPP(ihi, hi, 0x143, 0xC); break;
+  }
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double ag2_bcast63_d(double v) {
+  const long long iv = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)iv, 63), hi = __builtin_amdgcn_readlane((int)(iv >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ double wave_min_d(double v) {
+  const double id = __builtin_inf();
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double w = __shfl_xor(v, o, 64);
+  for (int s = 0; s < 6; s++) {
+    const double w = ag2_dpp_d(id, v, s, 0);
     v = (w < v) ? w : v;
   }
-  return v;
+  return ag2_bcast63_d(v);
 }
 __device__ __forceinline__ double wave_max_d(double v) {
+  const double id = -__builtin_inf();
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double w = __shfl_xor(v, o, 64);
+  for (int s = 0; s < 6; s++) {
+    const double w = ag2_dpp_d(id, v, s, 0);
     v = (w > v) ? w : v;
   }
-  return v;
+  return ag2_bcast63_d(v);
 }
 
 }  // namespace ag2

@@ -95,6 +95,7 @@ struct ag2_ctx {
   ag2::DevBuf d_images;    // uint8 n_img x 10800 (HWC)
   ag2::DevBuf d_logits;    // float n_img x 2
   ag2::DevBuf d_act1;      // LeNet intermediates (pooled2: n x 7200 float)
+  ag2::DevBuf d_fcpart;    // ip1 split-K partial sums [ksplit][n_pad][512]
   ag2::DevBuf d_tmp;       // misc staging
   ag2::DevBuf d_flags;     // uint32 flags / prefix for slot compaction
   ag2::DevBuf d_desc;      // image descriptors: int64 arena offset[n] then int32 count[n]

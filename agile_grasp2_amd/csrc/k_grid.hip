@@ -62,13 +62,27 @@ __global__ void __launch_bounds__(256) k_bounds(const float4* __restrict__ xyz, 
     }
   }
   cnt = wave_sum_i(cnt);
+  // one set of atomics per workgroup (7 contended addresses chip-wide)
+  __shared__ int part[4][7];
   if (lane_id() == 0) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      atomicMin((int*)&st->bounds[k], mn[k]);
-      atomicMax((int*)&st->bounds[3 + k], mx[k]);
+      part[wave_id()][k] = mn[k];
+      part[wave_id()][3 + k] = mx[k];
     }
-    atomicAdd(&st->bounds[6], (unsigned)cnt);
+    part[wave_id()][6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int k = threadIdx.x;
+    int v = part[0][k];
+    for (int w = 1; w < 4; w++) {
+      const int o = part[w][k];
+      v = (k < 3) ? min(v, o) : (k < 6 ? max(v, o) : v + o);
+    }
+    if (k < 3) atomicMin((int*)&st->bounds[k], v);
+    else if (k < 6) atomicMax((int*)&st->bounds[k], v);
+    else atomicAdd(&st->bounds[6], (unsigned)v);
   }
 }
 
@@ -207,7 +221,7 @@ int build_grid(ag2_ctx* c) {
   c->grid = GridDesc{};
   if (n == 0) return 0;
   const float4* xyz = c->d_xyz_in.as<float4>();
-  const int nb = std::min((n + 255) / 256, 2048);
+  const int nb = std::min((n + 255) / 256, 512);
   hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, c->stream, xyz, n, st);
   DevStats hs;
   AG2_HIP(c, hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));

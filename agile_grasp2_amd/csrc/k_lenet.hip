@@ -166,100 +166,96 @@ k_lenet_conv(const unsigned char* __restrict__ images, int n_img, const float* _
 
 struct FcShared {
   float a[2][kFcBM * kFcKCP];
-  float part[4][kFcBM][2];
 };
 
+// ip1 partial products: one 64-image x 128-output tile per workgroup over a K range (split-K so
+// that small batches still fill 256 CUs).  grid = (image tiles, 4 column tiles, K splits).
+// part[ks][image][512] receives the partial sums; k_lenet_fc_finish adds them in ks order.
 __global__ void __launch_bounds__(256)
-k_lenet_fc(const float* __restrict__ x, int n_img, const float* __restrict__ w3p,
-           const float* __restrict__ b3, const float* __restrict__ w4, const float* __restrict__ b4,
-           float* __restrict__ logits) {
+k_lenet_fc1(const float* __restrict__ x, int n_img, int n_pad, const float* __restrict__ w3p,
+            int chunks_per_split, float* __restrict__ part) {
   __shared__ FcShared S;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int img0 = blockIdx.x * kFcBM;
-  v16f acc[2][4];
-#pragma unroll
-  for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-  // stage one K chunk: 64 images x 96 k; thread t loads image t/4, 24 consecutive floats
+  const int col0 = blockIdx.y * 128 + wid * 32;
+  const int kbeg = blockIdx.z * chunks_per_split * kFcKC;
+  v16f acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  v16f acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // staging: 64 images x 96 k per chunk; thread t owns image t/4, 24 consecutive floats.  Global
+  // loads for chunk i+1 are issued before the MFMAs of chunk i and written to LDS after them.
   const int srow = tid >> 2, scol = (tid & 3) * 24;
   const bool srow_ok = (img0 + srow) < n_img;
-  const float* sx = x + (size_t)(img0 + srow) * kFcK + scol;
-  auto stage = [&](int buf, int kc) {
-    float4 v[6];
+  const float* sx = x + (size_t)(img0 + srow) * kFcK + scol + kbeg;
+  float4 v[6];
+  auto gload = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < 6; i++)
       v[i] = srow_ok ? *reinterpret_cast<const float4*>(sx + kc + 4 * i) : make_float4(0, 0, 0, 0);
+  };
+  auto lstore = [&](int buf) {
     float* d = &S.a[buf][srow * kFcKCP + scol];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
       d[4 * i] = v[i].x; d[4 * i + 1] = v[i].y; d[4 * i + 2] = v[i].z; d[4 * i + 3] = v[i].w;
     }
   };
-  stage(0, 0);
+  gload(0);
+  lstore(0);
   __syncthreads();
-  const float* wb = w3p + wid * 128 + l31;  // + k * 512 + nt * 32
-  for (int kc = 0, it = 0; kc < kFcK; kc += kFcKC, it++) {
+  const float* wb = w3p + (size_t)(kbeg + half) * kFcN + col0 + l31;
+  for (int it = 0; it < chunks_per_split; it++) {
     const int buf = it & 1;
-    if (kc + kFcKC < kFcK) stage(buf ^ 1, kc + kFcKC);
+    const bool more = (it + 1) < chunks_per_split;
+    if (more) gload((it + 1) * kFcKC);
     const float* a0 = &S.a[buf][l31 * kFcKCP + half];
     const float* a1 = a0 + 32 * kFcKCP;
-    const float* wk = wb + (size_t)(kc + half) * kFcN;
-#pragma unroll 8
+    const float* wk = wb + (size_t)it * kFcKC * kFcN;
+#pragma unroll 12
     for (int s = 0; s < kFcKC / 2; s++) {
-      const float av0 = a0[2 * s], av1 = a1[2 * s];
-      float bv[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; nt++) bv[nt] = wk[(size_t)(2 * s) * kFcN + nt * 32];
-#pragma unroll
-      for (int nt = 0; nt < 4; nt++) {
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv[nt], acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv[nt], acc[1][nt], 0, 0, 0);
-      }
+      const float bv = wk[(size_t)(2 * s) * kFcN];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2 * s], bv, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2 * s], bv, acc1, 0, 0, 0);
     }
+    if (more) lstore(buf ^ 1);
     __syncthreads();
   }
-  // epilogue: + bias, ReLU (in place on ip1, prototxt relu1), then ip2 partial sums over this
-  // wave's 128 columns, reduced over the 32 lanes of each half
-  float bias[4], w40[4], w41[4];
+  float* dst = part + ((size_t)blockIdx.z * n_pad + img0) * kFcN + col0 + l31;
 #pragma unroll
-  for (int nt = 0; nt < 4; nt++) {
-    const int n = wid * 128 + nt * 32 + l31;
-    bias[nt] = b3[n];
-    w40[nt] = w4[n];
-    w41[nt] = w4[kFcN + n];
+  for (int r = 0; r < 16; r++) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    dst[(size_t)row * kFcN] = acc0[r];
+    dst[(size_t)(row + 32) * kFcN] = acc1[r];
+  }
+}
+
+// ip1 finish (+ bias, ReLU in place: prototxt relu1) and ip2: one wave per image, partial sums
+// added in split order, the 512-wide dot products reduced with a fixed shuffle tree.
+__global__ void __launch_bounds__(256)
+k_lenet_fc_finish(const float* __restrict__ part, int n_img, int n_pad, int ksplit,
+                  const float* __restrict__ b3, const float* __restrict__ w4,
+                  const float* __restrict__ b4, float* __restrict__ logits) {
+  const int lane = threadIdx.x & 63;
+  const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (img >= n_img) return;
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int n = j * 64 + lane;
+    float h = 0.f;
+    for (int ks = 0; ks < ksplit; ks++) h += part[((size_t)ks * n_pad + img) * kFcN + n];
+    h = fmaxf(h + b3[n], 0.f);
+    s0 = __builtin_fmaf(h, w4[n], s0);
+    s1 = __builtin_fmaf(h, w4[kFcN + n], s1);
   }
 #pragma unroll
-  for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 4; nt++) {
-        const float h = fmaxf(acc[mt][nt][r] + bias[nt], 0.f);
-        s0 = __builtin_fmaf(h, w40[nt], s0);
-        s1 = __builtin_fmaf(h, w41[nt], s1);
-      }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        s0 += __shfl_xor(s0, o, 64);
-        s1 += __shfl_xor(s1, o, 64);
-      }
-      if (l31 == 0) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        S.part[wid][row][0] = s0;
-        S.part[wid][row][1] = s1;
-      }
-    }
-  __syncthreads();
-  if (tid < kFcBM * 2) {
-    const int row = tid >> 1, o = tid & 1;
-    if (img0 + row < n_img) {
-      const float v = ((S.part[0][row][o] + S.part[1][row][o]) + S.part[2][row][o]) + S.part[3][row][o];
-      logits[(size_t)(img0 + row) * 2 + o] = v + b4[o];
-    }
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+  }
+  if (lane == 0) {
+    logits[(size_t)img * 2] = s0 + b4[0];
+    logits[(size_t)img * 2 + 1] = s1 + b4[1];
   }
 }
 
@@ -336,10 +332,23 @@ int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits,
                      d.w1p.as<float>(), d.b1.as<float>(), d.w2p.as<float>(), d.b2.as<float>(),
                      c->d_act1.as<float>());
   if (ev_mid) AG2_HIP(c, hipEventRecord(ev_mid, c->stream));
-  const int gfc = (int)((n + kFcBM - 1) / kFcBM);
-  hipLaunchKernelGGL(k_lenet_fc, dim3(gfc), dim3(256), 0, c->stream, c->d_act1.as<float>(), (int)n,
-                     d.w3p.as<float>(), d.b3.as<float>(), d.w4.as<float>(), d.b4.as<float>(),
-                     d_logits);
+  const int mtiles = (int)((n + kFcBM - 1) / kFcBM);
+  const int n_pad = mtiles * kFcBM;
+  // split K (75 chunks of 96) so that small batches still put >= 2 workgroups on every CU
+  static const int kSplits[] = {1, 3, 5, 15, 25};
+  int ksplit = 25;
+  for (int ks : kSplits)
+    if ((long long)mtiles * 4 * ks >= 512) {
+      ksplit = ks;
+      break;
+    }
+  AG2_HIP(c, c->d_fcpart.reserve((size_t)ksplit * n_pad * kFcN * 4));
+  hipLaunchKernelGGL(k_lenet_fc1, dim3(mtiles, 4, ksplit), dim3(256), 0, c->stream,
+                     c->d_act1.as<float>(), (int)n, n_pad, d.w3p.as<float>(), 75 / ksplit,
+                     c->d_fcpart.as<float>());
+  hipLaunchKernelGGL(k_lenet_fc_finish, dim3(((int)n + 3) / 4), dim3(256), 0, c->stream,
+                     c->d_fcpart.as<float>(), (int)n, n_pad, ksplit, d.b3.as<float>(),
+                     d.w4.as<float>(), d.b4.as<float>(), d_logits);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }

@@ -19,7 +19,7 @@ namespace ag2 {
 
 constexpr int kSweepThreads = 256;
 constexpr int kSweepWaves = kSweepThreads / kWave;
-constexpr int kLdsCap = 2560;  // cropped points resident in LDS (24 B each); larger samples take
+constexpr int kLdsCap = 2528;  // cropped points resident in LDS (24 B each); larger samples take
                                // the global-scratch instantiation of the same kernel
 
 // ---------------------------------------------------------------------------------------------
@@ -259,7 +259,19 @@ struct SweepArgs {
   float* gscratch;           // global variant: 6 * gcap floats per block
   int gcap;
   float min_z;
+  int flags;                 // bit0: no row tightening (exact K2 accounting, diagnostic)
+  unsigned long long* prof;  // optional per-phase cycle sums (AG2_SWEEP_PROF=1), else nullptr
 };
+
+// phase stamps for the diagnostic build of the launch (thread 0 of each workgroup)
+#define AG2_PROF(i)                                                    \
+  do {                                                                 \
+    if (A.prof && tid == 0) {                                          \
+      const long long _t = clock64();                                  \
+      atomicAdd(&A.prof[i], (unsigned long long)(_t - tprev));         \
+      tprev = _t;                                                      \
+    }                                                                  \
+  } while (0)
 
 struct Red {
   double d[2][kSweepWaves][12];
@@ -267,16 +279,32 @@ struct Red {
   int i[2][kSweepWaves][2];
 };
 
+constexpr int kMaxPieces = 1024;
+constexpr int kRowsPerThread = kMaxRows / kSweepThreads;
+constexpr int kPiecesPerThread = kMaxPieces / kSweepThreads;
+
 struct SweepShared {
-  int row_start[kMaxRows];
-  int row_pref[kMaxRows + 1];
+  int row_start[kMaxRows];       // per stencil row (cy, cz): first sorted position, length
+  int row_len[kMaxRows];
+  int piece_start[kMaxPieces];   // rows cut into pieces of <= PL points
+  unsigned piece_lc[kMaxPieces]; // low 16 bits: length; high 16: survivor count, then offset
+  double fs[20], fsr[20];        // finger-slot table (exact path of pass A, deepen)
+  double depths[kMaxDepths];
+  double cosd[kMaxOrient], sind[kMaxOrient];    // hand angles, f64 (exact path)
+  float cosf_t[kMaxOrient], sinf_t[kMaxOrient]; // and rounded to f32 (classification)
+  unsigned res_a[kSweepWaves][kMaxOrient][2];   // pass A per wave: slot mask, flags
   Red red;
   int wave_cnt[kSweepWaves + 1];
   long long arena_off;
   int flag;
 };
 
-template <bool LDS_STORE>
+// two workgroups per CU: 2 x (control block + LDS-staged cropped list) must fit 160 KiB
+static_assert(((sizeof(SweepShared) + 15) & ~size_t(15)) + (size_t)kLdsCap * 26 <= 81920,
+              "k_sweep<true> no longer fits two workgroups per CU");
+
+// RMAX: compile-time bound on num_orientations (8, 16 or 32) for the per-orientation registers
+template <bool LDS_STORE, int RMAX>
 __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SweepShared& S = *reinterpret_cast<SweepShared*>(smem_raw);
@@ -305,9 +333,30 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
   const double hh = hc.hand_height;
   int red_sel = 0;
   const int n_work = LDS_STORE ? A.n_samples : A.n_overflow;
+  if (tid < 20) {
+    S.fs[tid] = hc.fs[tid];
+    S.fsr[tid] = hc.fsr[tid];
+  }
+  if (tid < kMaxDepths) S.depths[tid] = hc.depths[tid];
+  if (tid < kMaxOrient) {
+    S.cosd[tid] = hc.cos_t[tid];
+    S.sind[tid] = hc.sin_t[tid];
+    S.cosf_t[tid] = (float)hc.cos_t[tid];
+    S.sinf_t[tid] = (float)hc.sin_t[tid];
+  }
+  const int n_depths = hc.n_depths;
+  const double hand_depth = hc.hand_depth;
+  const double slot_inv_step = hc.slot_inv_step, slot_step = hc.slot_step;
+  const double hand_od = hc.hand_outer_diameter, finger_w = hc.finger_width;
+  const double slot_ratio = hc.finger_width * hc.slot_inv_step;  // finger width in slot spacings
+  const int slot_span = hc.slot_span;
+  const double slot_base0 = hc.fs[0], slot_base1 = hc.fs[10];
+  const float r2_hands = hc.r2_hands;
+  const bool tighten = (A.flags & 1) == 0;
 
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     const int t = LDS_STORE ? w : A.overflow[w];
+    long long tprev = A.prof ? clock64() : 0;
     if (!A.frame_ok[t]) continue;  // uniform
     const float4 q = A.sample_q[t];
     const double* fr = A.frames + (size_t)t * 12;
@@ -321,20 +370,184 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
     const int nz = qr.empty ? 0 : (qr.hi[2] - qr.lo[2] + 1);
     const int nrows = ny * nz;  // <= kMaxRows by check_params
     __syncthreads();            // previous sample's readers of S are done
-    {
-      int len[4], tot = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int r = tid * 4 + k;
-        len[k] = 0;
-        if (r < nrows) {
-          const int cz = qr.lo[2] + r / ny, cy = qr.lo[1] + r % ny;
-          const int rowbase = (cz * A.g.dims[1] + cy) * A.g.dims[0];
-          const int b = (int)A.cell[rowbase + qr.lo[0]], e = (int)A.cell[rowbase + qr.hi[0] + 1];
-          S.row_start[r] = b;
-          len[k] = e - b;
+    for (int r = tid; r < nrows; r += kSweepThreads) {
+      const int cz = qr.lo[2] + r / ny, cy = qr.lo[1] + r % ny;
+      int cxa = qr.lo[0], cxb = qr.hi[0];
+      if (tighten) {
+        // Shrink the row's x-cell range to what the sphere |p - q| < r and the crop slab
+        // |curv . (p - q)| < hand_height can reach.  Purely conservative (mg = 0.3 mm of slack on
+        // every bound, three orders above the float rounding of these few operations): the exact
+        // per-point tests below still decide, so the surviving set and its order are unchanged.
+        const float mg = 3.0e-4f;
+        const float h = 1.0f / A.g.inv;
+        const float dyl = (A.g.o[1] + (float)cy * h) - q.y - mg, dyh = dyl + h + 2.0f * mg;
+        const float dzl = (A.g.o[2] + (float)cz * h) - q.z - mg, dzh = dzl + h + 2.0f * mg;
+        const float dym = dyl > 0.f ? dyl : (dyh < 0.f ? -dyh : 0.f);
+        const float dzm = dzl > 0.f ? dzl : (dzh < 0.f ? -dzh : 0.f);
+        const float rm = hc.rq_hands + mg;
+        const float rho2 = rm * rm - dym * dym - dzm * dzm;
+        bool empty = !(rho2 > 0.f);
+        float xa = 0.f, xb = 0.f;
+        if (!empty) {
+          const float rho = __builtin_sqrtf(rho2);
+          xa = -rho;
+          xb = rho;
+          const float cxn = (float)F[0][2], cyn = (float)F[1][2], czn = (float)F[2][2];
+          const float hm = (float)hh + mg;
+          const float slo = cyn * (cyn >= 0.f ? dyl : dyh) + czn * (czn >= 0.f ? dzl : dzh);
+          const float shi = cyn * (cyn >= 0.f ? dyh : dyl) + czn * (czn >= 0.f ? dzh : dzl);
+          const float ulo = -hm - shi - mg, uhi = hm - slo + mg;  // cxn * dx must lie in (ulo, uhi)
+          const float acx = __builtin_fabsf(cxn);
+          if (uhi < -acx * rho || ulo > acx * rho) {
+            empty = true;
+          } else if (acx > 1.0e-4f) {
+            const float a = ulo / cxn, b2 = uhi / cxn;
+            const float sa = (a < b2 ? a : b2) - mg, sb = (a < b2 ? b2 : a) + mg;
+            xa = sa > xa ? sa : xa;
+            xb = sb < xb ? sb : xb;
+            if (xa > xb) empty = true;
+          }
         }
-        tot += len[k];
+        if (empty) {
+          cxb = cxa - 1;
+        } else {
+          cxa = max(cxa, cell_of(q.x + xa - mg, A.g.o[0], A.g.inv));
+          cxb = min(cxb, cell_of(q.x + xb + mg, A.g.o[0], A.g.inv));
+        }
+      }
+      const int rowbase = (cz * A.g.dims[1] + cy) * A.g.dims[0];
+      int b = 0, e = 0;
+      if (cxa <= cxb) {
+        b = (int)A.cell[rowbase + cxa];
+        e = (int)A.cell[rowbase + cxb + 1];
+      }
+      S.row_start[r] = b;
+      S.row_len[r] = e - b;
+    }
+    __syncthreads();
+    // ---- piece table: rows cut into pieces of <= PL consecutive points, in canonical order -----
+    // One thread walks one piece, so all 256 threads have an independent stream of loads in flight
+    // (the rows are short after the culling above; a wave per row would idle most lanes).
+    int nrows_c = 0, kcand = 0;
+    {
+      int cnt = 0, tot = 0;
+#pragma unroll
+      for (int k = 0; k < kRowsPerThread; k++) {
+        const int r = tid * kRowsPerThread + k;
+        const int l = (r < nrows) ? S.row_len[r] : 0;
+        cnt += (l > 0) ? 1 : 0;
+        tot += l;
+      }
+      cnt = wave_sum_i(cnt);
+      tot = wave_sum_i(tot);
+      if (lane == 0) {
+        S.wave_cnt[wid] = cnt;
+        S.red.i[0][wid][0] = tot;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kSweepWaves; k++) {
+        nrows_c += S.wave_cnt[k];
+        kcand += S.red.i[0][k][0];
+      }
+    }
+    int PL = 32;  // piece length; grows only if the table would overflow (dense clouds)
+    while (kcand / PL + nrows_c > kMaxPieces) PL <<= 1;
+    int n_pieces = 0;
+    {
+      int len[kRowsPerThread], st[kRowsPerThread], np = 0;
+#pragma unroll
+      for (int k = 0; k < kRowsPerThread; k++) {
+        const int r = tid * kRowsPerThread + k;
+        len[k] = (r < nrows) ? S.row_len[r] : 0;
+        st[k] = (r < nrows) ? S.row_start[r] : 0;
+        np += (len[k] + PL - 1) / PL;
+      }
+      int inc = np;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+      }
+      __syncthreads();  // totals above have been read by everyone
+      if (lane == 63) S.wave_cnt[wid] = inc;
+      __syncthreads();
+      int poff = 0;
+#pragma unroll
+      for (int k = 0; k < kSweepWaves; k++) {
+        if (k < wid) poff += S.wave_cnt[k];
+        n_pieces += S.wave_cnt[k];
+      }
+      int pi = poff + inc - np;
+#pragma unroll
+      for (int k = 0; k < kRowsPerThread; k++)
+        for (int o = 0; o < len[k]; o += PL) {
+          S.piece_start[pi] = st[k] + o;
+          S.piece_lc[pi] = (unsigned)min(PL, len[k] - o);  // low 16: length, high 16: count/offset
+          pi++;
+        }
+      __syncthreads();
+    }
+    AG2_PROF(0);
+
+    // ---- crop to the +-hand_height slab, ordered compaction --------------------------------
+    auto classify = [&](const float4& p, float4& d) -> int {  // 0 miss, 1 in radius, 3 + in slab
+      d = make_float4(p.x - q.x, p.y - q.y, p.z - q.z, 0.f);
+      const float d2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
+      if (!(d2 < r2_hands)) return 0;
+      // hand_search.cpp:209-210 centred in float then widened; :329-339 crop on row 2 of frame^T p
+      const double p0 = (double)d.x, p1 = (double)d.y, p2 = (double)d.z;
+      const double zf = (F[0][2] * p0 + F[1][2] * p1) + F[2][2] * p2;
+      return (zf > -1.0 * hh && zf < hh) ? 3 : 1;
+    };
+    // pass 1: survivors per piece.  Each HALF-wave (32 lanes) takes one piece, so one load
+    // instruction covers two pieces with 16-B-per-lane contiguous reads, and four such
+    // instructions are issued before the first result is needed (the path is latency-bound).
+    const int half = lane >> 5, l31 = lane & 31;
+    const unsigned long long half_mask = half ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+    const int n_pairs = (n_pieces + 1) >> 1;
+    int my_k2 = 0;
+    for (int pp0 = wid; pp0 < n_pairs; pp0 += 4 * kSweepWaves) {
+      int pb[4], pl[4];
+      float4 pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int pc = 2 * (pp0 + u * kSweepWaves) + half;
+        const bool ok = pc < n_pieces;
+        pb[u] = ok ? S.piece_start[pc] : 0;
+        pl[u] = ok ? (int)(S.piece_lc[pc] & 0xFFFFu) : 0;
+        pv[u] = make_float4(0, 0, 0, 0);
+        if (l31 < pl[u]) pv[u] = A.pts[pb[u] + l31];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int pc = 2 * (pp0 + u * kSweepWaves) + half;
+        float4 d;
+        int cls = (l31 < pl[u]) ? classify(pv[u], d) : 0;
+        int keep = __popcll(__ballot(cls == 3) & half_mask);
+        my_k2 += (cls != 0) ? 1 : 0;
+        for (int o = 32; o < pl[u]; o += 32) {  // pieces longer than 32 (dense clouds)
+          const int j = o + l31;
+          cls = (j < pl[u]) ? classify(A.pts[pb[u] + j], d) : 0;
+          keep += __popcll(__ballot(cls == 3) & half_mask);
+          my_k2 += (cls != 0) ? 1 : 0;
+        }
+        if (l31 == 0 && pc < n_pieces) S.piece_lc[pc] = (unsigned)pl[u] | ((unsigned)keep << 16);
+      }
+    }
+    my_k2 = wave_sum_i(my_k2);
+    if (lane == 0) S.red.i[0][wid][0] = my_k2;
+    __syncthreads();
+    AG2_PROF(1);
+    // exclusive scan of the per-piece counts (thread t owns pieces 4t .. 4t+3)
+    int K = 0, k2 = 0;
+    {
+      int c[kPiecesPerThread], tot = 0;
+#pragma unroll
+      for (int k = 0; k < kPiecesPerThread; k++) {
+        const int pc = tid * kPiecesPerThread + k;
+        c[k] = (pc < n_pieces) ? (int)(S.piece_lc[pc] >> 16) : 0;
+        tot += c[k];
       }
       int inc = tot;
 #pragma unroll
@@ -345,58 +558,21 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
       if (lane == 63) S.wave_cnt[wid] = inc;
       __syncthreads();
       int woff = 0;
-      for (int k = 0; k < wid; k++) woff += S.wave_cnt[k];
-      int run = woff + inc - tot;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int r = tid * 4 + k;
-        if (r < nrows) S.row_pref[r] = run;
-        run += len[k];
+      for (int k = 0; k < kSweepWaves; k++) {
+        if (k < wid) woff += S.wave_cnt[k];
+        K += S.wave_cnt[k];
+        k2 += S.red.i[0][k][0];
       }
-      if (tid == kSweepThreads - 1) S.row_pref[nrows] = run;  // rows beyond nrows have len 0
-      __syncthreads();
-    }
-    const int kcand = S.row_pref[nrows];
-
-    // ---- crop to the +-hand_height slab, ordered compaction (two passes, no barriers inside) ---
-    // each wave owns a contiguous quarter of the candidate sequence
-    const int seg = (((kcand + kSweepWaves - 1) / kSweepWaves) + 63) & ~63;
-    const int cbeg = min(wid * seg, kcand), cend = min(cbeg + seg, kcand);
-    auto test = [&](int gidx, float4& pout) -> int {  // 0: miss, 1: in radius, 3: in radius + slab
-      int lo = 0, hi = nrows;  // last row with row_pref <= gidx
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (S.row_pref[mid] <= gidx) lo = mid; else hi = mid;
+      if (K <= CAP) {  // offsets fit 16 bits: CAP <= 65536 and an offset is < K
+        int run = woff + inc - tot;
+#pragma unroll
+        for (int k = 0; k < kPiecesPerThread; k++) {
+          const int pc = tid * kPiecesPerThread + k;
+          if (pc < n_pieces) S.piece_lc[pc] = (S.piece_lc[pc] & 0xFFFFu) | ((unsigned)run << 16);
+          run += c[k];
+        }
       }
-      const int pos = S.row_start[lo] + (gidx - S.row_pref[lo]);
-      const float4 p = A.pts[pos];
-      pout = make_float4(p.x - q.x, p.y - q.y, p.z - q.z, __int_as_float(pos));
-      const float d2 = (pout.x * pout.x + pout.y * pout.y) + pout.z * pout.z;
-      if (!(d2 < hc.r2_hands)) return 0;
-      // hand_search.cpp:209-210 centred in float then widened; :329-339 crop on row 2 of frame^T p
-      const double p0 = (double)pout.x, p1 = (double)pout.y, p2 = (double)pout.z;
-      const double zf = (F[0][2] * p0 + F[1][2] * p1) + F[2][2] * p2;
-      return (zf > -1.0 * hh && zf < hh) ? 3 : 1;
-    };
-    int my_keep = 0, my_k2 = 0;
-    for (int g0 = cbeg; g0 < cend; g0 += 64) {
-      const int gi = g0 + lane;
-      int r = 0;
-      float4 pp;
-      if (gi < cend) r = test(gi, pp);
-      my_k2 += __popcll(__ballot(r != 0));
-      my_keep += __popcll(__ballot(r == 3));
-    }
-    if (lane == 0) {
-      S.wave_cnt[wid] = my_keep;
-      S.red.i[0][wid][0] = my_k2;
-    }
-    __syncthreads();
-    int kbase = 0, K = 0, k2 = 0;
-    for (int k = 0; k < kSweepWaves; k++) {
-      if (k < wid) kbase += S.wave_cnt[k];
-      K += S.wave_cnt[k];
-      k2 += S.red.i[0][k][0];
     }
     const bool too_big = K > CAP;
     if (too_big) {  // uniform
@@ -411,76 +587,183 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
       continue;
     }
     if (tid == 0) {
-      atomicAdd(&A.st->sum_k2, (unsigned long long)k2);
+      // K2 (all radius neighbours) is only visited when row tightening is off (debug_flags bit 0)
+      if (!tighten) atomicAdd(&A.st->sum_k2, (unsigned long long)k2);
       atomicAdd(&A.st->sum_kcrop, (unsigned long long)K);
     }
-    if (k2 == 0 || K == 0) continue;  // hand_search.cpp:201 / no cropped points => no fingers
-    {
-      int run = kbase;
-      for (int g0 = cbeg; g0 < cend; g0 += 64) {
-        const int gi = g0 + lane;
-        int r = 0;
-        float4 pp;
-        if (gi < cend) r = test(gi, pp);
-        const unsigned long long mask = __ballot(r == 3);
-        if (r == 3) {
-          const int dst = run + __popcll(mask & lt_mask);
-          const float4 nn = A.nrm[__float_as_int(pp.w)];
-          PX[dst] = pp.x; PY[dst] = pp.y; PZ[dst] = pp.z;
-          NX[dst] = nn.x; NY[dst] = nn.y; NZ[dst] = nn.z;
+    if (K == 0) continue;  // hand_search.cpp:201 (no neighbours) / no cropped points => no fingers
+    __syncthreads();
+    // pass 2: write the survivors of each piece at its offset (order within a piece preserved)
+    const unsigned long long lt_half = lt_mask & half_mask;  // lower lanes of my half-wave
+    for (int pp0 = wid; pp0 < n_pairs; pp0 += 4 * kSweepWaves) {
+      int pb[4], pl[4], po[4];
+      float4 pv[4], nv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int pc = 2 * (pp0 + u * kSweepWaves) + half;
+        const bool ok = pc < n_pieces;
+        const unsigned lc = ok ? S.piece_lc[pc] : 0u;
+        pb[u] = ok ? S.piece_start[pc] : 0;
+        pl[u] = (int)(lc & 0xFFFFu);
+        po[u] = (int)(lc >> 16);
+        pv[u] = nv[u] = make_float4(0, 0, 0, 0);
+        if (l31 < pl[u]) {
+          pv[u] = A.pts[pb[u] + l31];
+          nv[u] = A.nrm[pb[u] + l31];
         }
-        run += __popcll(mask);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int dst0 = po[u];
+        float4 d, nn = nv[u];
+        int cls = (l31 < pl[u]) ? classify(pv[u], d) : 0;
+        for (int o = 0;;) {
+          const unsigned long long mask = __ballot(cls == 3);
+          if (cls == 3) {
+            const int dst = dst0 + __popcll(mask & lt_half);
+            PX[dst] = d.x; PY[dst] = d.y; PZ[dst] = d.z;
+            NX[dst] = nn.x; NY[dst] = nn.y; NZ[dst] = nn.z;
+          }
+          dst0 += __popcll(mask & half_mask);
+          o += 32;
+          if (o >= pl[u]) break;
+          const int j = o + l31;
+          cls = 0;
+          if (j < pl[u]) {
+            nn = A.nrm[pb[u] + j];
+            cls = classify(A.pts[pb[u] + j], d);
+          }
+        }
       }
     }
     __syncthreads();
+    AG2_PROF(2);
+
+    // ---- pass A for ALL orientations in one sweep over the LDS list -------------------------
+    // evaluateFingers(points_rot, init_bite) (finger_hand.cpp:17-72) needs, per orientation, only
+    // three facts about the cropped points: is any below the fingertips (y < top), is any behind
+    // the hand (y < bottom), and which of the 20 finger slots hold a point.  All are threshold
+    // tests, so every point is CLASSIFIED from a float32 estimate of its rotated coordinates
+    //   x ~ c (n.p) + s (b.p),  y ~ c (b.p) - s (n.p)      (good to ~3e-7 m)
+    // whenever that estimate is more than 2e-6 m away from every threshold; a point nearer than
+    // that to any threshold (a few per thousand) is redone with the reference's exact f64
+    // expressions.  The decisions are therefore exactly those of the f64 arithmetic, at a fraction
+    // of the f64 work, and the points are read from LDS once instead of once per orientation.
+    const double top0 = hc.init_bite, bottom0 = hc.init_bite - hc.hand_depth;
+    auto exact_A = [&](int i, float fx, float fy, float fz, unsigned& flg, unsigned& blk_bits) {
+      const double cs = S.cosd[i], sn = S.sind[i];
+      const double p0 = (double)fx, p1 = (double)fy, p2 = (double)fz;
+      double c0[3], c1[3];  // columns 0 and 1 of frame_rot = frame * rot, hand_search.cpp:356-357
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        c0[a] = (F[a][0] * cs + F[a][1] * sn) + F[a][2] * 0.0;
+        c1[a] = (F[a][0] * (-1.0 * sn) + F[a][1] * cs) + F[a][2] * 0.0;
+      }
+      const double x = (c0[0] * p0 + c0[1] * p1) + c0[2] * p2;
+      const double y = (c1[0] * p0 + c1[1] * p1) + c1[2] * p2;
+      if (y < top0) {
+        flg |= 1u;
+        if (y < bottom0) flg |= 2u;
+        // strict f64 compares against the slot table (finger_hand.cpp:63).  Usual geometry: only
+        // slots kf-1, kf, kf+1 of each half can hold x; their bounds are re-derived in registers
+        // with the host's own expressions (fs[10+k] = k*step, fs[k] = (k*step - od) + fw,
+        // fsr = fs + fw; ag2_context.hip), bit-identical to the table, branch-free.
+        if (slot_span <= 2) {
+#pragma unroll
+          for (int blk = 0; blk < 2; blk++) {
+            double rel = (x - (blk ? slot_base1 : slot_base0)) * slot_inv_step;
+            rel = __builtin_fmin(__builtin_fmax(rel, -4.0), 14.0);
+            const int kf = (int)__builtin_floor(rel);
+#pragma unroll
+            for (int dk = -1; dk <= 1; dk++) {
+              const int k = kf + dk;
+              const double hk = (double)k * slot_step;
+              const double f = blk ? hk : ((hk - hand_od) + finger_w);
+              const bool in = (x > f) & (x < f + finger_w) & ((unsigned)k < 10u);
+              blk_bits |= in ? (1u << ((blk * 10 + k) & 31)) : 0u;
+            }
+          }
+        } else {
+          for (int kk = 0; kk < 20; kk++)
+            if (x > S.fs[kk] && x < S.fsr[kk]) blk_bits |= (1u << kk);
+        }
+      }
+    };
+    unsigned blk_acc[RMAX], flg_acc[RMAX];  // flg bit0: some point has y < top, bit1: y < bottom
+#pragma unroll
+    for (int i = 0; i < RMAX; i++) {
+      blk_acc[i] = 0;
+      flg_acc[i] = 0;
+    }
+    {
+      const float n0 = (float)F[0][0], n1 = (float)F[1][0], n2 = (float)F[2][0];
+      const float b0 = (float)F[0][1], b1 = (float)F[1][1], b2 = (float)F[2][1];
+      const float top0f = (float)top0, bot0f = (float)bottom0;
+      // Error budget of the estimates: |x|,|y| <= 0.1 m, a dozen f32 roundings => < 1.5e-7 m, i.e.
+      // < 2e-5 slot spacings.  Margins: 1e-6 m on y, 1e-4 spacings (~9e-7 m) on x.
+      const float mY = 1.0e-6f, eX = 1.0e-4f;
+      const float invs = (float)slot_inv_step, rm1 = (float)(slot_ratio - 1.0);
+      const float baseL = (float)slot_base0, baseR = (float)slot_base1;
+      // fast classification is only set up for the usual geometry: 1 < finger width / spacing < 2
+      const bool fast_ok = (slot_span <= 2) && slot_ratio > 1.001 && slot_ratio < 1.999;
+      for (int j = tid; j < K; j += kSweepThreads) {
+        const float px = PX[j], py = PY[j], pz = PZ[j];
+        const float u = (n0 * px + n1 * py) + n2 * pz;
+        const float v = (b0 * px + b1 * py) + b2 * pz;
+#pragma unroll
+        for (int i = 0; i < RMAX; i++) {
+          if (i < R) {
+            const float cf = S.cosf_t[i], sf = S.sinf_t[i];
+            const float xa = cf * u + sf * v, ya = cf * v - sf * u;
+            const bool near_y = (__builtin_fabsf(ya - top0f) < mY) | (__builtin_fabsf(ya - bot0f) < mY);
+            bool near = false;  // near a slot edge (matters only for points below the fingertips)
+            unsigned bits = 0;
+#pragma unroll
+            for (int blk = 0; blk < 2; blk++) {
+              float rel = (xa - (blk ? baseR : baseL)) * invs;
+              rel = __builtin_fminf(__builtin_fmaxf(rel, -4.5f), 14.5f);
+              const float kff = __builtin_floorf(rel);
+              const float frac = rel - kff;
+              const int kf = (int)kff;
+              near |= (frac < eX) | (frac > 1.f - eX) | (__builtin_fabsf(frac - rm1) < eX);
+              // slot kf holds x (0 < frac < 1 < width); slot kf - 1 holds it iff frac + 1 < width
+              bits |= ((unsigned)kf < 10u) ? (1u << ((blk * 10 + kf) & 31)) : 0u;
+              bits |= ((frac < rm1) & ((unsigned)(kf - 1) < 10u)) ? (1u << ((blk * 10 + kf - 1) & 31)) : 0u;
+            }
+            const bool below = ya < top0f;
+            if (fast_ok && !near_y && !(near && below)) {
+              if (below) {
+                flg_acc[i] |= (ya < bot0f) ? 3u : 1u;
+                blk_acc[i] |= bits;
+              }
+            } else {
+              exact_A(i, px, py, pz, flg_acc[i], blk_acc[i]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RMAX; i++) {
+      if (i < R) {
+        const unsigned bsum = wave_or_u(blk_acc[i]), fsum = wave_or_u(flg_acc[i]);
+        if (lane == 0) {
+          S.res_a[wid][i][0] = bsum;
+          S.res_a[wid][i][1] = fsum;
+        }
+      }
+    }
+    __syncthreads();
+    AG2_PROF(3);
 
     // ---- orientations -----------------------------------------------------------------------
     for (int oi = 0; oi < R; oi++) {
-      const double cs = hc.cos_t[oi], sn = hc.sin_t[oi];
-      // rot = [c -s 0; s c 0; 0 0 1], frame_rot = frame * rot, hand_search.cpp:356-357
-      double Fr[3][3];
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        Fr[a][0] = (F[a][0] * cs + F[a][1] * sn) + F[a][2] * 0.0;
-        Fr[a][1] = (F[a][0] * (-1.0 * sn) + F[a][1] * cs) + F[a][2] * 0.0;
-        Fr[a][2] = (F[a][0] * 0.0 + F[a][1] * 0.0) + F[a][2] * 1.0;
-      }
-      // pass A: evaluateFingers(points_rot, init_bite), finger_hand.cpp:17-72, for all 20 slots
-      const double top0 = hc.init_bite, bottom0 = hc.init_bite - hc.hand_depth;
-      unsigned blocked = 0, flags = 0;  // flags bit0: some point has y < top, bit1: y < bottom
-      double miny = __builtin_inf();
-      for (int j = tid; j < K; j += kSweepThreads) {
-        const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
-        const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
-        const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
-        miny = (y < miny) ? y : miny;
-        if (y < top0) {
-          flags |= 1u;
-          if (y < bottom0) flags |= 2u;
-#pragma unroll
-          for (int k = 0; k < 20; k++)
-            if (x > hc.fs[k] && x < hc.fsr[k]) blocked |= (1u << k);
-        }
-      }
-      blocked = wave_or_u(blocked);
-      flags = wave_or_u(flags);
-      miny = wave_min_d(miny);
-      red_sel ^= 1;
-      if (lane == 0) {
-        S.red.u[red_sel][wid][0] = blocked;
-        S.red.u[red_sel][wid][1] = flags;
-        S.red.d[red_sel][wid][0] = miny;
-      }
-      __syncthreads();
-      blocked = 0;
-      flags = 0;
-      double surface = __builtin_inf();
+      AG2_PROF(7);
+      unsigned blocked = 0, flags = 0;
 #pragma unroll
       for (int k = 0; k < kSweepWaves; k++) {
-        blocked |= S.red.u[red_sel][k][0];
-        flags |= S.red.u[red_sel][k][1];
-        const double v = S.red.d[red_sel][k][0];
-        surface = (v < surface) ? v : surface;  // finger_hand.cpp:158 min over ALL rotated points
+        blocked |= S.res_a[k][oi][0];
+        flags |= S.res_a[k][oi][1];
       }
       if ((flags & 2u) || !(flags & 1u)) continue;                  // finger_hand.cpp:35-36, :41-42
       const unsigned free_ = (~blocked) & 0xFFFFFu;
@@ -488,6 +771,16 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
       const unsigned hand = free_ & (free_ >> 10) & 0x3FFu;         // finger_hand.cpp:313-325
       const int nvalid = __popc(hand);
       if (!(nvalid > 0)) continue;                                  // hand_search.cpp:370
+      // From here on everything is the reference's f64 arithmetic, for the few orientations that
+      // pass the gates.  rot = [c -s 0; s c 0; 0 0 1], frame_rot = frame * rot, hand_search.cpp:356-357
+      const double cs = S.cosd[oi], sn = S.sind[oi];
+      double Fr[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        Fr[a][0] = (F[a][0] * cs + F[a][1] * sn) + F[a][2] * 0.0;
+        Fr[a][1] = (F[a][0] * (-1.0 * sn) + F[a][1] * cs) + F[a][2] * 0.0;
+        Fr[a][2] = (F[a][0] * 0.0 + F[a][1] * 0.0) + F[a][2] * 1.0;
+      }
       // deepenHand, finger_hand.cpp:96-134: middle valid hand = valid[ceil(n/2) - 1]
       int idx = 0;
       {
@@ -499,37 +792,50 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
             seen++;
           }
       }
-      const double fl0 = hc.fs[idx], fl1 = hc.fsr[idx], fr0 = hc.fs[10 + idx], fr1 = hc.fsr[10 + idx];
+      const double fl0 = S.fs[idx], fl1 = S.fsr[idx], fr0 = S.fs[10 + idx], fr1 = S.fsr[10 + idx];
       // pass B: first depth step that fails (some point under the finger pads or behind the hand)
-      int kfail = hc.n_depths;
+      // (the same pass yields surface = min y over ALL rotated points, finger_hand.cpp:158)
+      int kfail = n_depths;
+      double miny = __builtin_inf();
       for (int j = tid; j < K; j += kSweepThreads) {
         const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
         const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
         const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
+        miny = (y < miny) ? y : miny;
         const bool zone = (x > fl0 && x < fl1) || (x > fr0 && x < fr1);
         for (int di = 0; di < kfail; di++) {
-          const double d = hc.depths[di];
-          if (y < d && (zone || y < d - hc.hand_depth)) {
+          const double d = S.depths[di];
+          if (y < d && (zone || y < d - hand_depth)) {
             kfail = di;
             break;
           }
         }
       }
       kfail = wave_min_i(kfail);
+      miny = wave_min_d(miny);
       red_sel ^= 1;
-      if (lane == 0) S.red.i[red_sel][wid][0] = kfail;
+      if (lane == 0) {
+        S.red.i[red_sel][wid][0] = kfail;
+        S.red.d[red_sel][wid][0] = miny;
+      }
       __syncthreads();
-      kfail = hc.n_depths;
+      kfail = n_depths;
+      double surface = __builtin_inf();
 #pragma unroll
-      for (int k = 0; k < kSweepWaves; k++) kfail = min(kfail, S.red.i[red_sel][k][0]);
+      for (int k = 0; k < kSweepWaves; k++) {
+        kfail = min(kfail, S.red.i[red_sel][k][0]);
+        const double v = S.red.d[red_sel][k][0];
+        surface = (v < surface) ? v : surface;
+      }
       double top = top0, bottom = bottom0;
       if (kfail > 0) {  // last successful step, finger_hand.cpp:128-129
-        top = hc.depths[kfail - 1];
-        bottom = top - hc.hand_depth;
+        top = S.depths[kfail - 1];
+        bottom = top - hand_depth;
       }
+      AG2_PROF(4);
       // closing region, finger_hand.cpp:137-180
-      const double left = hc.fs[idx] + hc.finger_width;
-      const double right = hc.fs[10 + idx];
+      const double left = fl0 + hc.finger_width;
+      const double right = fr0;
       const double center = 0.5 * (left + right);
       // pass C: in-box points, ordered compaction (each wave a contiguous quarter of the list)
       const int segk = (((K + kSweepWaves - 1) / kSweepWaves) + 63) & ~63;
@@ -592,6 +898,7 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
           run += __popcll(mask);
         }
       }
+      AG2_PROF(5);
       const int slot = t * R + oi;
       if (tid == 0) {
         long long off = -1;
@@ -728,7 +1035,9 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
         atomicAdd(&A.st->n_hyp, 1u);
         atomicAdd(&A.st->sum_p, (unsigned long long)P);
       }
+      AG2_PROF(6);
     }
+    AG2_PROF(7);
   }
 }
 
@@ -812,21 +1121,36 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
   A.st = c->d_stats.as<DevStats>();
   A.overflow = c->d_overflow.as<int>();
   A.min_z = c->min_z;
-  const size_t lds = sweep_lds_bytes(true);
-  static bool attr_set = false;
-  if (!attr_set) {
-    AG2_HIP(c, hipFuncSetAttribute((const void*)k_sweep<true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+  A.flags = c->p.debug_flags & 1;
+  static DevBuf prof_buf;  // diagnostic only: per-phase cycle sums when AG2_SWEEP_PROF is set
+  const bool want_prof = getenv("AG2_SWEEP_PROF") != nullptr;
+  if (want_prof) {
+    AG2_HIP(c, prof_buf.reserve(16 * 8));
+    AG2_HIP(c, hipMemsetAsync(prof_buf.p, 0, 16 * 8, c->stream));
+    A.prof = prof_buf.as<unsigned long long>();
   }
+  const size_t lds = sweep_lds_bytes(true);
+  typedef void (*SweepFn)(SweepArgs);
+  const SweepFn fn_lds = (R <= 8) ? k_sweep<true, 8> : (R <= 16 ? k_sweep<true, 16> : k_sweep<true, 32>);
+  const SweepFn fn_glb = (R <= 8) ? k_sweep<false, 8> : (R <= 16 ? k_sweep<false, 16> : k_sweep<false, 32>);
+  AG2_HIP(c, hipFuncSetAttribute((const void*)fn_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
   const int grid = (int)std::min<size_t>(s, 256 * 2);
-  hipLaunchKernelGGL(k_sweep<true>, dim3(grid), dim3(kSweepThreads), lds, c->stream, A);
+  hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads), lds, c->stream, A);
   AG2_HIP(c, hipGetLastError());
   // overflow samples (cropped neighbourhood larger than the LDS stage): global-scratch variant
   DevStats hs;
   AG2_HIP(c, hipMemcpyAsync(&hs, c->d_stats.p, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
   c->cnt.n_overflow_samples = hs.n_overflow;
+  if (want_prof) {
+    unsigned long long h[8];
+    AG2_HIP(c, hipMemcpy(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[ag2 sweep prof, LDS variant, cycles summed over workgroups] rows %llu crop1 %llu "
+            "crop2 %llu passA %llu deepen %llu passC %llu passD %llu other %llu\n",
+            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    AG2_HIP(c, hipMemsetAsync(prof_buf.p, 0, 16 * 8, c->stream));
+  }
   if (hs.n_overflow > 0) {
     const int gcap = 1 << 16;
     const int g2 = (int)std::min<unsigned>(hs.n_overflow, 512u);
@@ -834,9 +1158,16 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
     A.n_overflow = (int)hs.n_overflow;
     A.gscratch = c->d_gscratch.as<float>();
     A.gcap = gcap;
-    hipLaunchKernelGGL(k_sweep<false>, dim3(g2), dim3(kSweepThreads), sweep_lds_bytes(false),
-                       c->stream, A);
+    hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads), sweep_lds_bytes(false), c->stream, A);
     AG2_HIP(c, hipGetLastError());
+    if (want_prof) {
+      unsigned long long h[8];
+      AG2_HIP(c, hipStreamSynchronize(c->stream));
+      AG2_HIP(c, hipMemcpy(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[ag2 sweep prof, global variant] rows %llu crop1 %llu crop2 %llu passA %llu "
+              "deepen %llu passC %llu passD %llu other %llu\n",
+              h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    }
   }
   return 0;
 }

@@ -177,13 +177,25 @@ def main():
             dist.destroy_process_group()
         return
 
+    # Untimed diagnostic pass: the measured path culls stencil rows by the sphere and the crop slab
+    # and so never visits all K2 radius neighbours; the roofline's algorithmic bytes are defined on
+    # K2, which debug_flags=1 counts exactly.
+    dd = capi.Detector(device=local_rank, **dict(launch_params(ws, R), debug_flags=1))
+    dd.set_stream(torch.cuda.current_stream().cuda_stream)
+    dd.lenet_load(weights)
+    dd.set_cloud_device(xyz_dev.data_ptr(), xyz.shape[0], 12)
+    dd.compute_normals()
+    dd.detect(sample_idx=idx, slot_base=rank * S, seed=args.seed, do_prune=True, want_all=False)
+    sum_k2 = dd.counters().sum_k2
+    dd.close()
+
     K = args.steps
     ms = {k: v / K for k, v in acc.items() if not k.startswith("reserved")}
     n_img = c.n_scored
     # algorithmic work per launch, measured neighbourhood sizes of this run
     kernels = {
         "k_normals": dict(bound="hbm", work=c.sum_k1 * 12 + c.n_valid_points * 12, ms=ms["normals_ms"]),
-        "k_sweep": dict(bound="hbm", work=c.sum_k2 * 24 + c.n_hypotheses * 176 + c.sum_p * 24, ms=ms["sweep_ms"]),
+        "k_sweep": dict(bound="hbm", work=sum_k2 * 24 + c.n_hypotheses * 176 + c.sum_p * 24, ms=ms["sweep_ms"]),
         "k_render": dict(bound="hbm", work=c.sum_p * 24 * (n_img / max(1, c.n_hypotheses)) + n_img * 10800,
                          ms=ms["render_ms"]),
         "k_lenet_conv": dict(bound="mfma", work=n_img * CONV_FLOP, ms=ms["lenet_conv_ms"]),
@@ -225,7 +237,7 @@ def main():
             "n_points": int(xyz.shape[0]), "num_samples_per_gpu": S, "num_orientations": R,
             "hypotheses_per_step_per_gpu": int(c.n_hypotheses), "scored_per_step_per_gpu": int(n_img),
             "slots_swept_per_s": S * R * world / (elapsed / K),
-            "mean_K1": c.sum_k1 / max(1, c.n_valid_points), "mean_K2": c.sum_k2 / max(1, c.n_frames),
+            "mean_K1": c.sum_k1 / max(1, c.n_valid_points), "mean_K2": sum_k2 / max(1, c.n_frames),
             "mean_Kcrop": c.sum_kcrop / max(1, c.n_frames), "mean_P": c.sum_p / max(1, c.n_hypotheses),
             "overflow_samples": int(c.n_overflow_samples),
             "parallelism": ("single GPU" if world == 1 else

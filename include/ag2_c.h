@@ -60,7 +60,9 @@ typedef struct ag2_params {
   double max_aperture;        /* 0.07 */
   double min_score_diff;      /* 500  */
   int32_t num_selected;       /* 50   */
-  int32_t reserved;
+  int32_t debug_flags;        /* 0. bit0: visit every radius neighbour in the hand sweep (no
+                                 sphere/slab row culling) so counters.sum_k2 is exact; results
+                                 are identical either way */
 } ag2_params;
 
 /* One grasp hypothesis = the fixed part of GraspHypothesis

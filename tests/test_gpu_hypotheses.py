@@ -63,9 +63,12 @@ def test_frames_bit_exact(small_scene):
     d.close()
 
 
-def test_hypotheses_small_scene(small_scene):
+@pytest.mark.parametrize("debug_flags", [0, 1])
+def test_hypotheses_small_scene(small_scene, debug_flags):
+    """debug_flags=1 visits every radius neighbour (exact K2 counter); 0 culls rows by the sphere
+    and the crop slab first.  Both must reproduce the oracle exactly."""
     xyz, ws, idx = small_scene
-    o, d = make_pair(xyz, ws)
+    o, d = make_pair(xyz, ws, debug_flags=debug_flags)
     got = d.generate_hypotheses(sample_idx=idx, seed=5)
     want = o.generate_hypotheses(sample_idx=idx, seed=5)
     assert len(want) > 20
@@ -73,7 +76,8 @@ def test_hypotheses_small_scene(small_scene):
     imgs = check_lists_and_images(o, d, want)
     assert imgs.max() > 0
     gc, wc = d.counters(), o.counters()
-    for f in ("n_frames", "n_hypotheses", "sum_k2", "sum_kcrop", "sum_p"):
+    fields = ("n_frames", "n_hypotheses", "sum_kcrop", "sum_p") + (("sum_k2",) if debug_flags else ())
+    for f in fields:
         assert getattr(gc, f) == getattr(wc, f), f
     d.close()
 
