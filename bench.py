@@ -130,9 +130,9 @@ def main():
     d.lenet_load(weights)
     xyz_dev = torch.from_numpy(xyz).cuda()          # HBM-resident input
     torch.cuda.synchronize()
-    slot_bytes = S * R * 176
+    from agile_grasp2_amd import sharding
+    slot_bytes = S * R * sharding.SLOT_BYTES
     local_tab = torch.empty(slot_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
-    gathered = torch.empty(slot_bytes * world, dtype=torch.uint8, device="cuda") if world > 1 else None
 
     acc = {}
 
@@ -142,8 +142,9 @@ def main():
         sel, n_scored = d.detect(sample_idx=idx, slot_base=rank * S, seed=args.seed, do_prune=True,
                                  want_all=False)
         if world > 1:
+            # the path's one exchange step: fixed-slot candidate tables, RCCL all-gather over xGMI
             d.export_candidates_device(local_tab.data_ptr(), slot_bytes)
-            dist.all_gather_into_tensor(gathered, local_tab)
+            sharding.all_gather_tables(local_tab, world)
         return n_scored
 
     def sync():
