@@ -1,0 +1,879 @@
+// ag2_host.cpp -- C++ host mirror of the reference's public classes for the hot path, sitting on
+// the C-ABI of libag2hip.so (include/ag2_c.h).  Same class / method names, argument meaning and
+// error behaviour (empty result + message, never an abort) as the reference; see the headers under
+// include/agile_grasp2/ for the reference file:line each method mirrors.  No compute happens here
+// beyond preprocessing and glue: normals, frames, hand search, images and LeNet run on the GPU.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+#include "agile_grasp2/caffe_classifier.h"
+#include "agile_grasp2/cloud_camera.h"
+#include "agile_grasp2/grasp_detector.h"
+#include "agile_grasp2/grasp_hypothesis.h"
+#include "agile_grasp2/hand_search.h"
+#include "agile_grasp2/learning.h"
+
+using ag2::Matrix3Xd;
+using ag2::Matrix4d;
+using ag2::MatrixXi;
+using ag2::Vector3d;
+
+// ------------------------------------------------------------------------------------------------
+// small matrix helpers
+// ------------------------------------------------------------------------------------------------
+Matrix4d Matrix4d::operator*(const Matrix4d& o) const {
+  Matrix4d r;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double s = 0.0;
+      for (int k = 0; k < 4; k++) s += m[i][k] * o.m[k][j];
+      r.m[i][j] = s;
+    }
+  return r;
+}
+
+Matrix4d Matrix4d::inverse() const {  // Gauss-Jordan with partial pivoting
+  double a[4][8];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      a[i][j] = m[i][j];
+      a[i][4 + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < 4; c++) {
+    int piv = c;
+    for (int r = c + 1; r < 4; r++)
+      if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+    if (piv != c)
+      for (int j = 0; j < 8; j++) std::swap(a[c][j], a[piv][j]);
+    const double d = a[c][c];
+    if (d == 0.0) return Matrix4d();
+    for (int j = 0; j < 8; j++) a[c][j] /= d;
+    for (int r = 0; r < 4; r++)
+      if (r != c) {
+        const double f = a[r][c];
+        for (int j = 0; j < 8; j++) a[r][j] -= f * a[c][j];
+      }
+  }
+  Matrix4d r;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) r.m[i][j] = a[i][4 + j];
+  return r;
+}
+
+namespace {
+uint64_t splitmix(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// CloudCamera
+// ------------------------------------------------------------------------------------------------
+CloudCamera::CloudCamera() : cloud_processed_(new PointCloudRGB), cloud_original_(new PointCloudRGB) {}
+
+static MatrixXi source_matrix(size_t n, int size_left) {
+  if ((size_t)size_left == n) return MatrixXi::Zero(1, (int)n);  // cloud_camera.cpp:14-17 (zeros!)
+  MatrixXi s = MatrixXi::Zero(2, (int)n);
+  for (int i = 0; i < size_left; i++) s(0, i) = 1;
+  for (size_t i = (size_t)size_left; i < n; i++) s(1, (int)i) = 1;
+  return s;
+}
+
+CloudCamera::CloudCamera(const PointCloudNormal::Ptr& cloud, int size_left_cloud)
+    : cloud_processed_(new PointCloudRGB), cloud_original_(new PointCloudRGB) {
+  const size_t n = cloud->size();
+  cloud_original_->points.resize(n);
+  for (size_t i = 0; i < n; i++) {
+    ag2::PointXYZRGBA& d = cloud_original_->points[i];
+    const ag2::PointXYZRGBNormal& s = cloud->points[i];
+    d.x = s.x; d.y = s.y; d.z = s.z; d.rgba = s.rgba;
+  }
+  *cloud_processed_ = *cloud_original_;
+  camera_source_ = source_matrix(n, size_left_cloud);
+  normals_.resize(3, (int)n);
+  for (size_t i = 0; i < n; i++) {
+    normals_(0, (int)i) = cloud->points[i].normal_x;
+    normals_(1, (int)i) = cloud->points[i].normal_y;
+    normals_(2, (int)i) = cloud->points[i].normal_z;
+  }
+}
+
+CloudCamera::CloudCamera(const PointCloudRGB::Ptr& cloud, int size_left_cloud)
+    : cloud_processed_(cloud), cloud_original_(cloud) {
+  camera_source_ = source_matrix(cloud->size(), size_left_cloud);
+}
+
+CloudCamera::CloudCamera(const std::string& filename) : cloud_processed_(new PointCloudRGB) {
+  cloud_processed_ = loadPointCloudFromFile(filename);
+  cloud_original_ = cloud_processed_;
+  camera_source_ = MatrixXi::Ones(1, (int)cloud_processed_->size());  // cloud_camera.cpp:59
+}
+
+CloudCamera::CloudCamera(const std::string& filename_left, const std::string& filename_right)
+    : cloud_processed_(new PointCloudRGB) {
+  PointCloudRGB::Ptr l = loadPointCloudFromFile(filename_left), r = loadPointCloudFromFile(filename_right);
+  cloud_processed_->points = l->points;
+  cloud_processed_->points.insert(cloud_processed_->points.end(), r->points.begin(), r->points.end());
+  cloud_original_ = cloud_processed_;
+  camera_source_ = MatrixXi::Zero(2, (int)cloud_processed_->size());
+  for (size_t i = 0; i < l->size(); i++) camera_source_(0, (int)i) = 1;
+  for (size_t i = 0; i < r->size(); i++) camera_source_(1, (int)(l->size() + i)) = 1;
+}
+
+void CloudCamera::filterWorkspace(const std::vector<double>& ws) {
+  if (ws.size() < 6) return;
+  std::vector<int> keep;
+  for (size_t i = 0; i < cloud_processed_->size(); i++) {
+    const ag2::PointXYZRGBA& p = cloud_processed_->points[i];
+    if (p.x > ws[0] && p.x < ws[1] && p.y > ws[2] && p.y < ws[3] && p.z > ws[4] && p.z < ws[5])
+      keep.push_back((int)i);
+  }
+  PointCloudRGB::Ptr cloud(new PointCloudRGB);
+  cloud->points.resize(keep.size());
+  MatrixXi src(camera_source_.rows(), (int)keep.size());
+  for (size_t i = 0; i < keep.size(); i++) {
+    cloud->points[i] = cloud_processed_->points[keep[i]];
+    for (int c = 0; c < camera_source_.rows(); c++) src(c, (int)i) = camera_source_(c, keep[i]);
+  }
+  if (normals_.cols() > 0) {
+    Matrix3Xd n(3, (int)keep.size());
+    for (size_t i = 0; i < keep.size(); i++)
+      for (int k = 0; k < 3; k++) n(k, (int)i) = normals_(k, keep[i]);
+    normals_ = n;
+  }
+  cloud_processed_ = cloud;
+  camera_source_ = src;
+}
+
+void CloudCamera::voxelizeCloud(double cell_size) {
+  const size_t n = cloud_processed_->size();
+  if (n == 0) return;
+  float mn[3] = {cloud_processed_->points[0].x, cloud_processed_->points[0].y, cloud_processed_->points[0].z};
+  for (size_t i = 1; i < n; i++) {
+    const ag2::PointXYZRGBA& p = cloud_processed_->points[i];
+    mn[0] = std::min(mn[0], p.x); mn[1] = std::min(mn[1], p.y); mn[2] = std::min(mn[2], p.z);
+  }
+  const float cell = (float)cell_size;
+  // std::set with the reference's comparator == map ordered by (ix, iy, iz); value = first index
+  std::map<std::array<int, 3>, int> bins;
+  for (size_t i = 0; i < n; i++) {
+    const ag2::PointXYZRGBA& p = cloud_processed_->points[i];
+    const std::array<int, 3> v = {(int)std::floor((p.x - mn[0]) / cell), (int)std::floor((p.y - mn[1]) / cell),
+                                  (int)std::floor((p.z - mn[2]) / cell)};
+    bins.insert(std::make_pair(v, (int)i));  // keeps the first point that hit the voxel
+  }
+  PointCloudRGB::Ptr cloud(new PointCloudRGB);
+  cloud->points.resize(bins.size());
+  MatrixXi src(camera_source_.rows(), (int)bins.size());
+  int i = 0;
+  for (const auto& kv : bins) {
+    ag2::PointXYZRGBA& d = cloud->points[i];
+    d.x = (float)kv.first[0] * cell + mn[0];
+    d.y = (float)kv.first[1] * cell + mn[1];
+    d.z = (float)kv.first[2] * cell + mn[2];
+    for (int c = 0; c < camera_source_.rows(); c++) src(c, i) = (camera_source_(c, kv.second) == 1) ? 1 : 0;
+    i++;
+  }
+  cloud_processed_ = cloud;
+  camera_source_ = src;
+  normals_ = Matrix3Xd();  // the reference does not carry normals through voxelisation either
+}
+
+void CloudCamera::subsampleUniformly(int num_samples, uint64_t seed) {
+  const int n = (int)cloud_processed_->size();
+  const int k = std::min(num_samples, n);
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; i++) idx[i] = i;
+  uint64_t s = seed ^ 0xA5A5A5A5DEADBEEFull;
+  for (int i = 0; i < k; i++) {  // partial Fisher-Yates
+    const int j = i + (int)(splitmix(s) % (uint64_t)(n - i));
+    std::swap(idx[i], idx[j]);
+  }
+  idx.resize(k);
+  std::sort(idx.begin(), idx.end());  // pcl::RandomSample returns ascending indices
+  sample_indices_ = idx;
+}
+
+void CloudCamera::subsampleSamples(const agile_grasp2::SamplesMsg& msg, int num_samples, uint64_t seed) {
+  const int n = (int)msg.samples.size();
+  std::vector<int> seq(n);
+  for (int i = 0; i < n; i++) seq[i] = i;
+  int k = n;
+  if (num_samples < n) {
+    uint64_t s = seed ^ 0x1234567887654321ull;
+    for (int i = n - 1; i > 0; i--) std::swap(seq[i], seq[(int)(splitmix(s) % (uint64_t)(i + 1))]);
+    k = num_samples;
+  }
+  samples_.resize(3, k);
+  for (int i = 0; i < k; i++) {
+    samples_(0, i) = msg.samples[seq[i]].x;
+    samples_(1, i) = msg.samples[seq[i]].y;
+    samples_(2, i) = msg.samples[seq[i]].z;
+  }
+}
+
+void CloudCamera::setSamples(const agile_grasp2::SamplesMsg& msg) {
+  samples_.resize(3, (int)msg.samples.size());
+  for (size_t i = 0; i < msg.samples.size(); i++) {
+    samples_(0, (int)i) = msg.samples[i].x;
+    samples_(1, (int)i) = msg.samples[i].y;
+    samples_(2, (int)i) = msg.samples[i].z;
+  }
+}
+
+// PCD reader (ASCII / binary, un-compressed): fields x y z (float32) and optionally rgb / rgba.
+PointCloudRGB::Ptr CloudCamera::loadPointCloudFromFile(const std::string& filename) {
+  PointCloudRGB::Ptr cloud(new PointCloudRGB);
+  std::ifstream f(filename.c_str(), std::ios::binary);
+  if (!f) {
+    fprintf(stderr, "Couldn't read .pcd file: %s\n", filename.c_str());  // cloud_camera.cpp:236
+    return cloud;
+  }
+  std::vector<std::string> fields;
+  std::vector<int> sizes, counts;
+  std::vector<char> types;
+  size_t npts = 0;
+  std::string data_mode, line;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (line.empty() || line[0] == '#') continue;
+    std::istringstream is(line);
+    std::string key;
+    is >> key;
+    if (key == "FIELDS") { std::string s; while (is >> s) fields.push_back(s); }
+    else if (key == "SIZE") { int v; while (is >> v) sizes.push_back(v); }
+    else if (key == "TYPE") { char c; while (is >> c) types.push_back(c); }
+    else if (key == "COUNT") { int v; while (is >> v) counts.push_back(v); }
+    else if (key == "POINTS") { is >> npts; }
+    else if (key == "DATA") { is >> data_mode; break; }
+  }
+  if (counts.empty()) counts.assign(fields.size(), 1);
+  if (fields.empty() || sizes.size() != fields.size() || (data_mode != "ascii" && data_mode != "binary")) {
+    fprintf(stderr, "Couldn't read .pcd file: %s (unsupported header)\n", filename.c_str());
+    return cloud;
+  }
+  int off = 0, ox = -1, oy = -1, oz = -1, orgb = -1, ix = -1, iy = -1, iz = -1, irgb = -1, col = 0;
+  for (size_t k = 0; k < fields.size(); k++) {
+    if (fields[k] == "x") { ox = off; ix = col; }
+    if (fields[k] == "y") { oy = off; iy = col; }
+    if (fields[k] == "z") { oz = off; iz = col; }
+    if (fields[k] == "rgb" || fields[k] == "rgba") { orgb = off; irgb = col; }
+    off += sizes[k] * counts[k];
+    col += counts[k];
+  }
+  if (ox < 0 || oy < 0 || oz < 0) {
+    fprintf(stderr, "Couldn't read .pcd file: %s (no x y z fields)\n", filename.c_str());
+    return cloud;
+  }
+  cloud->points.resize(npts);
+  if (data_mode == "binary") {
+    std::vector<char> rec((size_t)off);
+    for (size_t i = 0; i < npts; i++) {
+      if (!f.read(rec.data(), off)) { cloud->points.resize(i); break; }
+      ag2::PointXYZRGBA& p = cloud->points[i];
+      std::memcpy(&p.x, &rec[ox], 4); std::memcpy(&p.y, &rec[oy], 4); std::memcpy(&p.z, &rec[oz], 4);
+      if (orgb >= 0) std::memcpy(&p.rgba, &rec[orgb], 4);
+    }
+  } else {
+    for (size_t i = 0; i < npts; i++) {
+      if (!std::getline(f, line)) { cloud->points.resize(i); break; }
+      std::istringstream is(line);
+      std::vector<std::string> tok;
+      std::string s;
+      while (is >> s) tok.push_back(s);
+      if ((int)tok.size() < col) { cloud->points.resize(i); break; }
+      ag2::PointXYZRGBA& p = cloud->points[i];
+      p.x = std::strtof(tok[ix].c_str(), nullptr);
+      p.y = std::strtof(tok[iy].c_str(), nullptr);
+      p.z = std::strtof(tok[iz].c_str(), nullptr);
+      if (irgb >= 0) {
+        const float v = std::strtof(tok[irgb].c_str(), nullptr);
+        std::memcpy(&p.rgba, &v, 4);
+      }
+    }
+  }
+  return cloud;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GraspHypothesis
+// ------------------------------------------------------------------------------------------------
+GraspHypothesis::GraspHypothesis(const ag2_hypothesis& r)
+    : cam_source_(-1), axis_(r.axis[0], r.axis[1], r.axis[2]),
+      approach_(r.approach[0], r.approach[1], r.approach[2]),
+      binormal_(r.binormal[0], r.binormal[1], r.binormal[2]),
+      grasp_surface_(r.surface[0], r.surface[1], r.surface[2]),
+      grasp_bottom_(r.bottom[0], r.bottom[1], r.bottom[2]), grasp_top_(r.top[0], r.top[1], r.top[2]),
+      grasp_width_(r.width), score_(r.score), full_antipodal_(r.full_antipodal != 0),
+      half_antipodal_(r.half_antipodal != 0), sample_slot_(r.sample_slot), orientation_(r.orientation) {}
+
+agile_grasp2::GraspMsg GraspHypothesis::convertToGraspMsg() const {
+  agile_grasp2::GraspMsg m;
+  m.surface = {grasp_surface_(0), grasp_surface_(1), grasp_surface_(2)};
+  m.bottom = {grasp_bottom_(0), grasp_bottom_(1), grasp_bottom_(2)};
+  m.top = {grasp_top_(0), grasp_top_(1), grasp_top_(2)};
+  m.axis = {axis_(0), axis_(1), axis_(2)};
+  m.approach = {approach_(0), approach_(1), approach_(2)};
+  m.binormal = {binormal_(0), binormal_(1), binormal_(2)};
+  m.width = (float)grasp_width_;
+  m.score = (float)score_;
+  return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Context / HandSearch
+// ------------------------------------------------------------------------------------------------
+ag2::Context::Context(const ag2_params& p, int device) : c_(ag2_create(&p, device)), p_(p) {}
+ag2::Context::~Context() { if (c_) ag2_destroy(c_); }
+
+ag2_params HandSearch::toAbiParams(const Parameters& hp, int n_cams) {
+  ag2_params p;
+  ag2_default_params(&p);
+  p.finger_width = hp.finger_width_;
+  p.hand_outer_diameter = hp.hand_outer_diameter_;
+  p.hand_depth = hp.hand_depth_;
+  p.hand_height = hp.hand_height_;
+  p.init_bite = hp.init_bite_;
+  p.nn_radius_taubin = hp.nn_radius_taubin_;
+  p.nn_radius_hands = hp.nn_radius_hands_;
+  p.num_orientations = hp.num_orientations_;
+  p.num_threads = hp.num_threads_;
+  p.n_cams = n_cams;
+  for (int k = 0; k < 3; k++) {  // local_frame.cpp:8-12: translation column of the camera poses
+    p.cam_origin[0][k] = hp.cam_tf_left_(k, 3);
+    p.cam_origin[1][k] = hp.cam_tf_right_(k, 3);
+  }
+  return p;
+}
+
+int HandSearch::uploadCloud(ag2_ctx* ctx, const CloudCamera& cc) {
+  const PointCloudRGB::Ptr& cloud = cc.getCloudProcessed();
+  const size_t n = cloud->size();
+  const MatrixXi& src = cc.getCameraSource();
+  const Matrix3Xd& nrm = cc.getNormals();
+  const bool has_n = (size_t)nrm.cols() == n && n > 0;
+  int rc = ag2_set_cloud(ctx, n ? &cloud->points[0].x : nullptr, n, sizeof(ag2::PointXYZRGBA),
+                         src.cols() == (int)n && n ? src.data() : nullptr, std::max(1, src.rows()),
+                         has_n ? nrm.data() : nullptr);
+  if (rc) return rc;
+  if (!has_n) rc = ag2_compute_normals(ctx);  // hand_search.cpp:20-29
+  return rc;
+}
+
+std::vector<GraspHypothesis> HandSearch::generateHypotheses(const CloudCamera& cloud_cam, int, bool use_samples,
+                                                            bool, bool, bool) {
+  std::vector<GraspHypothesis> out;
+  const int n_cams = std::max(1, cloud_cam.getCameraSource().rows());
+  if (!ctx_ || ctx_->params().n_cams != n_cams) {
+    ctx_.reset(new ag2::Context(toAbiParams(params_, n_cams), device_));
+    if (!ctx_->ok()) {
+      fprintf(stderr, "HandSearch: could not create a GPU context (no CPU fallback)\n");
+      ctx_.reset();
+      return out;
+    }
+  }
+  ag2_ctx* c = ctx_->get();
+  int rc = uploadCloud(c, cloud_cam);
+  const size_t s = use_samples ? (size_t)cloud_cam.getSamples().cols() : cloud_cam.getSampleIndices().size();
+  std::vector<ag2_hypothesis> recs(std::max<size_t>(1, s * (size_t)params_.num_orientations_));
+  size_t n = 0;
+  if (!rc) {
+    std::vector<int32_t> idx(cloud_cam.getSampleIndices().begin(), cloud_cam.getSampleIndices().end());
+    rc = ag2_generate_hypotheses(c, use_samples ? nullptr : idx.data(),
+                                 use_samples ? cloud_cam.getSamples().data() : nullptr, s, 0, seed_,
+                                 recs.data(), recs.size(), &n);
+  }
+  if (rc) {
+    fprintf(stderr, "HandSearch::generateHypotheses: %s\n", ag2_last_error(c));
+    return out;
+  }
+  out.reserve(n);
+  for (size_t h = 0; h < n; h++) {
+    GraspHypothesis g(recs[h]);
+    Matrix3Xd pts(3, recs[h].n_points), nrm(3, recs[h].n_points);
+    if (ag2_hyp_points(c, h, pts.data(), nrm.data()) == 0) g.setPointsForLearning(std::move(pts), std::move(nrm));
+    out.push_back(std::move(g));
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Learning
+// ------------------------------------------------------------------------------------------------
+std::vector<ag2::Image> Learning::createGraspImages(const std::vector<GraspHypothesis>& hands,
+                                                    const Matrix3Xd&, bool, bool) {
+  std::vector<ag2::Image> out;
+  if (hands.empty()) return out;
+  if (num_horizontal_cells_ != 60 || num_vertical_cells_ != 60) {
+    fprintf(stderr, "Learning: only 60x60 grasp images are supported\n");
+    return out;
+  }
+  if (!ctx_) {
+    ag2_params p;
+    ag2_default_params(&p);
+    ctx_.reset(new ag2::Context(p, 0));
+  }
+  if (!ctx_->ok()) {
+    fprintf(stderr, "Learning: could not create a GPU context (no CPU fallback)\n");
+    return out;
+  }
+  std::vector<int64_t> offs(hands.size() + 1, 0);
+  for (size_t i = 0; i < hands.size(); i++) offs[i + 1] = offs[i] + hands[i].getPointsForLearning().cols();
+  std::vector<double> pts((size_t)std::max<int64_t>(offs.back(), 1) * 3), nrm(pts.size());
+  for (size_t i = 0; i < hands.size(); i++) {
+    const Matrix3Xd& p = hands[i].getPointsForLearning();
+    const Matrix3Xd& q = hands[i].getNormalsForLearning();
+    std::copy(p.d.begin(), p.d.end(), pts.begin() + offs[i] * 3);
+    std::copy(q.d.begin(), q.d.end(), nrm.begin() + offs[i] * 3);
+  }
+  std::vector<uint8_t> raw(hands.size() * 10800);
+  const int rc = ag2_render_images_from_points(ctx_->get(), hands.size(), offs.data(), pts.data(), nrm.data(),
+                                               raw.data());
+  if (rc) {
+    fprintf(stderr, "Learning::createGraspImages: %s\n", ag2_last_error(ctx_->get()));
+    return out;
+  }
+  out.resize(hands.size());
+  for (size_t i = 0; i < hands.size(); i++) {
+    out[i].rows = out[i].cols = 60;
+    out[i].chans = 3;
+    out[i].data.assign(raw.begin() + i * 10800, raw.begin() + (i + 1) * 10800);
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Classifier
+// ------------------------------------------------------------------------------------------------
+static const size_t kBlobSizes[8] = {20 * 3 * 25, 20, 50 * 20 * 25, 50, 500 * 7200, 500, 2 * 500, 2};
+
+Classifier::Classifier(const std::string& model_file, const std::string& trained_file,
+                       const std::string& label_file) {
+  if (!model_file.empty()) {
+    std::ifstream m(model_file.c_str());
+    if (!m) { err_ = "cannot open model file " + model_file; return; }
+  }
+  std::ifstream f(trained_file.c_str(), std::ios::binary);
+  char magic[4] = {0, 0, 0, 0};
+  if (!f || !f.read(magic, 4) || std::memcmp(magic, "AG2W", 4) != 0) {
+    err_ = "cannot read weights (expected an .ag2w container): " + trained_file;
+    return;
+  }
+  for (int b = 0; b < 8; b++) {
+    blobs_[b].resize(kBlobSizes[b]);
+    if (!f.read(reinterpret_cast<char*>(blobs_[b].data()), (std::streamsize)(kBlobSizes[b] * 4))) {
+      err_ = "truncated weights file " + trained_file;
+      return;
+    }
+  }
+  std::ifstream l(label_file.c_str());
+  if (!l) { err_ = "Unable to open labels file " + label_file; return; }  // caffe_classifier.cpp:27
+  std::string line;
+  while (std::getline(l, line)) labels_.push_back(line);
+  if (labels_.size() != 2) { err_ = "Number of labels is different from the output layer dimension."; return; }
+  ok_ = true;
+}
+
+void Classifier::setContext(std::shared_ptr<ag2::Context> ctx) {
+  ctx_ = std::move(ctx);
+  uploaded_ = false;
+}
+
+bool Classifier::ensureLoaded() {
+  if (!ok_) return false;
+  if (!ctx_) {
+    ag2_params p;
+    ag2_default_params(&p);
+    ctx_.reset(new ag2::Context(p, 0));
+  }
+  if (!ctx_->ok()) { err_ = "could not create a GPU context (no CPU fallback)"; return false; }
+  if (!uploaded_) {
+    const int rc = ag2_lenet_load(ctx_->get(), blobs_[0].data(), blobs_[1].data(), blobs_[2].data(),
+                                  blobs_[3].data(), blobs_[4].data(), blobs_[5].data(), blobs_[6].data(),
+                                  blobs_[7].data());
+    if (rc) { err_ = ag2_last_error(ctx_->get()); return false; }
+    uploaded_ = true;
+  }
+  return true;
+}
+
+std::vector<std::vector<Prediction>> Classifier::ClassifyBatch(const std::vector<ag2::Image>& imgs, int num_classes) {
+  std::vector<std::vector<Prediction>> out;
+  if (imgs.empty() || num_classes != 2) return out;
+  if (!ensureLoaded()) {
+    fprintf(stderr, "Classifier: %s\n", err_.c_str());
+    return out;
+  }
+  std::vector<uint8_t> raw(imgs.size() * 10800);
+  for (size_t i = 0; i < imgs.size(); i++) {
+    if (imgs[i].rows != 60 || imgs[i].cols != 60 || imgs[i].chans != 3 || imgs[i].data.size() != 10800) {
+      fprintf(stderr, "Classifier: image %zu is not 60x60x3 uint8\n", i);
+      return out;
+    }
+    std::copy(imgs[i].data.begin(), imgs[i].data.end(), raw.begin() + i * 10800);
+  }
+  std::vector<float> logits(imgs.size() * 2);
+  if (ag2_lenet_forward(ctx_->get(), raw.data(), imgs.size(), logits.data())) {
+    fprintf(stderr, "Classifier: %s\n", ag2_last_error(ctx_->get()));
+    return out;
+  }
+  out.resize(imgs.size());
+  for (size_t i = 0; i < imgs.size(); i++)
+    for (int k = 0; k < 2; k++) out[i].push_back(std::make_pair(labels_[k], logits[2 * i + k]));
+  return out;
+}
+
+std::vector<Prediction> Classifier::Classify(const ag2::Image& img, bool) {
+  std::vector<std::vector<Prediction>> r = ClassifyBatch(std::vector<ag2::Image>(1, img), 2);
+  return r.empty() ? std::vector<Prediction>() : r[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// GraspDetector
+// ------------------------------------------------------------------------------------------------
+namespace {
+std::string trim(const std::string& s) {
+  size_t a = s.find_first_not_of(" \t\r\n\""), b = s.find_last_not_of(" \t\r\n\"");
+  return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+}
+std::vector<double> parse_list(const std::string& v) {
+  std::vector<double> out;
+  std::string t = v;
+  for (char& ch : t)
+    if (ch == '[' || ch == ']' || ch == ',') ch = ' ';
+  std::istringstream is(t);
+  double d;
+  while (is >> d) out.push_back(d);
+  return out;
+}
+bool parse_bool(const std::string& v) { return v == "true" || v == "1" || v == "True"; }
+
+bool set_param(GraspDetector::Params* p, const std::string& k, const std::string& v, std::string* err) {
+#define AG2_NUM(name) if (k == #name) { p->name = (decltype(p->name))std::atof(v.c_str()); return true; }
+#define AG2_BOOL(name) if (k == #name) { p->name = parse_bool(v); return true; }
+#define AG2_STR(name) if (k == #name) { p->name = v; return true; }
+  if (k == "workspace") { p->workspace = parse_list(v); return true; }
+  if (k == "camera_pose") { p->camera_pose = parse_list(v); return true; }
+  if (k == "gripper_width_range") { p->gripper_width_range = parse_list(v); return true; }
+  if (k == "sample_indices") {
+    p->sample_indices.clear();
+    for (double d : parse_list(v)) p->sample_indices.push_back((int)d);
+    return true;
+  }
+  AG2_NUM(num_samples) AG2_NUM(num_threads) AG2_NUM(nn_radius_taubin) AG2_NUM(nn_radius_hands)
+  AG2_NUM(num_orientations) AG2_BOOL(voxelize) AG2_BOOL(filter_half_grasps) AG2_NUM(finger_width)
+  AG2_NUM(hand_outer_diameter) AG2_NUM(hand_depth) AG2_NUM(hand_height) AG2_NUM(init_bite)
+  AG2_NUM(antipodal_mode) AG2_STR(model_file) AG2_STR(trained_file) AG2_STR(label_file)
+  AG2_NUM(min_score_diff) AG2_NUM(batch_size) AG2_NUM(min_inliers) AG2_NUM(min_length)
+  AG2_BOOL(reuse_inliers) AG2_NUM(num_selected) AG2_NUM(plot_mode) AG2_BOOL(only_plot_output)
+  AG2_NUM(device) AG2_NUM(seed)
+#undef AG2_NUM
+#undef AG2_BOOL
+#undef AG2_STR
+  // node-level parameters of the reference that this library does not consume
+  static const char* ignored[] = {"cloud_type", "cloud_file_name", "cloud_topic", "samples_topic",
+                                  "use_importance_sampling", "use_service", "images_directory",
+                                  "normal_estimation_method", "rviz_topic", "num_init_samples",
+                                  "num_iterations", "num_samples_per_iteration", "prob_rand_samples",
+                                  "std", "sampling_method", "visualize_rounds"};
+  for (const char* ig : ignored)
+    if (k == ig) return true;
+  if (err) *err = "unknown parameter: " + k;
+  return false;
+}
+}  // namespace
+
+bool GraspDetector::Params::fromKeyValueText(const std::string& text, Params* out, std::string* err) {
+  std::istringstream is(text);
+  std::string line;
+  while (std::getline(is, line)) {
+    const size_t hash = line.find('#');
+    if (hash != std::string::npos) line = line.substr(0, hash);
+    const size_t eq = line.find('=');
+    if (eq == std::string::npos) {
+      if (!trim(line).empty()) { if (err) *err = "expected name=value: " + line; return false; }
+      continue;
+    }
+    if (!set_param(out, trim(line.substr(0, eq)), trim(line.substr(eq + 1)), err)) return false;
+  }
+  return true;
+}
+
+bool GraspDetector::Params::fromLaunchXml(const std::string& xml, Params* out, std::string* err) {
+  // strip <!-- comments -->
+  std::string s;
+  for (size_t i = 0; i < xml.size();) {
+    if (xml.compare(i, 4, "<!--") == 0) {
+      const size_t e = xml.find("-->", i + 4);
+      i = (e == std::string::npos) ? xml.size() : e + 3;
+    } else {
+      s.push_back(xml[i++]);
+    }
+  }
+  auto attr = [](const std::string& tag, const std::string& name) {
+    const size_t a = tag.find(name + "=\"");
+    if (a == std::string::npos) return std::string();
+    const size_t b = a + name.size() + 2, e = tag.find('"', b);
+    return e == std::string::npos ? std::string() : tag.substr(b, e - b);
+  };
+  size_t pos = 0;
+  while ((pos = s.find("<param ", pos)) != std::string::npos) {
+    const size_t e = s.find('>', pos);
+    if (e == std::string::npos) break;
+    const std::string tag = s.substr(pos, e - pos);
+    std::string v = attr(tag, "value");
+    const size_t find_macro = v.find("$(find agile_grasp2)");
+    if (find_macro != std::string::npos) v.replace(find_macro, 20, ".");
+    if (!set_param(out, attr(tag, "name"), v, err)) return false;
+    pos = e;
+  }
+  pos = 0;
+  while ((pos = s.find("<rosparam ", pos)) != std::string::npos) {
+    const size_t e = s.find('>', pos), c = s.find("</rosparam>", pos);
+    if (e == std::string::npos || c == std::string::npos) break;
+    if (!set_param(out, attr(s.substr(pos, e - pos), "param"), trim(s.substr(e + 1, c - e - 1)), err)) return false;
+    pos = c;
+  }
+  return true;
+}
+
+GraspDetector::GraspDetector(const Params& params) : p_(params), num_samples_(params.num_samples) {
+  indices_ = p_.sample_indices;
+  if (!indices_.empty()) num_samples_ = (int)indices_.size();  // grasp_detector.cpp:24-29
+  if (p_.antipodal_mode == PREDICTION)
+    classifier_.reset(new Classifier(p_.model_file, p_.trained_file, p_.label_file));
+  learning_.reset(new Learning(60, p_.num_threads));  // grasp_detector.cpp:56
+}
+
+GraspDetector::~GraspDetector() {}
+
+void GraspDetector::setIndicesFromMsg(const agile_grasp2::CloudIndexedIndices& msg) {
+  indices_.resize(msg.indices.size());
+  for (size_t i = 0; i < indices_.size(); i++) indices_[i] = (int)msg.indices[i];
+}
+
+void GraspDetector::cameraPoses(Matrix4d* left, Matrix4d* right) const {
+  if (p_.camera_pose.size() == 16) {  // grasp_detector.cpp:129-136
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) (*left)(i, j) = p_.camera_pose[4 * i + j];
+    *right = Matrix4d::Identity();
+    return;
+  }
+  // camera poses of the 2-camera Baxter setup, grasp_detector.cpp:108-126
+  Matrix4d base_tf, sqrt_tf;
+  const double b[16] = {0, 0.445417, 0.895323, 0.215, 1, 0, 0, -0.015, 0, 0.895323, -0.445417, 0.23, 0, 0, 0, 1};
+  const double q[16] = {0.9366, -0.0162, 0.3500, -0.2863, 0.0151, 0.9999, 0.0058, 0.0058,
+                        -0.3501, -0.0002, 0.9367, 0.0554, 0, 0, 0, 1};
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      base_tf(i, j) = b[4 * i + j];
+      sqrt_tf(i, j) = q[4 * i + j];
+    }
+  *left = base_tf * sqrt_tf.inverse();
+  *right = base_tf * sqrt_tf;
+}
+
+std::shared_ptr<ag2::Context> GraspDetector::contextFor(int n_cams) {
+  if (ctx_ && ctx_cams_ == n_cams) return ctx_;
+  HandSearch::Parameters hp;
+  hp.nn_radius_taubin_ = p_.nn_radius_taubin;
+  hp.nn_radius_hands_ = p_.nn_radius_hands;
+  hp.num_threads_ = p_.num_threads;
+  hp.num_samples_ = num_samples_;
+  hp.num_orientations_ = p_.num_orientations;
+  hp.finger_width_ = p_.finger_width;
+  hp.hand_outer_diameter_ = p_.hand_outer_diameter;
+  hp.hand_depth_ = p_.hand_depth;
+  hp.hand_height_ = p_.hand_height;
+  hp.init_bite_ = p_.init_bite;
+  cameraPoses(&hp.cam_tf_left_, &hp.cam_tf_right_);
+  ag2_params ap = HandSearch::toAbiParams(hp, n_cams);
+  ap.filter_half_grasps = p_.filter_half_grasps ? 1 : 0;
+  for (int i = 0; i < 6 && i < (int)p_.workspace.size(); i++) ap.workspace[i] = p_.workspace[i];
+  if (p_.gripper_width_range.size() >= 2) {
+    ap.min_aperture = p_.gripper_width_range[0];
+    ap.max_aperture = p_.gripper_width_range[1];
+  }
+  ap.min_score_diff = p_.min_score_diff;
+  ap.num_selected = p_.num_selected;
+  ctx_.reset(new ag2::Context(ap, p_.device));
+  ctx_cams_ = n_cams;
+  if (!ctx_->ok()) {
+    err_ = "could not create a GPU context (no CPU fallback)";
+    ctx_.reset();
+    return ctx_;
+  }
+  if (classifier_) classifier_->setContext(ctx_);
+  learning_->setContext(ctx_);
+  return ctx_;
+}
+
+std::vector<GraspHypothesis> GraspDetector::detectGraspPoses(const CloudCamera& cloud_cam, bool) {
+  std::vector<GraspHypothesis> out;
+  if (cloud_cam.getCloudOriginal()->size() == 0) {  // grasp_detector.cpp:86-91
+    fprintf(stderr, "Point cloud is empty!\n");
+    return out;
+  }
+  const int n_cams = std::max(1, cloud_cam.getCameraSource().rows());
+  std::shared_ptr<ag2::Context> ctx = contextFor(n_cams);
+  if (!ctx) {
+    fprintf(stderr, "GraspDetector: %s\n", err_.c_str());
+    return out;
+  }
+  ag2_ctx* c = ctx->get();
+  int rc = HandSearch::uploadCloud(c, cloud_cam);
+  const bool use_samples = use_incoming_samples_;
+  const size_t s = use_samples ? (size_t)cloud_cam.getSamples().cols() : cloud_cam.getSampleIndices().size();
+  std::vector<int32_t> idx(cloud_cam.getSampleIndices().begin(), cloud_cam.getSampleIndices().end());
+  const int32_t* pidx = use_samples ? nullptr : idx.data();
+  const double* pxyz = use_samples ? cloud_cam.getSamples().data() : nullptr;
+  const int32_t dummy = 0;
+  if (!use_samples && idx.empty()) pidx = &dummy;  // zero samples: a valid (empty) request
+  const bool do_prune = indices_.empty();          // grasp_detector.cpp:149-160
+  const size_t cap = std::max<size_t>(1, s * (size_t)p_.num_orientations);
+  std::vector<ag2_hypothesis> recs(cap);
+  size_t n = 0;
+  if (!rc) {
+    if (p_.antipodal_mode == PREDICTION) {
+      if (!classifier_ || !classifier_->ok()) {
+        fprintf(stderr, "GraspDetector: classifier not available: %s\n",
+                classifier_ ? classifier_->error().c_str() : "not constructed");
+        return out;
+      }
+      rc = ag2_lenet_load(c, classifier_->blob(0).data(), classifier_->blob(1).data(), classifier_->blob(2).data(),
+                          classifier_->blob(3).data(), classifier_->blob(4).data(), classifier_->blob(5).data(),
+                          classifier_->blob(6).data(), classifier_->blob(7).data());
+      if (!rc) rc = ag2_detect(c, pidx, pxyz, s, 0, p_.seed, do_prune ? 1 : 0, recs.data(), cap, &n, nullptr, 0, nullptr);
+    } else {
+      rc = ag2_generate_hypotheses(c, pidx, pxyz, s, 0, p_.seed, recs.data(), cap, &n);
+      if (!rc) {
+        std::vector<uint8_t> keep(n, 1);
+        if (do_prune && n) rc = ag2_prune(c, keep.data(), n);
+        size_t m = 0;
+        for (size_t h = 0; h < n; h++) {
+          const bool sel = keep[h] && (p_.antipodal_mode == NONE || recs[h].full_antipodal);  // :163-221
+          if (sel) recs[m++] = recs[h];
+        }
+        n = m;
+        if (p_.antipodal_mode == GEOMETRIC) {  // :239-252 (scores are all zero: stable order kept)
+          if ((int)n > p_.num_selected) n = (size_t)p_.num_selected;
+        }
+      }
+    }
+  }
+  if (rc) {
+    err_ = ag2_last_error(c);
+    fprintf(stderr, "GraspDetector::detectGraspPoses: %s\n", err_.c_str());
+    return out;
+  }
+  (void)ag2_get_stage_times(c, &times_);
+  (void)ag2_get_counters(c, &counters_);
+  out.reserve(n);
+  for (size_t h = 0; h < n; h++) out.push_back(GraspHypothesis(recs[h]));
+  return out;
+}
+
+void GraspDetector::preprocessPointCloud(CloudCamera& cloud_cam) {
+  if (indices_.empty()) {
+    if (p_.workspace.size() >= 6) cloud_cam.filterWorkspace(p_.workspace);   // 1. :292-296
+    if (p_.voxelize) cloud_cam.voxelizeCloud(voxel_size_);                   // 2. :299-303
+    const int n = (int)cloud_cam.getCloudProcessed()->size();
+    if (use_incoming_samples_) {                                             // 3. :306-321
+      agile_grasp2::SamplesMsg filtered;
+      for (const agile_grasp2::Point& p : samples_msg_.samples)
+        if (p_.workspace.size() < 6 ||
+            (p.x > p_.workspace[0] && p.x < p_.workspace[1] && p.y > p_.workspace[2] && p.y < p_.workspace[3] &&
+             p.z > p_.workspace[4] && p.z < p_.workspace[5]))
+          filtered.samples.push_back(p);
+      cloud_cam.subsampleSamples(filtered, num_samples_, p_.seed);
+    } else if (num_samples_ > n) {                                           // :322-330
+      std::vector<int> all(n);
+      for (int i = 0; i < n; i++) all[i] = i;
+      cloud_cam.setSampleIndices(all);
+    } else {
+      cloud_cam.subsampleUniformly(num_samples_, p_.seed);                   // :331-335
+    }
+  } else {
+    if (num_samples_ != (int)indices_.size() && num_samples_ < (int)cloud_cam.getCloudOriginal()->size()) {
+      std::vector<int> r(num_samples_);                                      // :339-345 (rand() -> seeded)
+      uint64_t s = p_.seed ^ 0x0F0F0F0F12345678ull;
+      for (int i = 0; i < num_samples_; i++) r[i] = indices_[(size_t)(splitmix(s) % indices_.size())];
+      cloud_cam.setSampleIndices(r);
+    } else {
+      cloud_cam.setSampleIndices(indices_);
+    }
+  }
+}
+
+std::vector<GraspHypothesis> GraspDetector::pruneGraspsOnHandParameters(const std::vector<GraspHypothesis>& hands,
+                                                                        float min_x, float max_x, float min_y,
+                                                                        float max_y, float min_z) {
+  std::vector<GraspHypothesis> out;  // grasp_detector.cpp:363-395 (host twin of the in-kernel predicate)
+  const double hw = 0.5 * p_.hand_outer_diameter;
+  const double min_ap = p_.gripper_width_range.size() >= 2 ? p_.gripper_width_range[0] : 0.03;
+  const double max_ap = p_.gripper_width_range.size() >= 2 ? p_.gripper_width_range[1] : 0.07;
+  for (const GraspHypothesis& h : hands) {
+    if (p_.filter_half_grasps && !h.isHalfAntipodal()) continue;
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; a++) {
+      const double c5[5] = {h.getGraspBottom()(a) + hw * h.getBinormal()(a), h.getGraspBottom()(a) - hw * h.getBinormal()(a),
+                            h.getGraspTop()(a) + hw * h.getBinormal()(a), h.getGraspTop()(a) - hw * h.getBinormal()(a),
+                            h.getGraspBottom()(a) - 0.10 * h.getApproach()(a)};
+      mn[a] = mx[a] = c5[0];
+      for (int k = 1; k < 5; k++) {
+        mn[a] = std::min(mn[a], c5[k]);
+        mx[a] = std::max(mx[a], c5[k]);
+      }
+    }
+    const double ap = h.getGraspWidth();
+    if (ap >= min_ap && ap <= max_ap && mn[2] >= (double)min_z && mn[1] >= (double)min_y && mx[1] <= (double)max_y &&
+        mn[0] >= (double)min_x && mx[0] <= (double)max_x)
+      out.push_back(h);
+  }
+  return out;
+}
+
+agile_grasp2::GraspListMsg GraspDetector::createGraspListMsg(const std::vector<GraspHypothesis>& hands) {
+  agile_grasp2::GraspListMsg msg;
+  for (const GraspHypothesis& h : hands) msg.grasps.push_back(h.convertToGraspMsg());
+  return msg;
+}
+
+bool GraspDetector::findGrasps(const CloudCamera& cloud_in, const agile_grasp2::FindGraspsRequest& req,
+                               agile_grasp2::FindGraspsResponse* resp) {
+  CloudCamera cc = cloud_in;
+  const std::vector<int> saved = indices_;
+  const int saved_n = num_samples_;
+  if (req.num_samples > 0) num_samples_ = req.num_samples;
+  if (req.grasps_signal == 2) {        // samples given by indices, grasp_detection_node.cpp:178-186
+    indices_.assign(req.indices.begin(), req.indices.end());
+  } else if (req.grasps_signal == 1) {  // samples drawn from an r-ball, :158-176 / :204-213
+    indices_.clear();
+    const float r2 = req.radius * req.radius;
+    const PointCloudRGB::Ptr& cl = cc.getCloudProcessed();
+    for (size_t i = 0; i < cl->size(); i++) {
+      const float dx = cl->points[i].x - (float)req.centroid.x, dy = cl->points[i].y - (float)req.centroid.y,
+                  dz = cl->points[i].z - (float)req.centroid.z;
+      if ((dx * dx + dy * dy) + dz * dz < r2) indices_.push_back((int)i);
+    }
+  } else {
+    indices_.clear();
+  }
+  preprocessPointCloud(cc);
+  const int saved_mode = p_.antipodal_mode;
+  if (req.calculate_antipodal) p_.antipodal_mode = GEOMETRIC;
+  const std::vector<GraspHypothesis> hands = detectGraspPoses(cc);
+  p_.antipodal_mode = saved_mode;
+  indices_ = saved;
+  num_samples_ = saved_n;
+  if (resp) resp->grasps_msg = createGraspListMsg(hands);  // filled (the reference leaves it empty, :196)
+  return true;
+}

@@ -19,6 +19,17 @@ SHAPES = {
 ORDER = ["conv1_w", "conv1_b", "conv2_w", "conv2_b", "ip1_w", "ip1_b", "ip2_w", "ip2_b"]
 
 
+def save_ag2w(path: str, w: dict) -> None:
+    """Write the flat weight container the C++ Classifier reads (caffe_classifier.h): magic "AG2W"
+    followed by the eight blobs as little-endian float32, Caffe blob order."""
+    with open(path, "wb") as f:
+        f.write(b"AG2W")
+        for name in ORDER:
+            a = np.ascontiguousarray(w[name], dtype="<f4")
+            assert a.shape == SHAPES[name], name
+            f.write(a.tobytes())
+
+
 def make_lenet_weights(seed: int) -> dict:
     rng = np.random.default_rng(seed)
     w = {}

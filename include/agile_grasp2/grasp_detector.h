@@ -1,0 +1,114 @@
+// grasp_detector.h -- host mirror of GraspDetector (include/agile_grasp2/grasp_detector.h:68-168,
+// src/agile_grasp2/grasp_detector.cpp).  The ros::NodeHandle of the reference constructor is
+// replaced by a plain Params struct carrying exactly the ROS parameter names and defaults of
+// grasp_detector.cpp:19-80 (plus readers for "key=value" text and roslaunch <param> XML).
+#ifndef AGILE_GRASP2_GRASP_DETECTOR_H
+#define AGILE_GRASP2_GRASP_DETECTOR_H
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "agile_grasp2/caffe_classifier.h"
+#include "agile_grasp2/cloud_camera.h"
+#include "agile_grasp2/grasp_hypothesis.h"
+#include "agile_grasp2/hand_search.h"
+#include "agile_grasp2/learning.h"
+#include "agile_grasp2/messages.h"
+
+class GraspDetector {
+ public:
+  static const int NONE = 0, PREDICTION = 1, GEOMETRIC = 2;   // antipodal_mode, grasp_detector.cpp:5-7
+  static const int NO_PLOTTING = 0, PCL = 1, RVIZ = 2;        // plot_mode (accepted, ignored)
+
+  struct Params {  // names and defaults: grasp_detector.cpp:19-80
+    std::vector<double> workspace;     // no default in the reference
+    std::vector<double> camera_pose;   // 16 values row-major, or empty => Baxter defaults (:108-126)
+    int num_samples = 1000;
+    std::vector<int> sample_indices;
+    int num_threads = 1;
+    double nn_radius_taubin = 0.01;
+    double nn_radius_hands = 0.1;
+    int num_orientations = 8;
+    bool voxelize = true;
+    bool filter_half_grasps = true;
+    double finger_width = 0.01;
+    double hand_outer_diameter = 0.09;
+    double hand_depth = 0.06;
+    double hand_height = 0.02;
+    double init_bite = 0.015;
+    int antipodal_mode = PREDICTION;
+    std::string model_file, trained_file, label_file;
+    double min_score_diff = 500.0;
+    int batch_size = 10;               // accepted; the GPU path scores all images in one batch
+    int min_inliers = 0;               // clustering (HandleSearch) is listed under "next"
+    double min_length = 0.005;
+    bool reuse_inliers = true;
+    int num_selected = 50;
+    std::vector<double> gripper_width_range{0.03, 0.07};
+    int plot_mode = NO_PLOTTING;
+    bool only_plot_output = true;
+    // not in the reference
+    int device = 0;
+    uint64_t seed = 0;
+    // "name=value" lines ('#' comments); vectors as "[a, b, c]".  Unknown names are an error.
+    static bool fromKeyValueText(const std::string& text, Params* out, std::string* err);
+    // <param name=".." value=".."/> and <rosparam param=".."> [..] </rosparam> of a roslaunch file
+    static bool fromLaunchXml(const std::string& xml, Params* out, std::string* err);
+  };
+
+  explicit GraspDetector(const Params& params);
+  ~GraspDetector();
+
+  // grasp_detector.cpp:84-282 (PREDICTION: hypotheses -> prune -> images -> LeNet -> threshold ->
+  // top-k by score; GEOMETRIC: keep full-antipodal; NONE: pruned hypotheses).  Empty vector for
+  // an empty cloud (:86-91) or on error (message on stderr).
+  std::vector<GraspHypothesis> detectGraspPoses(const CloudCamera& cloud_cam, bool clusters_grasps = true);
+  // grasp_detector.cpp:285-350
+  void preprocessPointCloud(CloudCamera& cloud_cam);
+
+  static bool isScoreGreater(const GraspHypothesis& a, const GraspHypothesis& b) {
+    return a.getScore() > b.getScore();
+  }
+  bool getUseIncomingSamples() const { return use_incoming_samples_; }
+  void setUseIncomingSamples(bool v) { use_incoming_samples_ = v; }
+  const std::vector<double>& getWorkspace() const { return p_.workspace; }
+  int getNumSamples() const { return num_samples_; }
+  void setNumSamples(int n) { num_samples_ = n; }
+  void setIndicesFromMsg(const agile_grasp2::CloudIndexedIndices& msg);
+  void setSamplesMsg(const agile_grasp2::SamplesMsg& msg) { samples_msg_ = msg; }
+
+  // grasp_detection_node.cpp:296-313 (createGraspListMsg)
+  static agile_grasp2::GraspListMsg createGraspListMsg(const std::vector<GraspHypothesis>& hands);
+  // find_grasps service body (grasp_detection_node.cpp:146-201) with the response FILLED -- the
+  // reference returns true without filling it (":196 TODO"); documented divergence.
+  bool findGrasps(const CloudCamera& cloud_in, const agile_grasp2::FindGraspsRequest& req,
+                  agile_grasp2::FindGraspsResponse* resp);
+
+  const ag2_times& lastStageTimes() const { return times_; }
+  const ag2_counters& lastCounters() const { return counters_; }
+  const std::string& lastError() const { return err_; }
+
+ private:
+  std::vector<GraspHypothesis> pruneGraspsOnHandParameters(const std::vector<GraspHypothesis>& hands,
+                                                           float min_x, float max_x, float min_y,
+                                                           float max_y, float min_z);
+  std::shared_ptr<ag2::Context> contextFor(int n_cams);
+  void cameraPoses(ag2::Matrix4d* left, ag2::Matrix4d* right) const;
+
+  Params p_;
+  int num_samples_;
+  std::vector<int> indices_;
+  bool use_incoming_samples_ = false;
+  double voxel_size_ = 0.003;  // grasp_detector.cpp:15
+  agile_grasp2::SamplesMsg samples_msg_;
+  std::unique_ptr<Classifier> classifier_;
+  std::unique_ptr<Learning> learning_;
+  std::shared_ptr<ag2::Context> ctx_;
+  int ctx_cams_ = 0;
+  ag2_times times_{};
+  ag2_counters counters_{};
+  std::string err_;
+};
+
+#endif  // AGILE_GRASP2_GRASP_DETECTOR_H

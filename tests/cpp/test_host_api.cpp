@@ -1,0 +1,130 @@
+// test_host_api.cpp -- drives the C++ host mirror (include/agile_grasp2/*.h) the way the reference's
+// GraspDetectionNode drives the reference classes (src/nodes/grasp_detection_node.cpp:98-143):
+//   CloudCamera -> GraspDetector::detectGraspPoses, and the stage-by-stage path
+//   HandSearch::generateHypotheses -> Learning::createGraspImages -> Classifier::ClassifyBatch.
+// Inputs and outputs are flat binary files so that tests/test_cpp_host.py can compare them with the
+// C-ABI results and with the oracle.
+//
+//   test_host_api <cloud.f32> <idx.i32> <params.txt> <out.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+#include "agile_grasp2/caffe_classifier.h"
+#include "agile_grasp2/cloud_camera.h"
+#include "agile_grasp2/grasp_detector.h"
+#include "agile_grasp2/hand_search.h"
+#include "agile_grasp2/learning.h"
+
+template <class T>
+static std::vector<T> read_all(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  std::vector<T> out(raw.size() / sizeof(T));
+  std::memcpy(out.data(), raw.data(), out.size() * sizeof(T));
+  return out;
+}
+
+template <class T>
+static void put(std::ofstream& f, const T* p, size_t n) {
+  f.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * sizeof(T)));
+}
+
+int main(int argc, char** argv) {
+  if (argc != 5) {
+    fprintf(stderr, "usage: %s cloud.f32 idx.i32 params.txt out.bin\n", argv[0]);
+    return 2;
+  }
+  const std::vector<float> xyz = read_all<float>(argv[1]);
+  const std::vector<int32_t> idx = read_all<int32_t>(argv[2]);
+  std::ifstream pf(argv[3]);
+  const std::string ptext((std::istreambuf_iterator<char>(pf)), std::istreambuf_iterator<char>());
+  GraspDetector::Params prm;
+  std::string err;
+  if (!GraspDetector::Params::fromKeyValueText(ptext, &prm, &err)) {
+    fprintf(stderr, "params: %s\n", err.c_str());
+    return 2;
+  }
+
+  PointCloudRGB::Ptr cloud(new PointCloudRGB);
+  cloud->points.resize(xyz.size() / 3);
+  for (size_t i = 0; i < cloud->size(); i++) {
+    cloud->points[i].x = xyz[3 * i];
+    cloud->points[i].y = xyz[3 * i + 1];
+    cloud->points[i].z = xyz[3 * i + 2];
+  }
+  CloudCamera cc(cloud, (int)cloud->size());  // one camera
+  cc.setSampleIndices(std::vector<int>(idx.begin(), idx.end()));
+
+  // ---- stage by stage, as src/tests/test_cnn.cpp does ----------------------------------------
+  HandSearch::Parameters hp;
+  hp.nn_radius_taubin_ = prm.nn_radius_taubin;
+  hp.nn_radius_hands_ = prm.nn_radius_hands;
+  hp.num_orientations_ = prm.num_orientations;
+  hp.finger_width_ = prm.finger_width;
+  hp.hand_outer_diameter_ = prm.hand_outer_diameter;
+  hp.hand_depth_ = prm.hand_depth;
+  hp.hand_height_ = prm.hand_height;
+  hp.init_bite_ = prm.init_bite;
+  if (prm.camera_pose.size() != 16) {
+    fprintf(stderr, "params: camera_pose needs 16 values, got %zu\n", prm.camera_pose.size());
+    return 2;
+  }
+  for (int k = 0; k < 3; k++) hp.cam_tf_left_(k, 3) = hp.cam_tf_right_(k, 3) = prm.camera_pose[4 * k + 3];
+  HandSearch hs(hp);
+  hs.setSeed(prm.seed);
+  const std::vector<GraspHypothesis> hyps = hs.generateHypotheses(cc, 0, false);
+  Learning learning(60, 1);
+  learning.setContext(hs.context());
+  const std::vector<ag2::Image> images = learning.createGraspImages(hyps, ag2::Matrix3Xd());
+  Classifier clf(prm.model_file, prm.trained_file, prm.label_file);
+  if (!clf.ok()) {
+    fprintf(stderr, "classifier: %s\n", clf.error().c_str());
+    return 3;
+  }
+  clf.setContext(hs.context());
+  const std::vector<std::vector<Prediction>> pred = clf.ClassifyBatch(images, 2);
+
+  // ---- the detector entry the node calls -------------------------------------------------------
+  GraspDetector det(prm);
+  const std::vector<GraspHypothesis> sel = det.detectGraspPoses(cc);
+  const agile_grasp2::GraspListMsg msg = GraspDetector::createGraspListMsg(sel);
+
+  std::ofstream out(argv[4], std::ios::binary);
+  const int64_t nh = (int64_t)hyps.size(), ni = (int64_t)images.size(), np = (int64_t)pred.size(),
+                ns = (int64_t)sel.size();
+  put(out, &nh, 1);
+  for (const GraspHypothesis& h : hyps) {
+    const double rec[20] = {h.getAxis()(0), h.getAxis()(1), h.getAxis()(2), h.getApproach()(0), h.getApproach()(1),
+                            h.getApproach()(2), h.getBinormal()(0), h.getBinormal()(1), h.getBinormal()(2),
+                            h.getGraspSurface()(0), h.getGraspSurface()(1), h.getGraspSurface()(2),
+                            h.getGraspBottom()(0), h.getGraspBottom()(1), h.getGraspBottom()(2),
+                            h.getGraspTop()(0), h.getGraspTop()(1), h.getGraspTop()(2), h.getGraspWidth(),
+                            (double)(h.isHalfAntipodal() + 2 * h.isFullAntipodal())};
+    put(out, rec, 20);
+    const int64_t p = h.getPointsForLearning().cols();
+    put(out, &p, 1);
+  }
+  put(out, &ni, 1);
+  for (const ag2::Image& im : images) put(out, im.data.data(), im.data.size());
+  put(out, &np, 1);
+  for (const auto& pr : pred) {
+    const float l[2] = {pr[0].second, pr[1].second};
+    put(out, l, 2);
+  }
+  put(out, &ns, 1);
+  std::vector<uint8_t> wire;
+  for (const agile_grasp2::GraspMsg& g : msg.grasps) agile_grasp2::serialize(g, wire);
+  put(out, wire.data(), wire.size());
+  for (const GraspHypothesis& h : sel) {
+    const int32_t so[2] = {h.getSampleSlot(), h.getOrientation()};
+    put(out, so, 2);
+  }
+  printf("host api ok: %lld hypotheses, %lld images, %lld selected, label0=%s\n", (long long)nh, (long long)ni,
+         (long long)ns, pred.empty() ? "-" : pred[0][0].first.c_str());
+  return 0;
+}

@@ -1,0 +1,204 @@
+"""The C++ host mirror (include/agile_grasp2/*.h, agile_grasp2_amd/host): same class / method names as
+the reference's GraspDetector / HandSearch / Learning / Classifier / CloudCamera.
+
+not-gpu: the library and a driver program compile and link against the headers; the parameter
+readers (key=value text, roslaunch XML with the reference's own parameter names) parse.
+gpu: the driver runs CloudCamera -> HandSearch::generateHypotheses -> Learning::createGraspImages ->
+Classifier::ClassifyBatch and GraspDetector::detectGraspPoses; results must equal the oracle's
+(poses/labels/images bit-exact, logits within the fp32 tolerance) and the GraspMsg wire bytes must be
+the f64/f32 fields of the selected hypotheses.
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import scene_params
+from agile_grasp2_amd import scene
+from agile_grasp2_amd.weights import make_lenet_weights, save_ag2w
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_DIR = os.path.join(ROOT, "agile_grasp2_amd", "host")
+CSRC_DIR = os.path.join(ROOT, "agile_grasp2_amd", "csrc")
+
+
+def build_driver(tmp):
+    subprocess.check_call(["make", "-C", CSRC_DIR, "-s", "-j", "8"])
+    subprocess.check_call(["make", "-C", HOST_DIR, "-s"])
+    exe = os.path.join(tmp, "test_host_api")
+    subprocess.check_call([
+        "g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+        os.path.join(ROOT, "tests", "cpp", "test_host_api.cpp"), "-o", exe,
+        "-L", HOST_DIR, "-lag2host", "-L", CSRC_DIR, "-lag2hip",
+        f"-Wl,-rpath,{HOST_DIR}", f"-Wl,-rpath,{CSRC_DIR}"])
+    return exe
+
+
+def test_host_library_and_driver_build(tmp_path):
+    exe = build_driver(str(tmp_path))
+    assert os.path.exists(exe)
+    out = subprocess.check_output(["nm", "-DC", "--defined-only", os.path.join(HOST_DIR, "libag2host.so")], text=True)
+    for sym in ("GraspDetector::detectGraspPoses", "GraspDetector::preprocessPointCloud",
+                "HandSearch::generateHypotheses", "Learning::createGraspImages", "Classifier::ClassifyBatch",
+                "CloudCamera::voxelizeCloud", "CloudCamera::filterWorkspace",
+                "GraspHypothesis::convertToGraspMsg"):
+        assert sym in out, sym
+    # the driver reports usage (exit code 2) without touching the GPU
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+def params_text(ws, wpath, lpath, seed):
+    cam = [float(v) for v in scene.CAMERA]
+    pose = [1.0, 0.0, 0.0, cam[0], 0.0, 1.0, 0.0, cam[1], 0.0, 0.0, 1.0, cam[2], 0.0, 0.0, 0.0, 1.0]
+    return "\n".join([
+        "# launch/file_detect_grasps.launch values",
+        f"workspace = {list(map(float, ws))}",
+        f"camera_pose = {pose}",
+        "num_orientations = 8", "nn_radius_taubin = 0.01", "nn_radius_hands = 0.1",
+        "finger_width = 0.01", "hand_outer_diameter = 0.09", "hand_depth = 0.06", "hand_height = 0.02",
+        "init_bite = 0.01", "filter_half_grasps = false", "gripper_width_range = [0.03, 0.08]",
+        "antipodal_mode = 1", f"trained_file = {wpath}", f"label_file = {lpath}", "model_file =",
+        "min_score_diff = -1e30", "num_selected = 1000", "plot_mode = 0", f"seed = {seed}", ""])
+
+
+@pytest.mark.gpu
+def test_cpp_host_matches_oracle(tmp_path, small_scene):
+    from oracle import api
+    tmp = str(tmp_path)
+    exe = build_driver(tmp)
+    xyz, ws, idx = small_scene
+    w = make_lenet_weights(7)
+    wpath, lpath = os.path.join(tmp, "w.ag2w"), os.path.join(tmp, "labels.txt")
+    save_ag2w(wpath, w)
+    open(lpath, "w").write("0\n1\n")  # caffe/labels.txt
+    xyz.astype("<f4").tofile(os.path.join(tmp, "cloud.f32"))
+    idx.astype("<i4").tofile(os.path.join(tmp, "idx.i32"))
+    seed = 5
+    open(os.path.join(tmp, "params.txt"), "w").write(params_text(ws, wpath, lpath, seed))
+    outp = os.path.join(tmp, "out.bin")
+    r = subprocess.run([exe, os.path.join(tmp, "cloud.f32"), os.path.join(tmp, "idx.i32"),
+                        os.path.join(tmp, "params.txt"), outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "host api ok" in r.stdout and "label0=0" in r.stdout
+
+    prm = scene_params(ws, min_score_diff=-1e30, num_selected=1000)
+    o = api.Oracle(**dict(prm, num_threads=4))
+    o.set_cloud(xyz)
+    o.compute_normals()
+    o.lenet_load(w)
+    want = o.generate_hypotheses(sample_idx=idx, seed=seed)
+    wimgs = o.render_images(0, len(want))
+    wlog = o.lenet_forward(wimgs)
+    wsel, wall = o.detect(sample_idx=idx, seed=seed, do_prune=True)
+
+    buf = open(outp, "rb").read()
+    off = 0
+
+    def take(fmt):
+        nonlocal off
+        v = struct.unpack_from(fmt, buf, off)
+        off += struct.calcsize(fmt)
+        return v
+
+    (nh,) = take("<q")
+    assert nh == len(want)
+    for k in range(nh):
+        rec = np.array(take("<20d"))
+        (p,) = take("<q")
+        h = want[k]
+        ref = np.concatenate([h["axis"], h["approach"], h["binormal"], h["surface"], h["bottom"], h["top"],
+                              [h["width"], h["half_antipodal"] + 2 * h["full_antipodal"]]])
+        assert np.array_equal(rec, ref), k
+        assert p == h["n_points"]
+    (ni,) = take("<q")
+    assert ni == nh
+    imgs = np.frombuffer(buf, dtype=np.uint8, count=ni * 10800, offset=off).reshape(ni, 60, 60, 3)
+    off += ni * 10800
+    assert np.array_equal(imgs, wimgs)
+    (npred,) = take("<q")
+    assert npred == nh
+    logits = np.frombuffer(buf, dtype="<f4", count=2 * npred, offset=off).reshape(npred, 2)
+    off += 8 * npred
+    tol = 1e-4 * np.abs(wlog).max() + 1e-3
+    assert np.abs(logits - wlog).max() <= tol
+    (ns,) = take("<q")
+    assert ns == len(wsel) and ns > 0
+    wire = np.frombuffer(buf, dtype=np.uint8, count=152 * ns, offset=off)
+    off += 152 * ns
+    slots = np.frombuffer(buf, dtype="<i4", count=2 * ns, offset=off).reshape(ns, 2)
+    key = {(int(h["sample_slot"]), int(h["orientation"])): h for h in wsel}
+    assert sorted(map(tuple, slots.tolist())) == sorted(key)
+    for k in range(ns):
+        h = key[tuple(slots[k])]
+        d = np.frombuffer(wire[152 * k: 152 * k + 144].tobytes(), dtype="<f8")
+        f = np.frombuffer(wire[152 * k + 144: 152 * (k + 1)].tobytes(), dtype="<f4")
+        ref = np.concatenate([h["surface"], h["bottom"], h["top"], h["axis"], h["approach"], h["binormal"]])
+        assert np.array_equal(d, ref)                       # GraspMsg.msg: 3 Points + 3 Vector3 (f64)
+        assert f[0] == np.float32(h["width"])               # std_msgs/Float32 width
+        assert abs(f[1] - np.float32(h["score"])) <= 2 * tol
+
+
+def test_launch_xml_and_keyvalue_readers(tmp_path):
+    """Params readers accept the reference's own launch file text (parameter NAMES are the
+    contract; the file is read at test time from /root/reference when present, else a literal
+    excerpt of its parameter names is used)."""
+    src = r'''
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include "agile_grasp2/grasp_detector.h"
+int main(int argc, char** argv) {
+  std::ifstream f(argv[1]);
+  std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  GraspDetector::Params p; std::string err;
+  bool ok = (std::string(argv[2]) == "xml") ? GraspDetector::Params::fromLaunchXml(text, &p, &err)
+                                            : GraspDetector::Params::fromKeyValueText(text, &p, &err);
+  if (!ok) { printf("ERR %s\n", err.c_str()); return 1; }
+  printf("%d %d %g %g %d %g %zu %g %d %d %g\n", p.num_samples, p.num_orientations, p.init_bite,
+         p.min_score_diff, p.num_selected, p.workspace.size() ? p.workspace[1] : -1.0, p.workspace.size(),
+         p.gripper_width_range[1], (int)p.filter_half_grasps, p.min_inliers, p.nn_radius_hands);
+  return 0;
+}
+'''
+    tmp = str(tmp_path)
+    subprocess.check_call(["make", "-C", CSRC_DIR, "-s", "-j", "8"])
+    subprocess.check_call(["make", "-C", HOST_DIR, "-s"])
+    cpp = os.path.join(tmp, "p.cpp")
+    open(cpp, "w").write(src)
+    exe = os.path.join(tmp, "p")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), cpp, "-o", exe,
+                           "-L", HOST_DIR, "-lag2host", "-L", CSRC_DIR, "-lag2hip",
+                           f"-Wl,-rpath,{HOST_DIR}", f"-Wl,-rpath,{CSRC_DIR}"])
+    xml = '''<launch><node name="detect_grasps_file" pkg="agile_grasp2" type="detect_grasps_file">
+    <param name="cloud_type" value="0" /> <!-- a comment <param name="bogus" value="1"/> -->
+    <rosparam param="workspace"> [0.48, 0.92, -0.6, 0.4, -0.25, 1] </rosparam>
+    <rosparam param="camera_pose"> [] </rosparam>
+    <param name="num_samples" value="5000" /> <param name="num_threads" value="4" />
+    <param name="nn_radius_taubin" value="0.01" /> <param name="nn_radius_hands" value="0.1" />
+    <param name="num_orientations" value="8" /> <param name="antipodal_mode" value="1" />
+    <param name="voxelize" value="true"/> <param name="filter_half_grasps" value="false"/>
+    <param name="gripper_width_range" value="[0.03, 0.08]" />
+    <param name="finger_width" value="0.01" /> <param name="hand_outer_diameter" value="0.09" />
+    <param name="hand_depth" value="0.06" /> <param name="hand_height" value="0.02" />
+    <param name="init_bite" value="0.01" />
+    <param name="model_file" value="$(find agile_grasp2)/caffe/test_1batch2.prototxt" />
+    <param name="min_score_diff" value="300" /> <param name="batch_size" value="100" />
+    <param name="min_inliers" value="5" /> <param name="num_selected" value="30" />
+    </node></launch>'''
+    ref_launch = "/root/reference/launch/file_detect_grasps.launch"
+    if os.path.exists(ref_launch):
+        xml = open(ref_launch).read()  # read as data at test time; nothing is copied into the repo
+    lx = os.path.join(tmp, "l.launch")
+    open(lx, "w").write(xml)
+    out = subprocess.check_output([exe, lx, "xml"], text=True).split()
+    assert out == ["5000", "8", "0.01", "300", "30", "0.92", "6", "0.08", "0", "5", "0.1"], out
+    kv = os.path.join(tmp, "k.txt")
+    open(kv, "w").write("num_samples=77 # comment\ninit_bite = 0.02\nworkspace=[1,2,3,4,5,6]\n")
+    out = subprocess.check_output([exe, kv, "kv"], text=True).split()
+    assert out[0] == "77" and out[2] == "0.02" and out[5] == "2" and out[6] == "6"
+    open(kv, "w").write("no_such_parameter = 1\n")
+    r = subprocess.run([exe, kv, "kv"], capture_output=True, text=True)
+    assert r.returncode == 1 and "unknown parameter" in r.stdout
