@@ -49,7 +49,7 @@ class Counters(C.Structure):
 class Times(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "grid_ms", "normals_ms", "frames_ms", "sweep_ms", "compact_ms", "render_ms",
-        "lenet_conv_ms", "lenet_fc_ms", "select_ms", "total_ms", "reserved0", "reserved1")]
+        "lenet_conv_ms", "lenet_fc_ms", "select_ms", "total_ms", "sweep_overflow_ms", "reserved")]
 
 
 HYP_DTYPE = np.dtype([

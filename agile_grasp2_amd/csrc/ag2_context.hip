@@ -97,6 +97,18 @@ static int check_params(ag2_ctx* c) {
   return 0;
 }
 
+// k_normals is launched without a host sync; its duration and neighbour counter are read here.
+int collect_normals_stats(ag2_ctx* c) {
+  if (!c->normals_pending) return 0;
+  AG2_HIP(c, hipEventSynchronize(c->ev[10]));
+  (void)hipEventElapsedTime(&c->times.normals_ms, c->ev[9], c->ev[10]);
+  unsigned long long k1 = 0;
+  AG2_HIP(c, hipMemcpy(&k1, (const char*)c->d_stats.p + offsetof(DevStats, sum_k1), 8, hipMemcpyDeviceToHost));
+  c->cnt.sum_k1 = (int64_t)k1;
+  c->normals_pending = false;
+  return 0;
+}
+
 }  // namespace ag2
 
 using namespace ag2;
@@ -194,6 +206,7 @@ int ag2_set_stream(ag2_ctx* c, void* hip_stream) {
 
 static int after_cloud(ag2_ctx* c) {
   memset(&c->cnt, 0, sizeof(c->cnt));
+  c->normals_pending = false;
   c->h_hyps.clear();
   c->h_slots.clear();
   c->h_offsets.clear();
@@ -277,15 +290,14 @@ int ag2_compute_normals(ag2_ctx* c) {
   if (!c) return AG2_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (!c->has_cloud) return set_err(c, AG2_ERR_STATE, "no cloud set");
-  AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
+  // asynchronous: the kernel time and the K1 counter are collected at the next point that
+  // synchronises anyway (ag2::collect_normals_stats)
+  AG2_HIP(c, hipMemsetAsync((char*)c->d_stats.p + offsetof(DevStats, sum_k1), 0, 8, c->stream));
+  AG2_HIP(c, hipEventRecord(c->ev[9], c->stream));
   const int rc = launch_normals(c);
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
-  DevStats hs;
-  AG2_HIP(c, hipMemcpyAsync(&hs, c->d_stats.p, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
-  AG2_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipEventElapsedTime(&c->times.normals_ms, c->ev[0], c->ev[1]);
-  c->cnt.sum_k1 = (int64_t)hs.sum_k1;
+  AG2_HIP(c, hipEventRecord(c->ev[10], c->stream));
+  c->normals_pending = true;
   c->has_normals = true;
   return 0;
 }
@@ -324,12 +336,16 @@ int ag2_get_grid_perm(ag2_ctx* c, int32_t* perm, size_t cap, size_t* n_valid) {
 
 int ag2_get_counters(ag2_ctx* c, ag2_counters* out) {
   if (!c || !out) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  (void)collect_normals_stats(c);
   *out = c->cnt;
   return 0;
 }
 
 int ag2_get_stage_times(ag2_ctx* c, ag2_times* out) {
   if (!c || !out) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  (void)collect_normals_stats(c);
   *out = c->times;
   return 0;
 }

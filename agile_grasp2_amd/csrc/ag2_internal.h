@@ -35,13 +35,16 @@ struct DevBuf {
 
 // Device-side counters / flags block (one per context, zeroed per call).
 struct DevStats {
-  unsigned long long sum_k1, sum_k2, sum_kcrop, sum_p;
+  // --- zeroed before every hypothesis run (everything before `bounds`) ---
+  unsigned long long sum_k2, sum_kcrop, sum_p;
   unsigned long long arena_top;      // in-box points reserved in the arena
   unsigned int n_frames, n_hyp, n_overflow, n_pruned_keep;
-  unsigned int err_flags;            // bit0 arena overflow, bit1 rows overflow, bit2 nb1 overflow,
-                                     // bit3 global sweep scratch overflow
+  unsigned int err_flags;            // bit0 arena overflow, bit3 global sweep scratch overflow
+  unsigned int pad0;
+  // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
-  unsigned int pad;
+  unsigned int pad1;
+  unsigned long long sum_k1;         // neighbours visited by k_normals
 };
 
 struct LeNetDev {
@@ -64,6 +67,7 @@ struct ag2_ctx {
   size_t n_valid = 0;     // finite points (grid-resident)
   ag2::GridDesc grid{};
   bool has_cloud = false, has_normals = false;
+  bool normals_pending = false;  // k_normals launched, stats not collected yet
   float min_z = 0.f;
   ag2::DevBuf d_xyz_in;    // packed float4 (x,y,z, cam mask bits) in ORIGINAL order
   ag2::DevBuf d_key;       // int32 cell key per original point (-1 invalid)
@@ -120,6 +124,8 @@ int set_err(ag2_ctx* c, int code, const std::string& msg);
       return ag2::set_err(c, AG2_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
+// ag2_context.hip
+int collect_normals_stats(ag2_ctx* c);
 // k_grid.hip
 int build_grid(ag2_ctx* c);
 int gather_normals(ag2_ctx* c);  // d_tmp (float4, original order) -> d_nrm (sorted order)

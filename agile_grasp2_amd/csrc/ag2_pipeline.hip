@@ -48,9 +48,8 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     rc = launch_frames(c, s, slot_base, seed);
     if (rc) return rc;
     AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
-    rc = launch_sweep(c, s, slot_base, emit_lists);
+    rc = launch_sweep(c, s, slot_base, emit_lists);  // records ev[2] (LDS variant) and ev[11]
     if (rc) return rc;
-    AG2_HIP(c, hipEventRecord(c->ev[2], c->stream));
     DevStats hs;
     rc = read_stats(c, &hs);
     if (rc) return rc;
@@ -67,8 +66,15 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     c->cnt.sum_k2 = (int64_t)hs.sum_k2;
     c->cnt.sum_kcrop = (int64_t)hs.sum_kcrop;
     c->cnt.sum_p = (int64_t)hs.sum_p;
+    c->cnt.n_overflow_samples = hs.n_overflow;
     (void)hipEventElapsedTime(&c->times.frames_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->times.sweep_ms, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&c->times.sweep_overflow_ms, c->ev[2], c->ev[11]);
+    if (c->normals_pending) {  // the stream has been synchronised: k_normals is long done
+      (void)hipEventElapsedTime(&c->times.normals_ms, c->ev[9], c->ev[10]);
+      c->cnt.sum_k1 = (int64_t)hs.sum_k1;
+      c->normals_pending = false;
+    }
     return 0;
   }
   return set_err(c, AG2_ERR_CAPACITY, "point-list arena could not be sized");
@@ -294,7 +300,7 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
     if (n_img) memcpy(scored_all, all.data(), n_img * sizeof(ag2_hypothesis));
   }
   AG2_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipEventElapsedTime(&c->times.compact_ms, c->ev[2], c->ev[3]);
+  (void)hipEventElapsedTime(&c->times.compact_ms, c->ev[11], c->ev[3]);
   (void)hipEventElapsedTime(&c->times.render_ms, c->ev[3], c->ev[4]);
   (void)hipEventElapsedTime(&c->times.lenet_conv_ms, c->ev[4], c->ev[5]);
   (void)hipEventElapsedTime(&c->times.lenet_fc_ms, c->ev[5], c->ev[6]);

@@ -332,7 +332,8 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
   const int R = hc.R;
   const double hh = hc.hand_height;
   int red_sel = 0;
-  const int n_work = LDS_STORE ? A.n_samples : A.n_overflow;
+  const int n_work = LDS_STORE ? A.n_samples : (int)A.st->n_overflow;  // queue filled by k_sweep<true>
+  if (!LDS_STORE && n_work == 0) return;
   if (tid < 20) {
     S.fs[tid] = hc.fs[tid];
     S.fsr[tid] = hc.fsr[tid];
@@ -1138,36 +1139,34 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
   const int grid = (int)std::min<size_t>(s, 256 * 2);
   hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads), lds, c->stream, A);
   AG2_HIP(c, hipGetLastError());
-  // overflow samples (cropped neighbourhood larger than the LDS stage): global-scratch variant
-  DevStats hs;
-  AG2_HIP(c, hipMemcpyAsync(&hs, c->d_stats.p, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
-  AG2_HIP(c, hipStreamSynchronize(c->stream));
-  c->cnt.n_overflow_samples = hs.n_overflow;
+  AG2_HIP(c, hipEventRecord(c->ev[2], c->stream));
   if (want_prof) {
     unsigned long long h[8];
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
     AG2_HIP(c, hipMemcpy(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[ag2 sweep prof, LDS variant, cycles summed over workgroups] rows %llu crop1 %llu "
             "crop2 %llu passA %llu deepen %llu passC %llu passD %llu other %llu\n",
             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     AG2_HIP(c, hipMemsetAsync(prof_buf.p, 0, 16 * 8, c->stream));
   }
-  if (hs.n_overflow > 0) {
-    const int gcap = 1 << 16;
-    const int g2 = (int)std::min<unsigned>(hs.n_overflow, 512u);
-    AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 7 * gcap * 4));
-    A.n_overflow = (int)hs.n_overflow;
-    A.gscratch = c->d_gscratch.as<float>();
-    A.gcap = gcap;
-    hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads), sweep_lds_bytes(false), c->stream, A);
-    AG2_HIP(c, hipGetLastError());
-    if (want_prof) {
-      unsigned long long h[8];
-      AG2_HIP(c, hipStreamSynchronize(c->stream));
-      AG2_HIP(c, hipMemcpy(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[ag2 sweep prof, global variant] rows %llu crop1 %llu crop2 %llu passA %llu "
-              "deepen %llu passC %llu passD %llu other %llu\n",
-              h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-    }
+  // Overflow samples (cropped neighbourhood larger than the LDS stage) were queued on the device;
+  // the global-scratch instantiation is always launched and reads the queue length itself
+  // (st->n_overflow), so no host round trip sits between the two launches.
+  const int gcap = 1 << 16, g2 = 256;  // 256 workgroups x 7 x 64 Ki floats = 470 MB of scratch
+  AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 7 * gcap * 4));
+  A.n_overflow = -1;  // read from st->n_overflow on the device
+  A.gscratch = c->d_gscratch.as<float>();
+  A.gcap = gcap;
+  hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads), sweep_lds_bytes(false), c->stream, A);
+  AG2_HIP(c, hipGetLastError());
+  AG2_HIP(c, hipEventRecord(c->ev[11], c->stream));
+  if (want_prof) {
+    unsigned long long h[8];
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+    AG2_HIP(c, hipMemcpy(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[ag2 sweep prof, global variant] rows %llu crop1 %llu crop2 %llu passA %llu "
+            "deepen %llu passC %llu passD %llu other %llu\n",
+            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
   }
   return 0;
 }

@@ -55,10 +55,11 @@ def launch_params(ws, R):
                 num_selected=30, cam_origin=[scene.CAMERA, scene.CAMERA], workspace=list(ws))
 
 
-def cpu_baseline(xyz, ws, idx, R, weights, n_sub=2500):
-    """Oracle (CPU restatement) on a bounded sample: all points for normals, the first n_sub samples
-    for the rest; normals time is charged pro rata so the rate is comparable to the full job.
-    Threads: the box's CPU share for one GPU (16), or fewer if the host has fewer cores."""
+def cpu_baseline(xyz, ws, idx, R, weights, budget_s=12.0, max_reps=400):
+    """Oracle (CPU restatement of the reference algorithm) on the SAME workload: whole steps (grid +
+    normals + detect over all samples), repeated until about budget_s seconds of CPU work have been
+    spent, so the sample is bounded in time, not in size.  Threads: the box's CPU share for one GPU
+    (16), or fewer if the host has fewer cores."""
     from oracle import api
     try:
         avail = len(os.sched_getaffinity(0))
@@ -67,25 +68,31 @@ def cpu_baseline(xyz, ws, idx, R, weights, n_sub=2500):
     cores = max(1, min(16, avail))
     prm = launch_params(ws, R)
     o = api.Oracle(**dict(prm, num_threads=cores))
-    o.set_cloud(xyz)
-    o.compute_normals()
     o.lenet_load(weights)
-    sub = idx[:n_sub]
-    t0 = time.perf_counter()
-    _, scored = o.detect(sample_idx=sub, seed=1, do_prune=True)
-    t_rest = time.perf_counter() - t0
-    c = o.counters()
-    t_norm = c.t_normals * (len(sub) / max(1, len(idx)))
-    t = t_rest + t_norm
+    reps, scored_tot, t_tot = 0, 0, 0.0
+    stage = {"grid": 0.0, "normals": 0.0, "frames": 0.0, "hands": 0.0, "images": 0.0, "lenet": 0.0}
+    while reps < max_reps and (reps == 0 or t_tot < budget_s):
+        t0 = time.perf_counter()
+        o.set_cloud(xyz)
+        t1 = time.perf_counter()
+        o.compute_normals()
+        _, scored = o.detect(sample_idx=idx, seed=1, do_prune=True)
+        t_tot += time.perf_counter() - t0
+        c = o.counters()
+        stage["grid"] += t1 - t0
+        for k in ("normals", "frames", "hands", "images", "lenet"):
+            stage[k] += getattr(c, "t_" + k)
+        scored_tot += len(scored)
+        reps += 1
     return {
-        "value": len(scored) / t if t > 0 else 0.0, "unit": "hypotheses/s", "cores": cores,
+        "value": scored_tot / t_tot if t_tot > 0 else 0.0, "unit": "hypotheses/s", "cores": cores,
         "kind": "port",
-        "sample": (f"oracle (CPU restatement, grid NN + own LeNet, -O3 -fopenmp) on the same cloud: "
-                   f"normals for all {xyz.shape[0]} points ({c.t_normals:.2f} s, charged pro rata "
-                   f"{len(sub)}/{len(idx)}), then {len(sub)} of {len(idx)} samples through frames, hand "
-                   f"search, images, LeNet ({t_rest:.2f} s); {len(scored)} hypotheses scored"),
-        "stage_s": {"normals_full": c.t_normals, "frames": c.t_frames, "hands": c.t_hands,
-                    "images": c.t_images, "lenet": c.t_lenet},
+        "sample": (f"oracle (CPU restatement: grid radius search instead of FLANN, own PCA normals / image "
+                   f"scatter / fp32 LeNet instead of PCL / OpenCV / Caffe; -O3 -fopenmp -DNDEBUG, {cores} threads) "
+                   f"on the same cloud, samples and weights: {reps} full steps in {t_tot:.2f} s, "
+                   f"{scored_tot // max(1, reps)} hypotheses scored per step"),
+        "ms_per_step": t_tot / max(1, reps) * 1e3,
+        "stage_ms_per_step": {k: round(v / max(1, reps) * 1e3, 3) for k, v in stage.items()},
     }
 
 
@@ -97,6 +104,8 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the RCCL exchange path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,6 +117,11 @@ def main():
         sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Exactly ONE line goes to stdout (the JSON, rank 0).  Libraries print banners there (RCCL's
+    # version block, for one), so fd 1 points at stderr until the result is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch  # plumbing only: device memory, stream, torch.distributed (RCCL)
     import torch.distributed as dist
@@ -117,9 +131,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29518")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     n_points, S, R, voxelised, kind = CONFIGS[args.config]
     xyz, ws = scene.make_scene(args.seed, n_points, kind=kind, voxel=scene.VOXEL if voxelised else None)
@@ -132,7 +150,7 @@ def main():
     torch.cuda.synchronize()
     from agile_grasp2_amd import sharding
     slot_bytes = S * R * sharding.SLOT_BYTES
-    local_tab = torch.empty(slot_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+    local_tab = torch.empty(slot_bytes, dtype=torch.uint8, device="cuda") if dist_on else None
 
     acc = {}
 
@@ -141,14 +159,14 @@ def main():
         d.compute_normals()
         sel, n_scored = d.detect(sample_idx=idx, slot_base=rank * S, seed=args.seed, do_prune=True,
                                  want_all=False)
-        if world > 1:
+        if dist_on:
             # the path's one exchange step: fixed-slot candidate tables, RCCL all-gather over xGMI
             d.export_candidates_device(local_tab.data_ptr(), slot_bytes)
             sharding.all_gather_tables(local_tab, world)
         return n_scored
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -167,15 +185,14 @@ def main():
     c = d.counters()
 
     tt = torch.tensor([elapsed, float(scored), float(c.n_hypotheses)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if dist_on:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
     total_scored = float(tt[1])
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     # Untimed diagnostic pass: the measured path culls stencil rows by the sphere and the crop slab
@@ -196,7 +213,8 @@ def main():
     # algorithmic work per launch, measured neighbourhood sizes of this run
     kernels = {
         "k_normals": dict(bound="hbm", work=c.sum_k1 * 12 + c.n_valid_points * 12, ms=ms["normals_ms"]),
-        "k_sweep": dict(bound="hbm", work=sum_k2 * 24 + c.n_hypotheses * 176 + c.sum_p * 24, ms=ms["sweep_ms"]),
+        "k_sweep": dict(bound="hbm", work=sum_k2 * 24 + c.n_hypotheses * 176 + c.sum_p * 24,
+                        ms=ms["sweep_ms"] + ms["sweep_overflow_ms"]),  # both instantiations
         "k_render": dict(bound="hbm", work=c.sum_p * 24 * (n_img / max(1, c.n_hypotheses)) + n_img * 10800,
                          ms=ms["render_ms"]),
         "k_lenet_conv": dict(bound="mfma", work=n_img * CONV_FLOP, ms=ms["lenet_conv_ms"]),
@@ -211,6 +229,11 @@ def main():
             k["peak"], k["unit"] = PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
         k["frac"] = k["achieved"] / k["peak"]
     dom = max(kernels, key=lambda n: kernels[n]["ms"])
+    # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of the same command
+    # (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
+    # with the gfx950 factor-2 correction of MI355X_MICROARCH.md).  Counters cannot be read from
+    # inside this process, so the committed summary of the last profiled run is quoted; null if the
+    # kernel is not in it.
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
@@ -250,9 +273,12 @@ def main():
     }
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(xyz, ws, idx, R, weights)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
     d.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -94,14 +94,15 @@ typedef struct ag2_times {
   float grid_ms;        /* K0 search grid (ag2_set_cloud*) */
   float normals_ms;     /* K1 k_normals */
   float frames_ms;      /* K2 k_frames */
-  float sweep_ms;       /* K3 k_sweep (both instantiations) */
+  float sweep_ms;       /* K3 k_sweep, LDS-staged instantiation */
   float compact_ms;     /* prune-flag compaction + image descriptors */
   float render_ms;      /* K4 k_render */
   float lenet_conv_ms;  /* K5 k_lenet_conv */
   float lenet_fc_ms;    /* K5 k_lenet_fc */
   float select_ms;      /* K6 score scatter, threshold compaction, record gather */
   float total_ms;       /* first to last event of the call */
-  float reserved[2];
+  float sweep_overflow_ms; /* K3 k_sweep, global-scratch instantiation (oversized neighbourhoods) */
+  float reserved;
 } ag2_times;
 
 int ag2_abi_version(void);
