@@ -99,6 +99,11 @@ static int check_params(ag2_ctx* c) {
 
 // k_normals is launched without a host sync; its duration and neighbour counter are read here.
 int collect_normals_stats(ag2_ctx* c) {
+  if (c->grid_pending) {
+    AG2_HIP(c, hipEventSynchronize(c->ev[13]));
+    (void)hipEventElapsedTime(&c->times.grid_ms, c->ev[12], c->ev[13]);
+    c->grid_pending = false;
+  }
   if (!c->normals_pending) return 0;
   AG2_HIP(c, hipEventSynchronize(c->ev[10]));
   (void)hipEventElapsedTime(&c->times.normals_ms, c->ev[9], c->ev[10]);
@@ -207,17 +212,17 @@ int ag2_set_stream(ag2_ctx* c, void* hip_stream) {
 static int after_cloud(ag2_ctx* c) {
   memset(&c->cnt, 0, sizeof(c->cnt));
   c->normals_pending = false;
+  c->grid_pending = false;
   c->h_hyps.clear();
   c->h_slots.clear();
   c->h_offsets.clear();
   c->s = 0;
   c->n_img = 0;
-  AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
-  const int rc = build_grid(c);
+  AG2_HIP(c, hipEventRecord(c->ev[12], c->stream));
+  const int rc = build_grid(c);  // one host round trip inside (cloud bounds -> grid dimensions)
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
-  AG2_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipEventElapsedTime(&c->times.grid_ms, c->ev[0], c->ev[1]);
+  AG2_HIP(c, hipEventRecord(c->ev[13], c->stream));
+  c->grid_pending = true;        // duration collected at the next synchronisation point
   c->cnt.n_points = (int64_t)c->n;
   c->cnt.n_valid_points = (int64_t)c->n_valid;
   c->has_cloud = true;
@@ -329,8 +334,10 @@ int ag2_get_grid_perm(ag2_ctx* c, int32_t* perm, size_t cap, size_t* n_valid) {
   if (!c->has_cloud) return set_err(c, AG2_ERR_STATE, "no cloud set");
   *n_valid = c->n_valid;
   if (cap < c->n_valid) return set_err(c, AG2_ERR_CAPACITY, "perm buffer too small");
-  if (c->n_valid)
-    AG2_HIP(c, hipMemcpy(perm, c->d_perm.p, c->n_valid * 4, hipMemcpyDeviceToHost));
+  if (c->n_valid) {  // ordered behind the grid kernels on the context's stream
+    AG2_HIP(c, hipMemcpyAsync(perm, c->d_perm.p, c->n_valid * 4, hipMemcpyDeviceToHost, c->stream));
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+  }
   return 0;
 }
 

@@ -40,6 +40,8 @@ struct DevStats {
   unsigned long long arena_top;      // in-box points reserved in the arena
   unsigned int n_frames, n_hyp, n_overflow, n_pruned_keep;
   unsigned int err_flags;            // bit0 arena overflow, bit3 global sweep scratch overflow
+  unsigned int n_list;               // hypotheses that go on to be scored (after the prune)
+  unsigned int n_sel;                // scored hypotheses with score >= min_score_diff
   unsigned int pad0;
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
@@ -60,7 +62,7 @@ struct ag2_ctx {
   std::string err;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipEvent_t ev[12] = {};
+  hipEvent_t ev[16] = {};
 
   // cloud
   size_t n = 0;           // points given
@@ -68,6 +70,7 @@ struct ag2_ctx {
   ag2::GridDesc grid{};
   bool has_cloud = false, has_normals = false;
   bool normals_pending = false;  // k_normals launched, stats not collected yet
+  bool grid_pending = false;     // grid kernels launched, duration not collected yet
   float min_z = 0.f;
   ag2::DevBuf d_xyz_in;    // packed float4 (x,y,z, cam mask bits) in ORIGINAL order
   ag2::DevBuf d_key;       // int32 cell key per original point (-1 invalid)
@@ -139,6 +142,8 @@ int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed);
 int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists);
 // k_select.hip
 int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out);
+int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count);
+int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned* d_count);
 int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypothesis>& recs,
                    std::vector<int64_t>* offs, std::vector<uint8_t>* keep);
 int make_image_descs(ag2_ctx* c, const int* d_list, size_t n);

@@ -33,8 +33,11 @@ int read_stats(ag2_ctx* c, DevStats* hs) {
 }
 
 // frames + sweep for s samples; fills the slot table (and the arena when emit_lists).
+// compact_mode >= 0 additionally queues the order-preserving compaction of the slot table into
+// d_list2 (0: every hypothesis, 1: those surviving the prune) BEFORE the one host read-back, so the
+// caller learns the list length (c->n_img) without a second round trip.
 int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
-                   uint64_t slot_base, uint64_t seed, bool emit_lists) {
+                   uint64_t slot_base, uint64_t seed, bool emit_lists, int compact_mode = -1) {
   if (s * (size_t)c->p.num_orientations > ((size_t)1 << 30))
     return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 table slots");
   c->s = s;
@@ -50,6 +53,11 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
     rc = launch_sweep(c, s, slot_base, emit_lists);  // records ev[2] (LDS variant) and ev[11]
     if (rc) return rc;
+    if (compact_mode >= 0) {
+      rc = compact_slots_async(c, s * (size_t)c->p.num_orientations, compact_mode, c->d_list2,
+                               &c->d_stats.as<DevStats>()->n_list);
+      if (rc) return rc;
+    }
     DevStats hs;
     rc = read_stats(c, &hs);
     if (rc) return rc;
@@ -67,9 +75,14 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     c->cnt.sum_kcrop = (int64_t)hs.sum_kcrop;
     c->cnt.sum_p = (int64_t)hs.sum_p;
     c->cnt.n_overflow_samples = hs.n_overflow;
+    if (compact_mode >= 0) c->n_img = hs.n_list;
     (void)hipEventElapsedTime(&c->times.frames_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->times.sweep_ms, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&c->times.sweep_overflow_ms, c->ev[2], c->ev[11]);
+    if (c->grid_pending) {
+      (void)hipEventElapsedTime(&c->times.grid_ms, c->ev[12], c->ev[13]);
+      c->grid_pending = false;
+    }
     if (c->normals_pending) {  // the stream has been synchronised: k_normals is long done
       (void)hipEventElapsedTime(&c->times.normals_ms, c->ev[9], c->ev[10]);
       c->cnt.sum_k1 = (int64_t)hs.sum_k1;
@@ -252,13 +265,13 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   if (rc) return rc;
   if (!c->net.loaded) return set_err(c, AG2_ERR_STATE, "lenet weights not loaded");
   const size_t n_slots = s * (size_t)c->p.num_orientations;
+  (void)n_slots;
   AG2_HIP(c, hipEventRecord(c->ev[8], c->stream));
-  rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true);   // 1. hypotheses
+  // 1. hypotheses + 2. prune (predicate evaluated in the sweep; the survivor list is compacted on
+  // the device and its length comes back with the sweep's statistics: one host round trip)
+  rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true, do_prune ? 1 : 0);
   if (rc) return rc;
-  size_t n_img = 0;                                                            // 2. prune
-  rc = compact_slots(c, n_slots, do_prune ? 1 : 0, c->d_list2, &n_img);
-  if (rc) return rc;
-  c->n_img = n_img;
+  const size_t n_img = c->n_img;
   c->cnt.n_pruned = (int64_t)n_img;
   AG2_HIP(c, c->d_images.reserve(std::max<size_t>(n_img, 1) * 10800));
   AG2_HIP(c, c->d_logits.reserve(std::max<size_t>(n_img, 1) * 8));
@@ -273,16 +286,30 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   rc = launch_lenet(c, c->d_images.as<uint8_t>(), n_img, c->d_logits.as<float>(), c->ev[5]);  // 3b.
   if (rc) return rc;
   AG2_HIP(c, hipEventRecord(c->ev[6], c->stream));
-  rc = launch_scatter_scores(c, c->d_list2.as<int>(), n_img);
-  if (rc) return rc;
-  size_t n_anti = 0;                                                           // score >= thr
-  rc = compact_slots(c, n_slots, 2, c->d_list, &n_anti);
-  if (rc) return rc;
-  std::vector<ag2_hypothesis> anti;
-  rc = gather_records(c, c->d_list.as<int>(), n_anti, anti, nullptr, nullptr);
+  // 4. score = ip2[1] - ip2[0], keep score >= min_score_diff, gather in order -- all on the device;
+  // one read-back brings the count and (for the usual small lists) the records themselves
+  unsigned* d_nsel = &c->d_stats.as<DevStats>()->n_sel;
+  rc = score_and_select_async(c, c->d_list2.as<int>(), n_img, d_nsel);
   if (rc) return rc;
   AG2_HIP(c, hipEventRecord(c->ev[7], c->stream));
-  for (auto& h : anti) h.full_antipodal = 1;                                   // :205
+  std::vector<ag2_hypothesis> anti;
+  {
+    unsigned n_anti = 0;
+    const bool small = n_img * sizeof(ag2_hypothesis) <= ((size_t)2 << 20);
+    if (small && n_img) {
+      anti.resize(n_img);
+      AG2_HIP(c, hipMemcpyAsync(anti.data(), c->d_tmp.p, n_img * sizeof(ag2_hypothesis),
+                                hipMemcpyDeviceToHost, c->stream));
+    }
+    AG2_HIP(c, hipMemcpyAsync(&n_anti, d_nsel, 4, hipMemcpyDeviceToHost, c->stream));
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+    if (!small && n_anti) {
+      anti.resize(n_anti);
+      AG2_HIP(c, hipMemcpy(anti.data(), c->d_tmp.p, (size_t)n_anti * sizeof(ag2_hypothesis),
+                           hipMemcpyDeviceToHost));
+    }
+    anti.resize(n_anti);
+  }
   // 5. top num_selected by score, descending (grasp_detector.cpp:239-252); ties by position
   std::stable_sort(anti.begin(), anti.end(),
                    [](const ag2_hypothesis& a, const ag2_hypothesis& b) { return a.score > b.score; });

@@ -34,9 +34,12 @@ __global__ void k_slot_scatter(const unsigned* __restrict__ pref, int n_slots,
   if (pref[i + 1] != pref[i]) list[pref[i]] = i;
 }
 
-int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out) {
-  *n_out = 0;
-  if (n_slots == 0) return 0;
+// Asynchronous: the list length is left on the device (*d_count) -- no host round trip.
+int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count) {
+  if (n_slots == 0) {
+    AG2_HIP(c, hipMemsetAsync(d_count, 0, 4, c->stream));
+    return 0;
+  }
   AG2_HIP(c, c->d_flags.reserve((n_slots + 1) * 4));
   AG2_HIP(c, out_list.reserve(n_slots * 4));
   unsigned* fl = c->d_flags.as<unsigned>();
@@ -48,10 +51,73 @@ int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t
   if (rc) return rc;
   hipLaunchKernelGGL(k_slot_scatter, dim3(nb), dim3(256), 0, c->stream, fl, (int)n_slots,
                      out_list.as<int>());
+  AG2_HIP(c, hipMemcpyAsync(d_count, fl + n_slots, 4, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out) {
+  *n_out = 0;
+  if (n_slots == 0) return 0;
+  unsigned* d_count = &c->d_stats.as<DevStats>()->n_list;
+  const int rc = compact_slots_async(c, n_slots, mode, out_list, d_count);
+  if (rc) return rc;
   unsigned total = 0;
-  AG2_HIP(c, hipMemcpyAsync(&total, fl + n_slots, 4, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipMemcpyAsync(&total, d_count, 4, hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
   *n_out = total;
+  return 0;
+}
+
+// ---- tail of detectGraspPoses: score, threshold, ordered gather (grasp_detector.cpp:198-207) ----
+// per scored image i (list order = output order): score = ip2[1] - ip2[0] (:200) written into the
+// table slot, flag = score >= min_score_diff (:202)
+__global__ void k_score_flags(const float* __restrict__ logits, const int* __restrict__ list, int n,
+                              ag2_hypothesis* __restrict__ table, unsigned char* __restrict__ keep,
+                              double thr, unsigned* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  unsigned f = 0;
+  if (i < n) {
+    const int s = list[i];
+    const float sc = logits[2 * i + 1] - logits[2 * i];
+    table[s].score = (double)sc;
+    keep[s] = 2;
+    f = ((double)sc >= thr) ? 1u : 0u;
+  }
+  flags[i] = f;
+}
+
+__global__ void k_gather_selected(const unsigned* __restrict__ pref, const int* __restrict__ list,
+                                  int n, const ag2_hypothesis* __restrict__ table,
+                                  ag2_hypothesis* __restrict__ out, unsigned* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *count = pref[n];
+  if (i >= n) return;
+  if (pref[i + 1] != pref[i]) {
+    ag2_hypothesis h = table[list[i]];
+    h.full_antipodal = 1;  // grasp_detector.cpp:205
+    out[pref[i]] = h;
+  }
+}
+
+// Leaves the selected records (score >= threshold, list order) in d_tmp and their count in *d_count.
+int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned* d_count) {
+  if (n_img == 0) {
+    AG2_HIP(c, hipMemsetAsync(d_count, 0, 4, c->stream));
+    return 0;
+  }
+  AG2_HIP(c, c->d_flags.reserve((n_img + 1) * 4));
+  AG2_HIP(c, c->d_tmp.reserve(n_img * sizeof(ag2_hypothesis)));
+  unsigned* fl = c->d_flags.as<unsigned>();
+  const int nb = ((int)n_img + 1 + 255) / 256;
+  hipLaunchKernelGGL(k_score_flags, dim3(nb), dim3(256), 0, c->stream, c->d_logits.as<float>(), d_list,
+                     (int)n_img, c->d_table.as<ag2_hypothesis>(), c->d_tab_keep.as<unsigned char>(),
+                     c->p.min_score_diff, fl);
+  const int rc = scan_exclusive_u32(c, fl, (int)n_img + 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_gather_selected, dim3(nb), dim3(256), 0, c->stream, fl, d_list, (int)n_img,
+                     c->d_table.as<ag2_hypothesis>(), c->d_tmp.as<ag2_hypothesis>(), d_count);
+  AG2_HIP(c, hipGetLastError());
   return 0;
 }
 

@@ -19,7 +19,7 @@ namespace ag2 {
 
 constexpr int kSweepThreads = 256;
 constexpr int kSweepWaves = kSweepThreads / kWave;
-constexpr int kLdsCap = 2528;  // cropped points resident in LDS (24 B each); larger samples take
+constexpr int kLdsCap = 3648;  // cropped points resident in LDS (16 B each); larger samples take
                                // the global-scratch instantiation of the same kernel
 
 // ---------------------------------------------------------------------------------------------
@@ -300,7 +300,7 @@ struct SweepShared {
 };
 
 // two workgroups per CU: 2 x (control block + LDS-staged cropped list) must fit 160 KiB
-static_assert(((sizeof(SweepShared) + 15) & ~size_t(15)) + (size_t)kLdsCap * 26 <= 81920,
+static_assert(((sizeof(SweepShared) + 15) & ~size_t(15)) + (size_t)kLdsCap * 18 <= 81920,
               "k_sweep<true> no longer fits two workgroups per CU");
 
 // RMAX: compile-time bound on num_orientations (8, 16 or 32) for the per-orientation registers
@@ -312,19 +312,19 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
   float* pbase;
   unsigned short* box16 = nullptr;
   int* box32 = nullptr;
+  // staged cropped list: centred xyz (float) + sorted position of the point (its normal is fetched
+  // from L2 only for the few points that end up inside a closing region) = 16 B per point
   if (LDS_STORE) {
     pbase = reinterpret_cast<float*>(smem_raw + ((sizeof(SweepShared) + 15) & ~size_t(15)));
-    box16 = reinterpret_cast<unsigned short*>(pbase + 6 * kLdsCap);
+    box16 = reinterpret_cast<unsigned short*>(pbase + 4 * kLdsCap);
   } else {
-    pbase = A.gscratch + (size_t)blockIdx.x * 7 * (size_t)A.gcap;
-    box32 = reinterpret_cast<int*>(pbase + 6 * (size_t)A.gcap);
+    pbase = A.gscratch + (size_t)blockIdx.x * 5 * (size_t)A.gcap;
+    box32 = reinterpret_cast<int*>(pbase + 4 * (size_t)A.gcap);
   }
   float* PX = pbase;
   float* PY = pbase + CAP;
   float* PZ = pbase + 2 * (size_t)CAP;
-  float* NX = pbase + 3 * (size_t)CAP;
-  float* NY = pbase + 4 * (size_t)CAP;
-  float* NZ = pbase + 5 * (size_t)CAP;
+  int* POS = reinterpret_cast<int*>(pbase + 3 * (size_t)CAP);
 
   const HandConst& hc = *A.hc;
   const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
     const unsigned long long lt_half = lt_mask & half_mask;  // lower lanes of my half-wave
     for (int pp0 = wid; pp0 < n_pairs; pp0 += 4 * kSweepWaves) {
       int pb[4], pl[4], po[4];
-      float4 pv[4], nv[4];
+      float4 pv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int pc = 2 * (pp0 + u * kSweepWaves) + half;
@@ -607,33 +607,27 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
         pb[u] = ok ? S.piece_start[pc] : 0;
         pl[u] = (int)(lc & 0xFFFFu);
         po[u] = (int)(lc >> 16);
-        pv[u] = nv[u] = make_float4(0, 0, 0, 0);
-        if (l31 < pl[u]) {
-          pv[u] = A.pts[pb[u] + l31];
-          nv[u] = A.nrm[pb[u] + l31];
-        }
+        pv[u] = make_float4(0, 0, 0, 0);
+        if (l31 < pl[u]) pv[u] = A.pts[pb[u] + l31];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         int dst0 = po[u];
-        float4 d, nn = nv[u];
-        int cls = (l31 < pl[u]) ? classify(pv[u], d) : 0;
+        float4 d;
+        int j = l31;
+        int cls = (j < pl[u]) ? classify(pv[u], d) : 0;
         for (int o = 0;;) {
           const unsigned long long mask = __ballot(cls == 3);
           if (cls == 3) {
             const int dst = dst0 + __popcll(mask & lt_half);
             PX[dst] = d.x; PY[dst] = d.y; PZ[dst] = d.z;
-            NX[dst] = nn.x; NY[dst] = nn.y; NZ[dst] = nn.z;
+            POS[dst] = pb[u] + j;
           }
           dst0 += __popcll(mask & half_mask);
           o += 32;
           if (o >= pl[u]) break;
-          const int j = o + l31;
-          cls = 0;
-          if (j < pl[u]) {
-            nn = A.nrm[pb[u] + j];
-            cls = classify(A.pts[pb[u] + j], d);
-          }
+          j = o + l31;
+          cls = (j < pl[u]) ? classify(A.pts[pb[u] + j], d) : 0;
         }
       }
     }
@@ -928,7 +922,8 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
       for (int b = tid; b < P; b += kSweepThreads) {
         const int j = LDS_STORE ? (int)box16[b] : box32[b];
         const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
-        const double q0 = (double)NX[j], q1 = (double)NY[j], q2 = (double)NZ[j];
+        const float4 nn = A.nrm[POS[j]];  // hand_search.cpp:211, :394: the point's normal
+        const double q0 = (double)nn.x, q1 = (double)nn.y, q2 = (double)nn.z;
         double X[3], Y[3], U[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -1044,7 +1039,7 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
 
 static size_t sweep_lds_bytes(bool lds_store) {
   size_t b = (sizeof(SweepShared) + 15) & ~size_t(15);
-  if (lds_store) b += (size_t)kLdsCap * 6 * 4 + (size_t)kLdsCap * 2;
+  if (lds_store) b += (size_t)kLdsCap * 4 * 4 + (size_t)kLdsCap * 2;
   return b;
 }
 
@@ -1152,8 +1147,8 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
   // Overflow samples (cropped neighbourhood larger than the LDS stage) were queued on the device;
   // the global-scratch instantiation is always launched and reads the queue length itself
   // (st->n_overflow), so no host round trip sits between the two launches.
-  const int gcap = 1 << 16, g2 = 256;  // 256 workgroups x 7 x 64 Ki floats = 470 MB of scratch
-  AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 7 * gcap * 4));
+  const int gcap = 1 << 16, g2 = 256;  // 256 workgroups x 5 x 64 Ki words = 336 MB of scratch
+  AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 5 * gcap * 4));
   A.n_overflow = -1;  // read from st->n_overflow on the device
   A.gscratch = c->d_gscratch.as<float>();
   A.gcap = gcap;
