@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libag2hip.so")
+# AG2_LIB lets a tuning experiment point the harness at another build of the SAME library
+LIB_PATH = os.environ.get("AG2_LIB") or os.path.join(_HERE, "csrc", "libag2hip.so")
 
 SYMBOLS = [
     "ag2_abi_version", "ag2_default_params", "ag2_create", "ag2_destroy", "ag2_last_error",
@@ -20,6 +21,7 @@ SYMBOLS = [
     "ag2_hyp_points", "ag2_prune", "ag2_render_images", "ag2_render_images_from_points",
     "ag2_lenet_load", "ag2_lenet_forward", "ag2_detect", "ag2_export_candidates_device",
     "ag2_get_counters", "ag2_get_stage_times",
+    "ag2_preprocess_cloud", "ag2_preprocess_cloud_device", "ag2_get_cloud", "ag2_subsample_uniformly",
 ]
 
 
@@ -49,7 +51,7 @@ class Counters(C.Structure):
 class Times(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "grid_ms", "normals_ms", "frames_ms", "sweep_ms", "compact_ms", "render_ms",
-        "lenet_conv_ms", "lenet_fc_ms", "select_ms", "total_ms", "sweep_overflow_ms", "reserved")]
+        "lenet_conv_ms", "lenet_fc_ms", "select_ms", "total_ms", "sweep_overflow_ms", "preprocess_ms")]
 
 
 HYP_DTYPE = np.dtype([
@@ -162,6 +164,52 @@ class Detector:
         self._ck(self.L.ag2_set_cloud_device(self.h, C.c_void_p(dptr), C.c_size_t(n),
                                              C.c_size_t(stride_bytes)))
 
+    def preprocess_cloud(self, xyz, cam_source=None, normals=None, filter_workspace=True,
+                         voxelize=True, voxel_size=0.003, flags=0):
+        """GraspDetector::preprocessPointCloud steps 1-2 on the GPU; returns the processed size."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n = xyz.shape[0]
+        ncam, cs, nr = 1, None, None
+        if cam_source is not None:
+            cs = np.asfortranarray(np.asarray(cam_source, dtype=np.int32))
+            ncam = cs.shape[0]
+        if normals is not None:
+            nr = np.asfortranarray(np.asarray(normals, dtype=np.float64))
+        m = C.c_size_t(0)
+        self._ck(self.L.ag2_preprocess_cloud(
+            self.h, _ptr(xyz), C.c_size_t(n), C.c_size_t(xyz.strides[0] if n else 12), _ptr(cs),
+            C.c_int(ncam), _ptr(nr), C.c_int(int(filter_workspace)), C.c_int(int(voxelize)),
+            C.c_double(voxel_size), C.c_int(flags), C.byref(m)))
+        self.n = m.value
+        return self.n
+
+    def preprocess_cloud_device(self, dptr: int, n: int, stride_bytes: int = 12,
+                                filter_workspace=True, voxelize=True, voxel_size=0.003):
+        m = C.c_size_t(0)
+        self._ck(self.L.ag2_preprocess_cloud_device(
+            self.h, C.c_void_p(dptr), C.c_size_t(n), C.c_size_t(stride_bytes),
+            C.c_int(int(filter_workspace)), C.c_int(int(voxelize)), C.c_double(voxel_size), C.byref(m)))
+        self.n = m.value
+        return self.n
+
+    def get_cloud(self):
+        ncam = int(self.params.n_cams)
+        xyz = np.zeros((self.n, 3), dtype=np.float32)
+        cam = np.zeros((ncam, self.n), dtype=np.int32, order="F")
+        m = C.c_size_t(0)
+        self._ck(self.L.ag2_get_cloud(self.h, _ptr(xyz), _ptr(cam), C.c_size_t(self.n), C.byref(m)))
+        assert m.value == self.n
+        return xyz, cam
+
+    def subsample_uniformly(self, num_samples, seed=0, want_indices=True):
+        """CloudCamera::subsampleUniformly; the indices also stay resident for detect(n_resident=...)."""
+        out = np.zeros(max(1, min(num_samples, self.n)), dtype=np.int32) if want_indices else None
+        m = C.c_size_t(0)
+        self._ck(self.L.ag2_subsample_uniformly(
+            self.h, C.c_size_t(num_samples), C.c_uint64(seed), _ptr(out),
+            C.c_size_t(out.shape[0] if want_indices else 0), C.byref(m)))
+        return out[: m.value].copy() if want_indices else m.value
+
     def compute_normals(self):
         self._ck(self.L.ag2_compute_normals(self.h))
 
@@ -177,8 +225,11 @@ class Detector:
         return out[: nv.value].copy()
 
     @staticmethod
-    def _samples(sample_idx, sample_xyz):
+    def _samples(sample_idx, sample_xyz, n_resident=None):
         si = sx = None
+        if n_resident is not None:  # indices left on the device by subsample_uniformly
+            assert sample_idx is None and sample_xyz is None
+            return None, None, int(n_resident)
         if sample_idx is not None:
             si = np.ascontiguousarray(sample_idx, dtype=np.int32)
             s = si.shape[0]
@@ -196,8 +247,9 @@ class Detector:
                                          C.c_uint64(slot_base), C.c_uint64(seed), _ptr(fr), _ptr(valid)))
         return fr, valid
 
-    def generate_hypotheses(self, sample_idx=None, sample_xyz=None, slot_base=0, seed=0):
-        si, sx, s = self._samples(sample_idx, sample_xyz)
+    def generate_hypotheses(self, sample_idx=None, sample_xyz=None, slot_base=0, seed=0,
+                            n_resident=None):
+        si, sx, s = self._samples(sample_idx, sample_xyz, n_resident)
         cap = max(1, s * int(self.params.num_orientations))
         out = np.zeros(cap, dtype=HYP_DTYPE)
         n = C.c_size_t(0)
@@ -251,8 +303,8 @@ class Detector:
         return out
 
     def detect(self, sample_idx=None, sample_xyz=None, slot_base=0, seed=0, do_prune=True,
-               want_all=True):
-        si, sx, s = self._samples(sample_idx, sample_xyz)
+               want_all=True, n_resident=None):
+        si, sx, s = self._samples(sample_idx, sample_xyz, n_resident)
         cap = max(1, s * int(self.params.num_orientations))
         sel = np.zeros(cap, dtype=HYP_DTYPE)
         allh = np.zeros(cap if want_all else 1, dtype=HYP_DTYPE)

@@ -114,6 +114,28 @@ int collect_normals_stats(ag2_ctx* c) {
   return 0;
 }
 
+// d_xyz_in / n hold a new cloud: drop everything derived from the previous one, build the grid.
+int after_cloud(ag2_ctx* c) {
+  memset(&c->cnt, 0, sizeof(c->cnt));
+  c->normals_pending = false;
+  c->grid_pending = false;
+  c->h_hyps.clear();
+  c->h_slots.clear();
+  c->h_offsets.clear();
+  c->s = 0;
+  c->n_img = 0;
+  c->n_resident_samples = 0;
+  AG2_HIP(c, hipEventRecord(c->ev[12], c->stream));
+  const int rc = build_grid(c);  // one host round trip inside (cloud bounds -> grid dimensions)
+  if (rc) return rc;
+  AG2_HIP(c, hipEventRecord(c->ev[13], c->stream));
+  c->grid_pending = true;        // duration collected at the next synchronisation point
+  c->cnt.n_points = (int64_t)c->n;
+  c->cnt.n_valid_points = (int64_t)c->n_valid;
+  c->has_cloud = true;
+  return 0;
+}
+
 }  // namespace ag2
 
 using namespace ag2;
@@ -188,8 +210,10 @@ void ag2_destroy(ag2_ctx* c) {
                     &c->d_nrm, &c->d_scan, &c->d_stats, &c->d_hc, &c->d_sample_q, &c->d_frames,
                     &c->d_frame_ok, &c->d_table, &c->d_tab_off, &c->d_tab_keep, &c->d_arena,
                     &c->d_overflow, &c->d_gscratch, &c->d_list, &c->d_list2, &c->d_images,
-                    &c->d_logits, &c->d_act1, &c->d_fcpart, &c->d_tmp, &c->d_flags, &c->d_desc, &c->net.w1p, &c->net.b1, &c->net.w2p,
-                    &c->net.b2, &c->net.w3p, &c->net.b3, &c->net.w4, &c->net.b4};
+                    &c->d_logits, &c->d_act1, &c->d_fcpart, &c->d_tmp, &c->d_flags, &c->d_desc,
+                    &c->d_raw, &c->d_raw_nrm, &c->d_pre, &c->d_pflags, &c->d_bitmap, &c->d_wrank,
+                    &c->d_first, &c->d_prestats, &c->d_hist, &c->d_samples, &c->net.w1p, &c->net.b1,
+                    &c->net.w2p, &c->net.b2, &c->net.w3p, &c->net.b3, &c->net.w4, &c->net.b4};
   for (DevBuf* b : bufs) b->release();
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -206,26 +230,6 @@ int ag2_set_stream(ag2_ctx* c, void* hip_stream) {
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   c->own_stream = false;
   c->stream = (hipStream_t)hip_stream;  // NULL = the HIP default (null) stream, torch's default
-  return 0;
-}
-
-static int after_cloud(ag2_ctx* c) {
-  memset(&c->cnt, 0, sizeof(c->cnt));
-  c->normals_pending = false;
-  c->grid_pending = false;
-  c->h_hyps.clear();
-  c->h_slots.clear();
-  c->h_offsets.clear();
-  c->s = 0;
-  c->n_img = 0;
-  AG2_HIP(c, hipEventRecord(c->ev[12], c->stream));
-  const int rc = build_grid(c);  // one host round trip inside (cloud bounds -> grid dimensions)
-  if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[13], c->stream));
-  c->grid_pending = true;        // duration collected at the next synchronisation point
-  c->cnt.n_points = (int64_t)c->n;
-  c->cnt.n_valid_points = (int64_t)c->n_valid;
-  c->has_cloud = true;
   return 0;
 }
 
@@ -286,7 +290,7 @@ int ag2_set_cloud_device(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_
   c->n = n;
   c->has_cloud = c->has_normals = false;
   AG2_HIP(c, c->d_xyz_in.reserve(std::max<size_t>(n, 1) * 16));
-  const int rc = pack_device_xyz(c, d_xyz, n, stride_bytes);
+  const int rc = pack_device_xyz(c, d_xyz, n, stride_bytes, c->d_xyz_in.as<float4>());
   if (rc) return rc;
   return after_cloud(c);
 }

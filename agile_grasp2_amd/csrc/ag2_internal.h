@@ -49,6 +49,28 @@ struct DevStats {
   unsigned long long sum_k1;         // neighbours visited by k_normals
 };
 
+// float <-> int whose signed order matches the float order (atomicMin/atomicMax on bounds)
+__host__ __device__ __forceinline__ int f2ord(float f) {
+  int i;
+  __builtin_memcpy(&i, &f, 4);
+  return i ^ ((i >> 31) & 0x7fffffff);
+}
+__host__ __device__ __forceinline__ float ord2f(int i) {
+  const int b = i ^ ((i >> 31) & 0x7fffffff);
+  float f;
+  __builtin_memcpy(&f, &b, 4);
+  return f;
+}
+
+// Device-side state of the preprocessing kernels (k_preprocess.hip).
+struct PreStats {
+  int mn[3], mx[3];            // ordered-int bounds of the points that pass the workspace filter
+  unsigned int n_keep;         // their count
+  unsigned int sel_prefix[3];  // radix select of the sub-sampling threshold: (hash hi, hash lo, index)
+  unsigned int sel_remaining;
+  unsigned int pad;
+};
+
 struct LeNetDev {
   bool loaded = false;
   DevBuf w1p, b1, w2p, b2, w3p, b3, w4, b4;  // packed for the MFMA lane layout (k_lenet.hip)
@@ -83,6 +105,19 @@ struct ag2_ctx {
   ag2::DevBuf d_stats;     // DevStats
   ag2::DevBuf d_hc;        // HandConst
   ag2::HandConst hc{};
+
+  // preprocessing (k_preprocess.hip)
+  ag2::DevBuf d_raw;       // float4 (x,y,z, cam mask bits) as handed over, before filter / voxel grid
+  ag2::DevBuf d_raw_nrm;   // float4 normals that came with the raw cloud
+  ag2::DevBuf d_pre;       // float4 points that passed the workspace filter
+  ag2::DevBuf d_pflags;    // uint32 keep flags -> exclusive prefix
+  ag2::DevBuf d_bitmap;    // occupancy bit per voxel, ascending (ix, iy, iz) key
+  ag2::DevBuf d_wrank;     // uint32 per bitmap word: rank of its first voxel
+  ag2::DevBuf d_first;     // int32 per voxel: smallest point index inside
+  ag2::DevBuf d_prestats;  // PreStats
+  ag2::DevBuf d_hist;      // 65536-bin digit histogram of the sub-sampling radix select
+  ag2::DevBuf d_samples;   // int32 sample indices left resident by ag2_subsample_uniformly
+  size_t n_resident_samples = 0;
 
   // samples / hypotheses of the last generate call
   size_t s = 0;
@@ -129,10 +164,11 @@ int set_err(ag2_ctx* c, int code, const std::string& msg);
 
 // ag2_context.hip
 int collect_normals_stats(ag2_ctx* c);
+int after_cloud(ag2_ctx* c);
 // k_grid.hip
 int build_grid(ag2_ctx* c);
 int gather_normals(ag2_ctx* c);  // d_tmp (float4, original order) -> d_nrm (sorted order)
-int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes);
+int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, float4* dst);
 int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n);
 // k_normals.hip
 int launch_normals(ag2_ctx* c);

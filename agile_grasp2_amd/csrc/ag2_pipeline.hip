@@ -11,12 +11,16 @@ using namespace ag2;
 
 namespace {
 
-int check_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz) {
+int check_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s) {
   if (!c->has_cloud) return set_err(c, AG2_ERR_STATE, "no cloud set");
   if (!c->has_normals)
     return set_err(c, AG2_ERR_STATE, "normals missing: call ag2_compute_normals or pass normals");
-  if ((sample_idx == nullptr) == (sample_xyz == nullptr))
-    return set_err(c, AG2_ERR_ARG, "exactly one of sample_idx / sample_xyz must be given");
+  if (sample_idx && sample_xyz)
+    return set_err(c, AG2_ERR_ARG, "at most one of sample_idx / sample_xyz may be given");
+  if (!sample_idx && !sample_xyz && s > c->n_resident_samples)
+    return set_err(c, AG2_ERR_ARG,
+                   "no sample_idx / sample_xyz given and fewer than s indices left by "
+                   "ag2_subsample_uniformly");
   return 0;
 }
 
@@ -101,7 +105,7 @@ int ag2_local_frames(ag2_ctx* c, const int32_t* sample_idx, const double* sample
                      uint64_t slot_base, uint64_t seed, double* frames, int32_t* valid) {
   if (!c) return AG2_ERR_ARG;
   (void)hipSetDevice(c->device);
-  int rc = check_samples(c, sample_idx, sample_xyz);
+  int rc = check_samples(c, sample_idx, sample_xyz, s);
   if (rc) return rc;
   rc = reset_stats(c);
   if (rc) return rc;
@@ -125,7 +129,7 @@ int ag2_generate_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double*
                             size_t cap, size_t* n_out) {
   if (!c || !n_out) return AG2_ERR_ARG;
   (void)hipSetDevice(c->device);
-  int rc = check_samples(c, sample_idx, sample_xyz);
+  int rc = check_samples(c, sample_idx, sample_xyz, s);
   if (rc) return rc;
   rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true);
   if (rc) return rc;
@@ -261,7 +265,7 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
                size_t* n_scored) {
   if (!c || !n_selected) return AG2_ERR_ARG;
   (void)hipSetDevice(c->device);
-  int rc = check_samples(c, sample_idx, sample_xyz);
+  int rc = check_samples(c, sample_idx, sample_xyz, s);
   if (rc) return rc;
   if (!c->net.loaded) return set_err(c, AG2_ERR_STATE, "lenet weights not loaded");
   const size_t n_slots = s * (size_t)c->p.num_orientations;

@@ -8,17 +8,6 @@
 
 namespace ag2 {
 
-__device__ __forceinline__ int f2ord(float f) {
-  const int i = __float_as_int(f);
-  return i ^ ((i >> 31) & 0x7fffffff);
-}
-static inline float ord2f(int i) {
-  const int b = i ^ ((i >> 31) & 0x7fffffff);
-  float f;
-  __builtin_memcpy(&f, &b, 4);
-  return f;
-}
-
 __global__ void k_init_stats(DevStats* st) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     DevStats z{};
@@ -205,10 +194,10 @@ int gather_normals(ag2_ctx* c) {
   return 0;
 }
 
-int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes) {
+int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, float4* dst) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_pack_xyz, dim3(((int)n + 255) / 256), dim3(256), 0, c->stream,
-                     (const char*)d_xyz, stride_bytes, (int)n, c->d_xyz_in.as<float4>());
+                     (const char*)d_xyz, stride_bytes, (int)n, dst);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }

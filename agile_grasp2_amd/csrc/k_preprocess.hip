@@ -1,0 +1,533 @@
+// k_preprocess.hip -- the step in front of the hot path, on the GPU.
+//
+// Replaces GraspDetector::preprocessPointCloud steps 1-3 (src/agile_grasp2/grasp_detector.cpp:285-335):
+//   1. CloudCamera::filterWorkspace   (cloud_camera.cpp:89-121)  flag -> scan -> ordered compaction
+//   2. CloudCamera::voxelizeCloud     (cloud_camera.cpp:124-168) occupancy bitmap in (ix, iy, iz) key
+//      order instead of a std::set: marking is one atomicOr per point, the sorted unique voxel list
+//      falls out of a popcount scan over the bitmap words -- no sort, no hash table
+//   3. CloudCamera::subsampleUniformly (cloud_camera.cpp:171-178) the num_samples smallest of the
+//      per-point keys (draw_u64(seed, stream, i), i), found by a 6-digit radix select that never
+//      materialises the keys
+// The result is written straight into the context's cloud buffer (as ag2_set_cloud would) and the
+// sample indices stay on the device for ag2_detect / ag2_generate_hypotheses.
+//
+// All of it is HBM-bound integer/byte work: per point 16 B read + 4 B flag, 16 B write for the
+// survivors; per voxel-grid word 4 B read twice + 4 B rank.
+#include <math.h>
+
+#include <algorithm>
+
+#include "ag2_internal.h"
+
+namespace ag2 {
+
+constexpr uint64_t kSubsampleStream = 0xFFFFFFFFFFFFFFF0ull;  // "slot" of the sub-sampling draws
+
+struct WsBox {
+  double b[6];
+};
+struct VoxDesc {
+  float mn[3];
+  float cell;
+  int dims[3];
+  int pad;
+};
+
+__global__ void k_pre_init(PreStats* ps) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    PreStats z{};
+    z.mn[0] = z.mn[1] = z.mn[2] = 0x7fffffff;
+    z.mx[0] = z.mx[1] = z.mx[2] = (int)0x80000000;
+    *ps = z;
+  }
+}
+
+// cloud_camera.cpp:94-95: strict bounds, the float coordinate widened to double.  Non-finite
+// points fail every comparison; they are dropped when the filter is off as well.
+__global__ void __launch_bounds__(256) k_pre_flag_bounds(const float4* __restrict__ raw, int n,
+                                                         WsBox ws, int do_filter,
+                                                         unsigned* __restrict__ flags,
+                                                         PreStats* __restrict__ ps) {
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+  int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  int cnt = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = raw[i];
+    bool keep = finite3(p.x, p.y, p.z);
+    if (keep && do_filter)
+      keep = (double)p.x > ws.b[0] && (double)p.x < ws.b[1] && (double)p.y > ws.b[2] &&
+             (double)p.y < ws.b[3] && (double)p.z > ws.b[4] && (double)p.z < ws.b[5];
+    flags[i] = keep ? 1u : 0u;
+    if (keep) {
+      cnt++;
+      const int a[3] = {f2ord(p.x), f2ord(p.y), f2ord(p.z)};
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        mn[k] = min(mn[k], a[k]);
+        mx[k] = max(mx[k], a[k]);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) flags[n] = 0u;  // the scan leaves the total here
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[k] = min(mn[k], __shfl_xor(mn[k], o, 64));
+      mx[k] = max(mx[k], __shfl_xor(mx[k], o, 64));
+    }
+  }
+  cnt = wave_sum_i(cnt);
+  __shared__ int part[4][7];
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      part[wave_id()][k] = mn[k];
+      part[wave_id()][3 + k] = mx[k];
+    }
+    part[wave_id()][6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int k = threadIdx.x;
+    int v = part[0][k];
+    for (int w = 1; w < 4; w++) {
+      const int o = part[w][k];
+      v = (k < 3) ? min(v, o) : (k < 6 ? max(v, o) : v + o);
+    }
+    if (k < 3) atomicMin(&ps->mn[k], v);
+    else if (k < 6) atomicMax(&ps->mx[k - 3], v);
+    else atomicAdd(&ps->n_keep, (unsigned)v);
+  }
+}
+
+// order-preserving compaction (cloud_camera.cpp:101-118); pref = exclusive prefix of the flags
+__global__ void k_pre_compact(const float4* __restrict__ raw, const float4* __restrict__ nrm,
+                              const unsigned* __restrict__ pref, int n, float4* __restrict__ dst,
+                              float4* __restrict__ nrm_dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned a = pref[i];
+  if (pref[i + 1] != a) {
+    dst[a] = raw[i];
+    if (nrm) nrm_dst[a] = nrm[i];
+  }
+}
+
+// cloud_camera.cpp:139 + floorVector :212-218, in float like Eigen evaluates it
+__device__ __forceinline__ long long vox_key(const float4& p, const VoxDesc& v) {
+  const int ix = (int)__builtin_floorf((p.x - v.mn[0]) / v.cell);
+  const int iy = (int)__builtin_floorf((p.y - v.mn[1]) / v.cell);
+  const int iz = (int)__builtin_floorf((p.z - v.mn[2]) / v.cell);
+  return ((long long)ix * v.dims[1] + iy) * v.dims[2] + iz;  // ascending == the set's comparator
+}
+
+__global__ void k_vox_mark(const float4* __restrict__ pts, int m, VoxDesc v,
+                           unsigned* __restrict__ bitmap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const long long key = vox_key(pts[i], v);
+  atomicOr(&bitmap[key >> 5], 1u << (key & 31));
+}
+
+__global__ void k_vox_popc(const unsigned* __restrict__ bitmap, int words,
+                           unsigned* __restrict__ wrank) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > words) return;
+  wrank[w] = (w < words) ? (unsigned)__popc(bitmap[w]) : 0u;
+}
+
+__device__ __forceinline__ unsigned vox_rank(long long key, const unsigned* __restrict__ bitmap,
+                                             const unsigned* __restrict__ wrank) {
+  const long long w = key >> 5;
+  const unsigned below = bitmap[w] & ((1u << (key & 31)) - 1u);
+  return wrank[w] + (unsigned)__popc(below);
+}
+
+// smallest point index per voxel = the point whose std::set insert succeeded (:140-141)
+__global__ void k_vox_first(const float4* __restrict__ pts, int m, VoxDesc v,
+                            const unsigned* __restrict__ bitmap,
+                            const unsigned* __restrict__ wrank, int* __restrict__ first) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  atomicMin(&first[vox_rank(vox_key(pts[i], v), bitmap, wrank)], i);
+}
+
+// voxel value = index * cell + min (:155-157), two float roundings; camera mask filled in later
+__global__ void k_vox_emit(const unsigned* __restrict__ bitmap, const unsigned* __restrict__ wrank,
+                           int words, VoxDesc v, float4* __restrict__ out) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= words) return;
+  unsigned bits = bitmap[w];
+  unsigned r = wrank[w];
+  const long long plane = (long long)v.dims[1] * v.dims[2];
+  while (bits) {
+    const int b = __ffs((int)bits) - 1;
+    bits &= bits - 1u;
+    const long long key = ((long long)w << 5) + b;
+    const int ix = (int)(key / plane);
+    const long long rem = key - (long long)ix * plane;
+    const int iy = (int)(rem / v.dims[2]);
+    const int iz = (int)(rem - (long long)iy * v.dims[2]);
+    out[r++] = make_float4((float)ix * v.cell + v.mn[0], (float)iy * v.cell + v.mn[1],
+                           (float)iz * v.cell + v.mn[2], __int_as_float(1));
+  }
+}
+
+__global__ void k_vox_firsthit_flags(const float4* __restrict__ pts, int m, VoxDesc v,
+                                     const unsigned* __restrict__ bitmap,
+                                     const unsigned* __restrict__ wrank,
+                                     const int* __restrict__ first, unsigned* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > m) return;
+  flags[i] = (i < m && first[vox_rank(vox_key(pts[i], v), bitmap, wrank)] == i) ? 1u : 0u;
+}
+
+// Literal reference indexing: idx_cam_source is filled in SCAN order (:140-141) but read with the
+// voxel's position in SET order (:149-152), so voxel k takes the mask of the k-th first-hit point.
+__global__ void k_vox_cam_literal(const float4* __restrict__ pts, int m,
+                                  const unsigned* __restrict__ pref, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const unsigned a = pref[i];
+  if (pref[i + 1] != a) out[a].w = pts[i].w;
+}
+// flags bit 0: the mask of the first point that hit the voxel
+__global__ void k_vox_cam_owner(const float4* __restrict__ pts, const int* __restrict__ first,
+                                int n_vox_max, const unsigned* __restrict__ n_vox,
+                                float4* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_vox_max || k >= (int)*n_vox) return;
+  out[k].w = pts[first[k]].w;
+}
+
+// ---- sub-sampling: radix select of the num_samples-th smallest (hash hi, hash lo, index) ---------
+__device__ __forceinline__ void sel_words(uint64_t seed, int i, unsigned W[3]) {
+  const uint64_t h = draw_u64(seed, kSubsampleStream, (uint64_t)i);
+  W[0] = (unsigned)(h >> 32);
+  W[1] = (unsigned)h;
+  W[2] = (unsigned)i;
+}
+
+__global__ void k_sel_init(PreStats* ps, unsigned k) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    ps->sel_prefix[0] = ps->sel_prefix[1] = ps->sel_prefix[2] = 0u;
+    ps->sel_remaining = k;
+  }
+}
+
+__global__ void k_sel_hist(int n, uint64_t seed, int digit, const PreStats* __restrict__ ps,
+                           unsigned* __restrict__ hist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned W[3];
+  sel_words(seed, i, W);
+  const int w = digit >> 1;
+  bool match = true;
+  for (int k = 0; k < w; k++) match = match && (W[k] == ps->sel_prefix[k]);
+  if (digit & 1) match = match && ((W[w] >> 16) == (ps->sel_prefix[w] >> 16));
+  if (match) atomicAdd(&hist[(W[w] >> ((digit & 1) ? 0 : 16)) & 0xFFFFu], 1u);
+}
+
+// one workgroup: find the bin where the running count reaches sel_remaining, extend the prefix,
+// clear the histogram for the next digit
+__global__ void __launch_bounds__(1024) k_sel_pick(unsigned* __restrict__ hist, int digit,
+                                                   PreStats* __restrict__ ps) {
+  __shared__ unsigned wsum[16];
+  const int t = threadIdx.x;
+  unsigned loc[64];
+  unsigned tot = 0;
+#pragma unroll
+  for (int k = 0; k < 64; k++) {
+    loc[k] = hist[t * 64 + k];
+    tot += loc[k];
+    hist[t * 64 + k] = 0u;
+  }
+  unsigned inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = (unsigned)__shfl_up((int)inc, o, 64);
+    if (lane_id() >= o) inc += v;
+  }
+  if (lane_id() == 63) wsum[wave_id()] = inc;
+  __syncthreads();
+  unsigned woff = 0;
+  for (int w = 0; w < wave_id(); w++) woff += wsum[w];
+  const unsigned before = woff + inc - tot;  // keys in bins below mine
+  const unsigned rem = ps->sel_remaining;
+  __syncthreads();                            // everyone has read sel_remaining
+  if (rem > before && rem <= before + tot) {
+    unsigned run = before;
+    for (int k = 0; k < 64; k++) {
+      if (rem <= run + loc[k]) {
+        const unsigned bin = (unsigned)(t * 64 + k);
+        ps->sel_prefix[digit >> 1] |= bin << ((digit & 1) ? 0 : 16);
+        ps->sel_remaining = rem - run;
+        break;
+      }
+      run += loc[k];
+    }
+  }
+}
+
+__global__ void k_sel_flags(int n, uint64_t seed, const PreStats* __restrict__ ps,
+                            unsigned* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  unsigned f = 0u;
+  if (i < n) {
+    unsigned W[3];
+    sel_words(seed, i, W);
+    const unsigned* T = ps->sel_prefix;
+    const bool le = (W[0] != T[0]) ? (W[0] < T[0]) : ((W[1] != T[1]) ? (W[1] < T[1]) : (W[2] <= T[2]));
+    f = le ? 1u : 0u;
+  }
+  flags[i] = f;
+}
+
+__global__ void k_sel_scatter(const unsigned* __restrict__ pref, int n, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned a = pref[i];
+  if (pref[i + 1] != a) out[a] = i;
+}
+
+__global__ void k_iota(int n, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+
+// d_raw (and d_raw_nrm when have_nrm) hold n points
+static int preprocess_resident(ag2_ctx* c, size_t n, bool have_cam, bool have_nrm,
+                               int filter_workspace, int voxelize, double voxel_size, int flags,
+                               size_t* n_out) {
+  if (voxelize && have_nrm)
+    return set_err(c, AG2_ERR_ARG, "normals do not survive voxelisation (cloud_camera.cpp:124-168)");
+  if (voxelize && !((float)voxel_size > 0.f)) return set_err(c, AG2_ERR_ARG, "voxel_size must be positive");
+  c->has_cloud = c->has_normals = false;
+  AG2_HIP(c, hipEventRecord(c->ev[14], c->stream));
+  auto finish = [&](size_t m) -> int {
+    c->n = m;
+    if (n_out) *n_out = m;
+    AG2_HIP(c, hipEventRecord(c->ev[15], c->stream));
+    int rc = after_cloud(c);
+    if (rc) return rc;
+    if (have_nrm && c->n_valid) {  // d_tmp holds the survivors' normals in cloud order
+      rc = gather_normals(c);
+      if (rc) return rc;
+      c->has_normals = true;
+    }
+    AG2_HIP(c, hipEventSynchronize(c->ev[15]));
+    (void)hipEventElapsedTime(&c->times.preprocess_ms, c->ev[14], c->ev[15]);
+    return 0;
+  };
+  AG2_HIP(c, c->d_xyz_in.reserve(std::max<size_t>(n, 1) * 16));
+  if (n == 0) return finish(0);
+  AG2_HIP(c, c->d_prestats.reserve(sizeof(PreStats)));
+  AG2_HIP(c, c->d_pflags.reserve((n + 1) * 4));
+  if (voxelize) AG2_HIP(c, c->d_pre.reserve(n * 16));
+  if (have_nrm) AG2_HIP(c, c->d_tmp.reserve(n * 16));
+  PreStats* ps = c->d_prestats.as<PreStats>();
+  unsigned* pf = c->d_pflags.as<unsigned>();
+  const float4* raw = c->d_raw.as<float4>();
+  float4* kept = voxelize ? c->d_pre.as<float4>() : c->d_xyz_in.as<float4>();
+  WsBox ws;
+  for (int k = 0; k < 6; k++) ws.b[k] = c->p.workspace[k];
+  const int ni = (int)n, g256 = (ni + 255) / 256;
+  hipLaunchKernelGGL(k_pre_init, dim3(1), dim3(64), 0, c->stream, ps);
+  hipLaunchKernelGGL(k_pre_flag_bounds, dim3(std::min(g256, 1024)), dim3(256), 0, c->stream, raw, ni,
+                     ws, filter_workspace ? 1 : 0, pf, ps);
+  int rc = scan_exclusive_u32(c, pf, ni + 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pre_compact, dim3(g256), dim3(256), 0, c->stream, raw,
+                     have_nrm ? c->d_raw_nrm.as<float4>() : (const float4*)nullptr, pf, ni, kept,
+                     have_nrm ? c->d_tmp.as<float4>() : (float4*)nullptr);
+  PreStats hs;
+  AG2_HIP(c, hipMemcpyAsync(&hs, ps, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  const size_t m = hs.n_keep;
+  if (!voxelize || m == 0) return finish(m);
+
+  VoxDesc v{};
+  v.cell = (float)voxel_size;
+  long long ncells = 1;
+  for (int a = 0; a < 3; a++) {
+    v.mn[a] = ord2f(hs.mn[a]);
+    const float mx = ord2f(hs.mx[a]);
+    const float top = floorf((mx - v.mn[a]) / v.cell);  // same expression as vox_key
+    if (!(top < 2.0e6f)) return set_err(c, AG2_ERR_CAPACITY, "voxel grid too fine for the cloud extent");
+    v.dims[a] = (int)top + 1;
+    ncells *= v.dims[a];
+    if (ncells > (1ll << 33)) return set_err(c, AG2_ERR_CAPACITY, "voxel grid has more than 2^33 cells");
+  }
+  const int words = (int)((ncells + 31) >> 5);
+  const int mi = (int)m, gm = (mi + 255) / 256, gw = (words + 256) / 256;
+  AG2_HIP(c, c->d_bitmap.reserve((size_t)words * 4));
+  AG2_HIP(c, c->d_wrank.reserve(((size_t)words + 1) * 4));
+  unsigned* bitmap = c->d_bitmap.as<unsigned>();
+  unsigned* wrank = c->d_wrank.as<unsigned>();
+  float4* out = c->d_xyz_in.as<float4>();
+  AG2_HIP(c, hipMemsetAsync(bitmap, 0, (size_t)words * 4, c->stream));
+  hipLaunchKernelGGL(k_vox_mark, dim3(gm), dim3(256), 0, c->stream, kept, mi, v, bitmap);
+  hipLaunchKernelGGL(k_vox_popc, dim3(gw), dim3(256), 0, c->stream, bitmap, words, wrank);
+  rc = scan_exclusive_u32(c, wrank, words + 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_vox_emit, dim3(gw), dim3(256), 0, c->stream, bitmap, wrank, words, v, out);
+  if (have_cam) {
+    AG2_HIP(c, c->d_first.reserve(m * 4));
+    int* first = c->d_first.as<int>();
+    AG2_HIP(c, hipMemsetAsync(first, 0x7f, m * 4, c->stream));
+    hipLaunchKernelGGL(k_vox_first, dim3(gm), dim3(256), 0, c->stream, kept, mi, v, bitmap, wrank, first);
+    if (flags & 1) {
+      hipLaunchKernelGGL(k_vox_cam_owner, dim3(gm), dim3(256), 0, c->stream, kept, first, mi,
+                         wrank + words, out);
+    } else {
+      hipLaunchKernelGGL(k_vox_firsthit_flags, dim3((mi + 256) / 256), dim3(256), 0, c->stream, kept, mi,
+                         v, bitmap, wrank, first, pf);
+      rc = scan_exclusive_u32(c, pf, mi + 1);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_vox_cam_literal, dim3(gm), dim3(256), 0, c->stream, kept, mi, pf, out);
+    }
+  }
+  AG2_HIP(c, hipGetLastError());
+  unsigned n_vox = 0;
+  AG2_HIP(c, hipMemcpyAsync(&n_vox, wrank + words, 4, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  return finish(n_vox);
+}
+
+}  // namespace ag2
+
+using namespace ag2;
+
+extern "C" {
+
+int ag2_preprocess_cloud(ag2_ctx* c, const float* xyz, size_t n, size_t stride_bytes,
+                         const int32_t* cam_source, int n_cams, const double* normals,
+                         int filter_workspace, int voxelize, double voxel_size, int flags,
+                         size_t* n_out) {
+  if (!c) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (n_cams != c->p.n_cams) return set_err(c, AG2_ERR_ARG, "n_cams differs from ag2_params.n_cams");
+  if (stride_bytes < 12 || stride_bytes % 4 != 0) return set_err(c, AG2_ERR_ARG, "bad stride");
+  if (n > 0 && !xyz) return set_err(c, AG2_ERR_ARG, "xyz is NULL");
+  if (n > (size_t)1 << 30) return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 points");
+  std::vector<float> pack(n * 4);
+  const char* base = (const char*)xyz;
+  for (size_t i = 0; i < n; i++) {
+    const float* pt = (const float*)(base + i * stride_bytes);
+    int mask = 0;
+    for (int cam = 0; cam < n_cams; cam++) {
+      const int v = cam_source ? cam_source[i * (size_t)n_cams + cam] : 1;  // cloud_camera.cpp:59
+      if (v == 1) mask |= (1 << cam);
+    }
+    pack[4 * i] = pt[0];
+    pack[4 * i + 1] = pt[1];
+    pack[4 * i + 2] = pt[2];
+    __builtin_memcpy(&pack[4 * i + 3], &mask, 4);
+  }
+  AG2_HIP(c, c->d_raw.reserve(std::max<size_t>(n, 1) * 16));
+  if (n) AG2_HIP(c, hipMemcpyAsync(c->d_raw.p, pack.data(), n * 16, hipMemcpyHostToDevice, c->stream));
+  std::vector<float> nf;
+  if (normals && n) {  // cloud_camera.cpp:27-31: float PointNormal fields
+    nf.assign(n * 4, 0.f);
+    for (size_t i = 0; i < n; i++) {
+      nf[4 * i] = (float)normals[3 * i];
+      nf[4 * i + 1] = (float)normals[3 * i + 1];
+      nf[4 * i + 2] = (float)normals[3 * i + 2];
+    }
+    AG2_HIP(c, c->d_raw_nrm.reserve(n * 16));
+    AG2_HIP(c, hipMemcpyAsync(c->d_raw_nrm.p, nf.data(), n * 16, hipMemcpyHostToDevice, c->stream));
+  }
+  AG2_HIP(c, hipStreamSynchronize(c->stream));  // staging vectors go out of scope
+  // without explicit masks every voxel gets the one-camera mask 1 that k_vox_emit writes
+  return preprocess_resident(c, n, cam_source != nullptr || n_cams > 1, normals != nullptr && n > 0,
+                             filter_workspace, voxelize, voxel_size, flags, n_out);
+}
+
+int ag2_preprocess_cloud_device(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes,
+                                int filter_workspace, int voxelize, double voxel_size,
+                                size_t* n_out) {
+  if (!c) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (c->p.n_cams != 1) return set_err(c, AG2_ERR_ARG, "device clouds are single-camera");
+  if (stride_bytes < 12 || stride_bytes % 4 != 0) return set_err(c, AG2_ERR_ARG, "bad stride");
+  if (n > 0 && !d_xyz) return set_err(c, AG2_ERR_ARG, "d_xyz is NULL");
+  if (n > (size_t)1 << 30) return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 points");
+  AG2_HIP(c, c->d_raw.reserve(std::max<size_t>(n, 1) * 16));
+  if (n) {
+    const int rc = pack_device_xyz(c, d_xyz, n, stride_bytes, c->d_raw.as<float4>());
+    if (rc) return rc;
+  }
+  return preprocess_resident(c, n, false, false, filter_workspace, voxelize, voxel_size, 0, n_out);
+}
+
+int ag2_get_cloud(ag2_ctx* c, float* xyz_nx3, int32_t* cam_source, size_t cap, size_t* n) {
+  if (!c || !n) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (!c->has_cloud) return set_err(c, AG2_ERR_STATE, "no cloud set");
+  *n = c->n;
+  if (cap < c->n) return set_err(c, AG2_ERR_CAPACITY, "cloud buffer too small");
+  if (c->n == 0) return 0;
+  std::vector<float> pack(c->n * 4);
+  AG2_HIP(c, hipMemcpyAsync(pack.data(), c->d_xyz_in.p, c->n * 16, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  const int n_cams = c->p.n_cams;
+  for (size_t i = 0; i < c->n; i++) {
+    if (xyz_nx3) {
+      xyz_nx3[3 * i] = pack[4 * i];
+      xyz_nx3[3 * i + 1] = pack[4 * i + 1];
+      xyz_nx3[3 * i + 2] = pack[4 * i + 2];
+    }
+    if (cam_source) {
+      int mask;
+      __builtin_memcpy(&mask, &pack[4 * i + 3], 4);
+      for (int cam = 0; cam < n_cams; cam++) cam_source[i * (size_t)n_cams + cam] = (mask >> cam) & 1;
+    }
+  }
+  return 0;
+}
+
+int ag2_subsample_uniformly(ag2_ctx* c, size_t num_samples, uint64_t seed, int32_t* idx_out,
+                            size_t cap, size_t* n_out) {
+  if (!c || !n_out) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (!c->has_cloud) return set_err(c, AG2_ERR_STATE, "no cloud set");
+  const size_t n = c->n, k = std::min(num_samples, n);  // grasp_detector.cpp:321-335
+  *n_out = k;
+  c->n_resident_samples = 0;
+  if (idx_out && cap < k) return set_err(c, AG2_ERR_CAPACITY, "sample buffer too small");
+  if (k == 0) return 0;
+  AG2_HIP(c, c->d_samples.reserve(k * 4));
+  int* out = c->d_samples.as<int>();
+  const int ni = (int)n, g256 = (ni + 255) / 256;
+  if (k == n) {
+    hipLaunchKernelGGL(k_iota, dim3(g256), dim3(256), 0, c->stream, ni, out);
+  } else {
+    AG2_HIP(c, c->d_prestats.reserve(sizeof(PreStats)));
+    AG2_HIP(c, c->d_hist.reserve(65536 * 4));
+    AG2_HIP(c, c->d_pflags.reserve((n + 1) * 4));
+    PreStats* ps = c->d_prestats.as<PreStats>();
+    unsigned* hist = c->d_hist.as<unsigned>();
+    unsigned* pf = c->d_pflags.as<unsigned>();
+    AG2_HIP(c, hipMemsetAsync(hist, 0, 65536 * 4, c->stream));
+    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, c->stream, ps, (unsigned)k);
+    for (int digit = 0; digit < 6; digit++) {
+      hipLaunchKernelGGL(k_sel_hist, dim3(g256), dim3(256), 0, c->stream, ni, seed, digit, ps, hist);
+      hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(1024), 0, c->stream, hist, digit, ps);
+    }
+    hipLaunchKernelGGL(k_sel_flags, dim3((ni + 256) / 256), dim3(256), 0, c->stream, ni, seed, ps, pf);
+    const int rc = scan_exclusive_u32(c, pf, ni + 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sel_scatter, dim3(g256), dim3(256), 0, c->stream, pf, ni, out);
+  }
+  AG2_HIP(c, hipGetLastError());
+  if (idx_out) {
+    AG2_HIP(c, hipMemcpyAsync(idx_out, out, k * 4, hipMemcpyDeviceToHost, c->stream));
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  c->n_resident_samples = k;
+  return 0;
+}
+
+}  // extern "C"

@@ -17,10 +17,14 @@
 
 namespace ag2 {
 
-constexpr int kSweepThreads = 256;
+// 512 threads per workgroup (8 waves, two workgroups per CU => 4 waves per SIMD) measured 3-4 %
+// faster than 256 on cfg2 despite ~75 spilled VGPRs at the 128-register cap: the sweep is
+// latency-bound (SQ_WAIT_ANY ~ 52 % of wave cycles), so the extra waves pay.
+#ifndef AG2_SWEEP_THREADS
+#define AG2_SWEEP_THREADS 512
+#endif
+constexpr int kSweepThreads = AG2_SWEEP_THREADS;  // 256 or 512 (tuning knob)
 constexpr int kSweepWaves = kSweepThreads / kWave;
-constexpr int kLdsCap = 3648;  // cropped points resident in LDS (16 B each); larger samples take
-                               // the global-scratch instantiation of the same kernel
 
 // ---------------------------------------------------------------------------------------------
 // sample queries: (x, y, z, valid) per sample
@@ -280,8 +284,8 @@ struct Red {
 };
 
 constexpr int kMaxPieces = 1024;
-constexpr int kRowsPerThread = kMaxRows / kSweepThreads;
-constexpr int kPiecesPerThread = kMaxPieces / kSweepThreads;
+constexpr int kRowsPerThread = (kMaxRows + kSweepThreads - 1) / kSweepThreads;
+constexpr int kPiecesPerThread = (kMaxPieces + kSweepThreads - 1) / kSweepThreads;
 
 struct SweepShared {
   int row_start[kMaxRows];       // per stencil row (cy, cz): first sorted position, length
@@ -299,13 +303,15 @@ struct SweepShared {
   int flag;
 };
 
-// two workgroups per CU: 2 x (control block + LDS-staged cropped list) must fit 160 KiB
-static_assert(((sizeof(SweepShared) + 15) & ~size_t(15)) + (size_t)kLdsCap * 18 <= 81920,
-              "k_sweep<true> no longer fits two workgroups per CU");
+// Cropped points resident in LDS (16 B + a 2-B in-box index each): whatever two workgroups per CU
+// leave after the control block (2 x 80 KiB = 160 KiB).  Larger samples take the global-scratch
+// instantiation of the same kernel.
+constexpr int kLdsCap = (int)(((81920 - ((sizeof(SweepShared) + 15) & ~size_t(15))) / 18) & ~size_t(31));
+static_assert(kLdsCap >= 2048 && kLdsCap <= 65536, "unexpected LDS stage size");
 
 // RMAX: compile-time bound on num_orientations (8, 16 or 32) for the per-orientation registers
 template <bool LDS_STORE, int RMAX>
-__global__ void __launch_bounds__(kSweepThreads) k_sweep(SweepArgs A) {
+__global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_sweep(SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SweepShared& S = *reinterpret_cast<SweepShared*>(smem_raw);
   const int CAP = LDS_STORE ? kLdsCap : A.gcap;
@@ -1060,14 +1066,17 @@ int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
   AG2_HIP(c, c->d_frame_ok.reserve(std::max<size_t>(s, 1) * 4));
   if (s == 0) return 0;
   AG2_HIP(c, hipMemsetAsync(c->d_frame_ok.p, 0, s * 4, c->stream));
-  if (sample_idx) {
-    AG2_HIP(c, c->d_tmp.reserve(s * 4));
-    AG2_HIP(c, hipMemcpyAsync(c->d_tmp.p, sample_idx, s * 4, hipMemcpyHostToDevice, c->stream));
+  if (sample_idx || !sample_xyz) {
+    const int* d_idx = c->d_samples.as<int>();  // left by ag2_subsample_uniformly
+    if (sample_idx) {
+      AG2_HIP(c, c->d_tmp.reserve(s * 4));
+      AG2_HIP(c, hipMemcpyAsync(c->d_tmp.p, sample_idx, s * 4, hipMemcpyHostToDevice, c->stream));
+      d_idx = c->d_tmp.as<int>();  // consumed before d_tmp can be reused: same stream
+    }
     hipLaunchKernelGGL(k_sample_queries_idx, dim3(((unsigned)s + 255) / 256), dim3(256), 0, c->stream,
-                       c->d_tmp.as<int>(), (int)s, c->d_xyz_in.as<float4>(), (int)c->n,
+                       d_idx, (int)s, c->d_xyz_in.as<float4>(), (int)c->n,
                        c->d_sample_q.as<float4>());
     AG2_HIP(c, hipGetLastError());
-    // the index buffer is consumed before d_tmp can be reused: same stream
   } else {
     std::vector<float> q(s * 4);
     for (size_t i = 0; i < s; i++) {

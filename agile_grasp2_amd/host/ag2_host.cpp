@@ -66,6 +66,17 @@ Matrix4d Matrix4d::inverse() const {  // Gauss-Jordan with partial pivoting
 }
 
 namespace {
+// the library's counter-based draw (csrc/ag2_device.h draw_u64), for the host twins of GPU steps
+uint64_t draw_u64(uint64_t seed, uint64_t slot, uint64_t j) {
+  uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (slot + 1ull));
+  x += 0xD1B54A32D192ED03ull * (j + 1ull);
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
 uint64_t splitmix(uint64_t& s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -170,6 +181,11 @@ void CloudCamera::voxelizeCloud(double cell_size) {
                                   (int)std::floor((p.z - mn[2]) / cell)};
     bins.insert(std::make_pair(v, (int)i));  // keeps the first point that hit the voxel
   }
+  // :140-141 pushes the first-hit indices in scan order, :149-152 reads them by position in set order
+  std::vector<int> idx_cam_source;
+  idx_cam_source.reserve(bins.size());
+  for (const auto& kv : bins) idx_cam_source.push_back(kv.second);
+  std::sort(idx_cam_source.begin(), idx_cam_source.end());
   PointCloudRGB::Ptr cloud(new PointCloudRGB);
   cloud->points.resize(bins.size());
   MatrixXi src(camera_source_.rows(), (int)bins.size());
@@ -179,7 +195,8 @@ void CloudCamera::voxelizeCloud(double cell_size) {
     d.x = (float)kv.first[0] * cell + mn[0];
     d.y = (float)kv.first[1] * cell + mn[1];
     d.z = (float)kv.first[2] * cell + mn[2];
-    for (int c = 0; c < camera_source_.rows(); c++) src(c, i) = (camera_source_(c, kv.second) == 1) ? 1 : 0;
+    for (int c = 0; c < camera_source_.rows(); c++)
+      src(c, i) = (camera_source_(c, idx_cam_source[i]) == 1) ? 1 : 0;
     i++;
   }
   cloud_processed_ = cloud;
@@ -190,16 +207,24 @@ void CloudCamera::voxelizeCloud(double cell_size) {
 void CloudCamera::subsampleUniformly(int num_samples, uint64_t seed) {
   const int n = (int)cloud_processed_->size();
   const int k = std::min(num_samples, n);
-  std::vector<int> idx(n);
-  for (int i = 0; i < n; i++) idx[i] = i;
-  uint64_t s = seed ^ 0xA5A5A5A5DEADBEEFull;
-  for (int i = 0; i < k; i++) {  // partial Fisher-Yates
-    const int j = i + (int)(splitmix(s) % (uint64_t)(n - i));
-    std::swap(idx[i], idx[j]);
+  std::vector<int> idx(k);
+  if (k == n) {
+    for (int i = 0; i < n; i++) idx[i] = i;
+  } else {  // the k smallest keys (draw(seed, i), i): same draw as ag2_subsample_uniformly
+    std::vector<std::pair<uint64_t, int>> keys(n);
+    for (int i = 0; i < n; i++) keys[i] = std::make_pair(draw_u64(seed, 0xFFFFFFFFFFFFFFF0ull, (uint64_t)i), i);
+    std::nth_element(keys.begin(), keys.begin() + k, keys.end());
+    for (int i = 0; i < k; i++) idx[i] = keys[i].second;
+    std::sort(idx.begin(), idx.end());  // pcl::RandomSample returns ascending indices
   }
-  idx.resize(k);
-  std::sort(idx.begin(), idx.end());  // pcl::RandomSample returns ascending indices
   sample_indices_ = idx;
+}
+
+void CloudCamera::adoptProcessed(const PointCloudRGB::Ptr& cloud, const MatrixXi& camera_source,
+                                 const Matrix3Xd& normals) {
+  cloud_processed_ = cloud;
+  camera_source_ = camera_source;
+  normals_ = normals;
 }
 
 void CloudCamera::subsampleSamples(const agile_grasp2::SamplesMsg& msg, int num_samples, uint64_t seed) {
@@ -706,6 +731,7 @@ std::shared_ptr<ag2::Context> GraspDetector::contextFor(int n_cams) {
   ap.num_selected = p_.num_selected;
   ctx_.reset(new ag2::Context(ap, p_.device));
   ctx_cams_ = n_cams;
+  resident_ctx_ = nullptr;
   if (!ctx_->ok()) {
     err_ = "could not create a GPU context (no CPU fallback)";
     ctx_.reset();
@@ -729,7 +755,16 @@ std::vector<GraspHypothesis> GraspDetector::detectGraspPoses(const CloudCamera& 
     return out;
   }
   ag2_ctx* c = ctx->get();
-  int rc = HandSearch::uploadCloud(c, cloud_cam);
+  int rc = 0;
+  if (c == resident_ctx_ && cloud_cam.getCloudProcessed().get() == resident_cloud_ &&
+      cloud_cam.getCloudProcessed()->size() == resident_n_) {
+    // preprocessPointCloud left exactly this cloud (and its grid) in the context
+    if (!resident_normals_) rc = ag2_compute_normals(c);  // hand_search.cpp:20-29
+    resident_normals_ = true;
+  } else {
+    resident_ctx_ = nullptr;
+    rc = HandSearch::uploadCloud(c, cloud_cam);
+  }
   const bool use_samples = use_incoming_samples_;
   const size_t s = use_samples ? (size_t)cloud_cam.getSamples().cols() : cloud_cam.getSampleIndices().size();
   std::vector<int32_t> idx(cloud_cam.getSampleIndices().begin(), cloud_cam.getSampleIndices().end());
@@ -781,10 +816,58 @@ std::vector<GraspHypothesis> GraspDetector::detectGraspPoses(const CloudCamera& 
   return out;
 }
 
+// Steps 1-2 (+ the uniform draw of step 3) on the GPU through ag2_preprocess_cloud; the processed
+// cloud is read back into cloud_cam (getCloudProcessed / getCameraSource keep their meaning) and
+// stays resident in the context for the detectGraspPoses call that follows.
+bool GraspDetector::preprocessOnDevice(CloudCamera& cloud_cam) {
+  const int n_cams = std::max(1, cloud_cam.getCameraSource().rows());
+  std::shared_ptr<ag2::Context> ctx = contextFor(n_cams);
+  if (!ctx) {
+    fprintf(stderr, "GraspDetector::preprocessPointCloud: %s\n", err_.c_str());
+    return false;
+  }
+  ag2_ctx* c = ctx->get();
+  const PointCloudRGB::Ptr& raw = cloud_cam.getCloudProcessed();
+  const size_t n = raw->size();
+  const MatrixXi& src = cloud_cam.getCameraSource();
+  const Matrix3Xd& nrm = cloud_cam.getNormals();
+  const bool carry_normals = !p_.voxelize && n > 0 && (size_t)nrm.cols() == n;
+  size_t m = 0;
+  int rc = ag2_preprocess_cloud(c, n ? &raw->points[0].x : nullptr, n, sizeof(ag2::PointXYZRGBA),
+                                src.cols() == (int)n && n ? src.data() : nullptr, n_cams,
+                                carry_normals ? nrm.data() : nullptr, p_.workspace.size() >= 6 ? 1 : 0,
+                                p_.voxelize ? 1 : 0, voxel_size_, 0, &m);
+  std::vector<float> xyz(3 * std::max<size_t>(m, 1));
+  MatrixXi cam(n_cams, (int)m);
+  if (!rc) rc = ag2_get_cloud(c, xyz.data(), m ? cam.data() : nullptr, m, &m);
+  Matrix3Xd out_n;
+  if (!rc && carry_normals && m) {
+    out_n.resize(3, (int)m);
+    rc = ag2_get_normals(c, out_n.data());
+  }
+  if (rc) {
+    err_ = ag2_last_error(c);
+    fprintf(stderr, "GraspDetector::preprocessPointCloud: %s\n", err_.c_str());
+    return false;
+  }
+  PointCloudRGB::Ptr cloud(new PointCloudRGB);
+  cloud->points.resize(m);
+  for (size_t i = 0; i < m; i++) {
+    cloud->points[i].x = xyz[3 * i];
+    cloud->points[i].y = xyz[3 * i + 1];
+    cloud->points[i].z = xyz[3 * i + 2];
+  }
+  cloud_cam.adoptProcessed(cloud, cam, out_n);
+  resident_cloud_ = cloud.get();
+  resident_n_ = m;
+  resident_ctx_ = c;
+  resident_normals_ = carry_normals && m;
+  return true;
+}
+
 void GraspDetector::preprocessPointCloud(CloudCamera& cloud_cam) {
   if (indices_.empty()) {
-    if (p_.workspace.size() >= 6) cloud_cam.filterWorkspace(p_.workspace);   // 1. :292-296
-    if (p_.voxelize) cloud_cam.voxelizeCloud(voxel_size_);                   // 2. :299-303
+    if (!preprocessOnDevice(cloud_cam)) return;  // 1.-2. :292-303; no host fallback: the error is printed
     const int n = (int)cloud_cam.getCloudProcessed()->size();
     if (use_incoming_samples_) {                                             // 3. :306-321
       agile_grasp2::SamplesMsg filtered;
@@ -799,7 +882,15 @@ void GraspDetector::preprocessPointCloud(CloudCamera& cloud_cam) {
       for (int i = 0; i < n; i++) all[i] = i;
       cloud_cam.setSampleIndices(all);
     } else {
-      cloud_cam.subsampleUniformly(num_samples_, p_.seed);                   // :331-335
+      std::vector<int32_t> idx((size_t)std::max(num_samples_, 1));           // :331-335, drawn on the GPU
+      size_t k = 0;
+      ag2_ctx* c = const_cast<ag2_ctx*>(resident_ctx_);
+      if (ag2_subsample_uniformly(c, (size_t)std::max(num_samples_, 0), p_.seed, idx.data(), idx.size(), &k)) {
+        err_ = ag2_last_error(c);
+        fprintf(stderr, "GraspDetector::preprocessPointCloud: %s\n", err_.c_str());
+        return;
+      }
+      cloud_cam.setSampleIndices(std::vector<int>(idx.begin(), idx.begin() + (long)k));
     }
   } else {
     if (num_samples_ != (int)indices_.size() && num_samples_ < (int)cloud_cam.getCloudOriginal()->size()) {

@@ -102,7 +102,7 @@ typedef struct ag2_times {
   float select_ms;      /* K6 score scatter, threshold compaction, record gather */
   float total_ms;       /* first to last event of the call */
   float sweep_overflow_ms; /* K3 k_sweep, global-scratch instantiation (oversized neighbourhoods) */
-  float reserved;
+  float preprocess_ms;  /* workspace filter + voxel grid (ag2_preprocess_cloud*), without the grid build */
 } ag2_times;
 
 int ag2_abi_version(void);
@@ -169,6 +169,39 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
  * (i * R + orientation), n_points == 0 where empty, score filled where scored.  Copied
  * device-to-device into d_dst (e.g. a torch tensor) for the RCCL all-gather. */
 int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes);
+
+/* ---- the step in front of the path: GraspDetector::preprocessPointCloud, grasp_detector.cpp:285-335 ----
+ * Steps 1-2 on the GPU: CloudCamera::filterWorkspace (cloud_camera.cpp:89-121; bounds =
+ * ag2_params.workspace, strict, order kept) and CloudCamera::voxelizeCloud (:124-168; voxel value =
+ * floor((p - min) / cell) * cell + min in float, output ascending in (ix, iy, iz)).  The result
+ * becomes the context's cloud exactly as if handed to ag2_set_cloud; *n_out = its size.  Arguments as
+ * ag2_set_cloud.  normals are carried through the filter; they cannot be combined with voxelize
+ * (the reference leaves normals_ untouched there).  Non-finite points are always dropped.
+ * flags bit 0: a voxel's camera source is that of the first point that hit it; default is the
+ * reference's literal indexing (:137-152: k-th voxel in set order <- k-th first-hit point in scan
+ * order), identical whenever all points carry the same mask.  The reference's linear indexing
+ * of the 2-camera matrix in filterWorkspace (:107) is a bug and is not reproduced. */
+#define AG2_PRE_OWNER_CAMERA_SOURCE 1
+int ag2_preprocess_cloud(ag2_ctx* c, const float* xyz, size_t n, size_t stride_bytes,
+                         const int32_t* cam_source, int n_cams, const double* normals,
+                         int filter_workspace, int voxelize, double voxel_size, int flags,
+                         size_t* n_out);
+/* Same with the raw cloud already in device memory (single camera, no normals). */
+int ag2_preprocess_cloud_device(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes,
+                                int filter_workspace, int voxelize, double voxel_size,
+                                size_t* n_out);
+/* CloudCamera::getCloudProcessed / getCameraSource: the context's current cloud, xyz n x 3 packed,
+ * cam_source n_cams x n column-major (either may be NULL). */
+int ag2_get_cloud(ag2_ctx* c, float* xyz_nx3, int32_t* cam_source, size_t cap, size_t* n);
+/* Step 3, CloudCamera::subsampleUniformly (cloud_camera.cpp:171-178, grasp_detector.cpp:321-335):
+ * min(num_samples, n) distinct indices into the current cloud, ascending.  The reference's
+ * pcl::RandomSample is seeded from wall time; here point i gets the key
+ * (draw(seed, i), i) and the num_samples smallest keys are taken.  The indices stay on the device:
+ * a following ag2_generate_hypotheses / ag2_detect with sample_idx == sample_xyz == NULL and
+ * s <= *n_out uses the first s of them.  idx_out may be NULL. */
+int ag2_subsample_uniformly(ag2_ctx* c, size_t num_samples, uint64_t seed, int32_t* idx_out,
+                            size_t cap, size_t* n_out);
+
 int ag2_get_counters(ag2_ctx* c, ag2_counters* out);
 int ag2_get_stage_times(ag2_ctx* c, ag2_times* out);
 

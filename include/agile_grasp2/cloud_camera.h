@@ -31,11 +31,18 @@ class CloudCamera {
   // reference's linear indexing of the 2-camera source matrix at :107 is a bug; fixed here.)
   void filterWorkspace(const std::vector<double>& workspace);
   // cloud_camera.cpp:124-168: voxel value = floor((p - min) / cell) * cell + min in float, output
-  // sorted lexicographically by (ix, iy, iz), camera source of the first point that hit the voxel.
+  // sorted lexicographically by (ix, iy, iz); camera source indexed as the reference does it
+  // (:137-152: k-th voxel in set order <- k-th first-hit point in scan order).
   void voxelizeCloud(double cell_size);
   // cloud_camera.cpp:171-178 (pcl::RandomSample): num_samples indices without replacement,
-  // ascending.  The reference seeds from wall time; here the seed is explicit.
+  // ascending.  The reference seeds from wall time; here the seed is explicit and the draw is the
+  // one ag2_subsample_uniformly makes (include/ag2_c.h).
   void subsampleUniformly(int num_samples, uint64_t seed = 0);
+  // Host-side twins of what GraspDetector::preprocessPointCloud runs on the GPU; results identical.
+  // Replace the processed cloud with what the GPU front end produced (mirror-only, used by
+  // GraspDetector::preprocessPointCloud).
+  void adoptProcessed(const PointCloudRGB::Ptr& cloud, const ag2::MatrixXi& camera_source,
+                      const ag2::Matrix3Xd& normals);
   // cloud_camera.cpp:181-206
   void subsampleSamples(const agile_grasp2::SamplesMsg& msg, int num_samples, uint64_t seed = 0);
 

@@ -94,6 +94,7 @@ class GraspDetector {
                                                            float min_x, float max_x, float min_y,
                                                            float max_y, float min_z);
   std::shared_ptr<ag2::Context> contextFor(int n_cams);
+  bool preprocessOnDevice(CloudCamera& cloud_cam);
   void cameraPoses(ag2::Matrix4d* left, ag2::Matrix4d* right) const;
 
   Params p_;
@@ -106,6 +107,11 @@ class GraspDetector {
   std::unique_ptr<Learning> learning_;
   std::shared_ptr<ag2::Context> ctx_;
   int ctx_cams_ = 0;
+  // cloud left in the context by preprocessPointCloud: detectGraspPoses does not upload it again
+  const void* resident_cloud_ = nullptr;
+  size_t resident_n_ = 0;
+  const ag2_ctx* resident_ctx_ = nullptr;
+  bool resident_normals_ = false;
   ag2_times times_{};
   ag2_counters counters_{};
   std::string err_;

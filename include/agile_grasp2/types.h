@@ -67,6 +67,7 @@ struct MatrixXi {
   int32_t& operator()(int row, int c) { return d[(size_t)c * r + row]; }
   int32_t operator()(int row, int c) const { return d[(size_t)c * r + row]; }
   const int32_t* data() const { return d.data(); }
+  int32_t* data() { return d.data(); }
 };
 
 // pcl::PointXYZRGBA: 32 bytes, xyz at offset 0 (what ag2_set_cloud's stride argument is for).

@@ -1093,4 +1093,131 @@ int ag2o_get_counters(ag2o_ctx* c, ag2o_counters* out) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Preprocessing: GraspDetector::preprocessPointCloud steps 1-3,
+// grasp_detector.cpp:285-335.
+// ------------------------------------------------------------------------------------------------
+int ag2o_preprocess_cloud(ag2o_ctx* c, const float* xyz, size_t n, size_t stride_bytes,
+                          const int32_t* cam_source, int n_cams, const double* normals,
+                          int filter_workspace, int voxelize, double voxel_size, int flags,
+                          size_t* n_out) {
+  if (!c) return -1;
+  if (n_cams < 1 || n_cams > 2) return fail(c, "n_cams must be 1 or 2");
+  if (stride_bytes < 12 || stride_bytes % 4 != 0) return fail(c, "bad stride");
+  if (voxelize && normals) return fail(c, "normals do not survive voxelisation");
+  if (voxelize && !((float)voxel_size > 0.f)) return fail(c, "voxel_size must be positive");
+  const char* base = (const char*)xyz;
+  const double* ws = c->p.workspace;
+  // 1. CloudCamera::filterWorkspace, cloud_camera.cpp:89-121: strict bounds, float coordinate
+  //    widened to double for the comparison, order kept.  Non-finite points fail every comparison;
+  //    they are dropped when the filter is off as well (no such path in the reference).  The
+  //    2-camera source matrix is copied column by column (the linear index at :107 is a bug).
+  std::vector<size_t> keep;
+  keep.reserve(n);
+  for (size_t i = 0; i < n; i++) {
+    const float* p = (const float*)(base + i * stride_bytes);
+    if (!finite3f(p[0], p[1], p[2])) continue;
+    if (filter_workspace &&
+        !((double)p[0] > ws[0] && (double)p[0] < ws[1] && (double)p[1] > ws[2] &&
+          (double)p[1] < ws[3] && (double)p[2] > ws[4] && (double)p[2] < ws[5]))
+      continue;
+    keep.push_back(i);
+  }
+  const size_t m = keep.size();
+  std::vector<float> px(3 * m);
+  std::vector<int32_t> cam(m * (size_t)n_cams, 1);
+  std::vector<double> nrm;
+  for (size_t k = 0; k < m; k++) {
+    const float* p = (const float*)(base + keep[k] * stride_bytes);
+    px[3 * k] = p[0]; px[3 * k + 1] = p[1]; px[3 * k + 2] = p[2];
+    if (cam_source)
+      for (int j = 0; j < n_cams; j++) cam[k * n_cams + j] = cam_source[keep[k] * n_cams + j];
+  }
+  if (normals) {
+    nrm.resize(3 * m);
+    for (size_t k = 0; k < m; k++)
+      for (int a = 0; a < 3; a++) nrm[3 * k + a] = normals[3 * keep[k] + a];
+  }
+  if (!voxelize || m == 0) {
+    if (n_out) *n_out = m;
+    return ag2o_set_cloud(c, px.data(), m, 12, cam.data(), n_cams, normals ? nrm.data() : nullptr);
+  }
+  // 2. CloudCamera::voxelizeCloud, cloud_camera.cpp:124-168.  All arithmetic in float: Eigen
+  //    converts the double cell_size to the vector's scalar type (:139, :155-157).
+  float mn[3] = {px[0], px[1], px[2]};
+  for (size_t k = 1; k < m; k++)
+    for (int a = 0; a < 3; a++) mn[a] = std::min(mn[a], px[3 * k + a]);  // :127-128
+  const float cell = (float)voxel_size;
+  struct Bin { int v[3]; size_t first; };
+  std::vector<Bin> bins(m);
+  for (size_t k = 0; k < m; k++) {
+    for (int a = 0; a < 3; a++) bins[k].v[a] = (int)std::floor((px[3 * k + a] - mn[a]) / cell);  // :139
+    bins[k].first = k;
+  }
+  // std::set with UniqueVectorComparator (cloud_camera.h:164-175) == ascending (ix, iy, iz); the
+  // index of the point whose insert succeeded is the smallest index in the voxel
+  std::sort(bins.begin(), bins.end(), [](const Bin& a, const Bin& b) {
+    for (int k = 0; k < 3; k++)
+      if (a.v[k] != b.v[k]) return a.v[k] < b.v[k];
+    return a.first < b.first;
+  });
+  size_t u = 0;
+  for (size_t k = 0; k < m; k++)
+    if (k == 0 || bins[k].v[0] != bins[u - 1].v[0] || bins[k].v[1] != bins[u - 1].v[1] ||
+        bins[k].v[2] != bins[u - 1].v[2])
+      bins[u++] = bins[k];
+  bins.resize(u);
+  // :137-141 pushes the first-hit indices in SCAN order, :149-152 reads entry i for the i-th voxel
+  // in SET order -- replicated literally (flags bit 0 selects "the first point that hit the voxel")
+  std::vector<size_t> scan_order(u);
+  for (size_t v = 0; v < u; v++) scan_order[v] = bins[v].first;
+  std::sort(scan_order.begin(), scan_order.end());
+  std::vector<float> vx(3 * u);
+  std::vector<int32_t> vcam(u * (size_t)n_cams);
+  for (size_t v = 0; v < u; v++) {
+    for (int a = 0; a < 3; a++) vx[3 * v + a] = (float)bins[v].v[a] * cell + mn[a];  // :155-157
+    const size_t src = (flags & 1) ? bins[v].first : scan_order[v];
+    for (int j = 0; j < n_cams; j++) vcam[v * n_cams + j] = (cam[src * n_cams + j] == 1) ? 1 : 0;
+  }
+  if (n_out) *n_out = u;
+  return ag2o_set_cloud(c, vx.data(), u, 12, vcam.data(), n_cams, nullptr);
+}
+
+int ag2o_get_cloud(ag2o_ctx* c, float* xyz_nx3, int32_t* cam_source, size_t cap, size_t* n) {
+  if (!c || !n) return -1;
+  *n = c->n;
+  if (cap < c->n) return fail(c, "get_cloud: capacity too small");
+  for (size_t i = 0; i < c->n; i++) {
+    if (xyz_nx3) { xyz_nx3[3 * i] = c->x[i]; xyz_nx3[3 * i + 1] = c->y[i]; xyz_nx3[3 * i + 2] = c->z[i]; }
+  }
+  // as the 0/1 "seen by camera" mask every consumer reduces it to (== 1: hand_search.cpp:139,
+  // cloud_camera.cpp:151)
+  if (cam_source)
+    for (size_t i = 0; i < c->cam.size(); i++) cam_source[i] = (c->cam[i] == 1) ? 1 : 0;
+  return 0;
+}
+
+// 3. CloudCamera::subsampleUniformly, cloud_camera.cpp:171-178 / grasp_detector.cpp:321-335:
+// min(num_samples, n) distinct indices, ascending (pcl::RandomSample's output order).  The
+// reference seeds from wall time, so only the distribution can be kept: every point gets the key
+// (draw_u64(seed, kSubsampleStream, i), i) and the num_samples smallest keys win -- a uniform
+// draw without replacement that needs no sequential state.
+int ag2o_subsample_uniformly(ag2o_ctx* c, size_t num_samples, uint64_t seed, int32_t* idx_out,
+                             size_t cap, size_t* n_out) {
+  if (!c || !n_out) return -1;
+  const size_t n = c->n, k = std::min(num_samples, n);
+  *n_out = k;
+  if (cap < k) return fail(c, "subsample: capacity too small");
+  if (k == n) {
+    for (size_t i = 0; i < n; i++) idx_out[i] = (int32_t)i;
+    return 0;
+  }
+  std::vector<std::pair<uint64_t, uint32_t>> keys(n);
+  for (size_t i = 0; i < n; i++) keys[i] = {draw_u64(seed, 0xFFFFFFFFFFFFFFF0ull, (uint64_t)i), (uint32_t)i};
+  std::nth_element(keys.begin(), keys.begin() + (long)k, keys.end());
+  for (size_t i = 0; i < k; i++) idx_out[i] = (int32_t)keys[i].second;
+  std::sort(idx_out, idx_out + k);
+  return 0;
+}
+
 }  // extern "C"

@@ -118,6 +118,21 @@ int ag2o_detect(ag2o_ctx* c, const int32_t* sample_idx, const double* sample_xyz
                 size_t* n_scored);
 int ag2o_get_counters(ag2o_ctx* c, ag2o_counters* out);
 
+/* Preprocessing in front of the path (GraspDetector::preprocessPointCloud, grasp_detector.cpp:285-335):
+ * CloudCamera::filterWorkspace (cloud_camera.cpp:89-121, bounds = params.workspace) and
+ * CloudCamera::voxelizeCloud (:124-168); the result becomes the context's cloud.  flags bit 0:
+ * a voxel's camera source comes from the first point that hit it (default: the literal
+ * reference indexing, :137-152). */
+int ag2o_preprocess_cloud(ag2o_ctx* c, const float* xyz, size_t n, size_t stride_bytes,
+                          const int32_t* cam_source, int n_cams, const double* normals,
+                          int filter_workspace, int voxelize, double voxel_size, int flags,
+                          size_t* n_out);
+/* current cloud: xyz n x 3 packed, cam_source n_cams x n column-major (either may be NULL) */
+int ag2o_get_cloud(ag2o_ctx* c, float* xyz_nx3, int32_t* cam_source, size_t cap, size_t* n);
+/* CloudCamera::subsampleUniformly (cloud_camera.cpp:171-178): min(num_samples, n) indices, ascending */
+int ag2o_subsample_uniformly(ag2o_ctx* c, size_t num_samples, uint64_t seed, int32_t* idx_out,
+                             size_t cap, size_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,6 +129,7 @@ class Oracle:
         assert xyz.ndim == 2 and xyz.shape[1] >= 3
         self.n = xyz.shape[0]
         ncam = 1
+        self.n_cams = 1 if cam_source is None else np.asarray(cam_source).shape[0]
         cs = None
         if cam_source is not None:
             cs = np.asarray(cam_source, dtype=np.int32)
@@ -140,6 +141,41 @@ class Oracle:
             assert nr.shape == (3, self.n)
         self._ck(self.L.ag2o_set_cloud(self.h, _ptr(xyz), C.c_size_t(self.n),
                                        C.c_size_t(xyz.strides[0]), _ptr(cs), C.c_int(ncam), _ptr(nr)))
+
+    def preprocess_cloud(self, xyz, cam_source=None, normals=None, filter_workspace=True,
+                         voxelize=True, voxel_size=0.003, flags=0):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n = xyz.shape[0]
+        ncam, cs, nr = 1, None, None
+        if cam_source is not None:
+            cs = np.asfortranarray(np.asarray(cam_source, dtype=np.int32))
+            ncam = cs.shape[0]
+        if normals is not None:
+            nr = np.asfortranarray(np.asarray(normals, dtype=np.float64))
+        m = C.c_size_t(0)
+        stride = xyz.strides[0] if n else 12
+        self._ck(self.L.ag2o_preprocess_cloud(
+            self.h, _ptr(xyz), C.c_size_t(n), C.c_size_t(stride), _ptr(cs), C.c_int(ncam), _ptr(nr),
+            C.c_int(int(filter_workspace)), C.c_int(int(voxelize)), C.c_double(voxel_size),
+            C.c_int(flags), C.byref(m)))
+        self.n = m.value
+        self.n_cams = ncam
+        return self.n
+
+    def get_cloud(self):
+        ncam = getattr(self, "n_cams", 1)
+        xyz = np.zeros((self.n, 3), dtype=np.float32)
+        cam = np.zeros((ncam, self.n), dtype=np.int32, order="F")
+        m = C.c_size_t(0)
+        self._ck(self.L.ag2o_get_cloud(self.h, _ptr(xyz), _ptr(cam), C.c_size_t(self.n), C.byref(m)))
+        return xyz, cam
+
+    def subsample_uniformly(self, num_samples, seed=0):
+        out = np.zeros(max(1, min(num_samples, self.n)), dtype=np.int32)
+        m = C.c_size_t(0)
+        self._ck(self.L.ag2o_subsample_uniformly(self.h, C.c_size_t(num_samples), C.c_uint64(seed),
+                                                 _ptr(out), C.c_size_t(out.shape[0]), C.byref(m)))
+        return out[: m.value].copy()
 
     def compute_normals(self):
         self._ck(self.L.ag2o_compute_normals(self.h))

@@ -34,9 +34,57 @@ static void put(std::ofstream& f, const T* p, size_t n) {
   f.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * sizeof(T)));
 }
 
+// test_host_api --preprocess <raw.f32> <params.txt> <out.bin>: the node's own sequence for a raw
+// cloud (grasp_detection_node.cpp:98-143): preprocessPointCloud -> detectGraspPoses.
+static int run_preprocess(const char* raw_path, const char* params_path, const char* out_path) {
+  const std::vector<float> xyz = read_all<float>(raw_path);
+  std::ifstream pf(params_path);
+  const std::string ptext((std::istreambuf_iterator<char>(pf)), std::istreambuf_iterator<char>());
+  GraspDetector::Params prm;
+  std::string err;
+  if (!GraspDetector::Params::fromKeyValueText(ptext, &prm, &err)) {
+    fprintf(stderr, "params: %s\n", err.c_str());
+    return 2;
+  }
+  PointCloudRGB::Ptr cloud(new PointCloudRGB);
+  cloud->points.resize(xyz.size() / 3);
+  for (size_t i = 0; i < cloud->size(); i++) {
+    cloud->points[i].x = xyz[3 * i];
+    cloud->points[i].y = xyz[3 * i + 1];
+    cloud->points[i].z = xyz[3 * i + 2];
+  }
+  CloudCamera cc(cloud, (int)cloud->size());
+  GraspDetector det(prm);
+  det.preprocessPointCloud(cc);
+  const std::vector<GraspHypothesis> sel = det.detectGraspPoses(cc);
+  std::ofstream out(out_path, std::ios::binary);
+  const int64_t m = (int64_t)cc.getCloudProcessed()->size(), k = (int64_t)cc.getSampleIndices().size(),
+                ns = (int64_t)sel.size();
+  put(out, &m, 1);
+  for (const ag2::PointXYZRGBA& p : cc.getCloudProcessed()->points) put(out, &p.x, 3);
+  put(out, &k, 1);
+  for (int i : cc.getSampleIndices()) {
+    const int32_t v = i;
+    put(out, &v, 1);
+  }
+  put(out, &ns, 1);
+  for (const GraspHypothesis& h : sel) {
+    const int32_t so[2] = {h.getSampleSlot(), h.getOrientation()};
+    const double sc = h.getScore();
+    put(out, so, 2);
+    put(out, &sc, 1);
+  }
+  printf("preprocess ok: %lld raw -> %lld points, %lld samples, %lld grasps, preprocess %.3f ms\n",
+         (long long)cloud->size(), (long long)m, (long long)k, (long long)ns,
+         (double)det.lastStageTimes().preprocess_ms);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 5 && std::string(argv[1]) == "--preprocess") return run_preprocess(argv[2], argv[3], argv[4]);
   if (argc != 5) {
-    fprintf(stderr, "usage: %s cloud.f32 idx.i32 params.txt out.bin\n", argv[0]);
+    fprintf(stderr, "usage: %s cloud.f32 idx.i32 params.txt out.bin | --preprocess raw.f32 params.txt out.bin\n",
+            argv[0]);
     return 2;
   }
   const std::vector<float> xyz = read_all<float>(argv[1]);

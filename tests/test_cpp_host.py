@@ -202,3 +202,56 @@ int main(int argc, char** argv) {
     open(kv, "w").write("no_such_parameter = 1\n")
     r = subprocess.run([exe, kv, "kv"], capture_output=True, text=True)
     assert r.returncode == 1 and "unknown parameter" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_preprocess_then_detect_matches_oracle(tmp_path):
+    """GraspDetector::preprocessPointCloud (GPU front end behind the reference's method name) followed
+    by detectGraspPoses on a raw cloud == oracle preprocess -> subsample -> detect."""
+    from oracle import api
+    tmp = str(tmp_path)
+    exe = build_driver(tmp)
+    raw, ws = scene.make_scene(seed=12, n_target=50000, voxel=None, spacing=0.0015)
+    w = make_lenet_weights(7)
+    wpath, lpath = os.path.join(tmp, "w.ag2w"), os.path.join(tmp, "labels.txt")
+    save_ag2w(wpath, w)
+    open(lpath, "w").write("0\n1\n")
+    raw.astype("<f4").tofile(os.path.join(tmp, "raw.f32"))
+    seed, ns_req = 5, 120
+    text = params_text(ws, wpath, lpath, seed) + f"num_samples = {ns_req}\nvoxelize = true\n"
+    open(os.path.join(tmp, "params.txt"), "w").write(text)
+    outp = os.path.join(tmp, "out.bin")
+    r = subprocess.run([exe, "--preprocess", os.path.join(tmp, "raw.f32"), os.path.join(tmp, "params.txt"), outp],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "preprocess ok" in r.stdout
+
+    o = api.Oracle(**scene_params(ws, min_score_diff=-1e30, num_selected=1000, num_threads=4))
+    m = o.preprocess_cloud(raw, voxel_size=0.003)
+    want_xyz, _ = o.get_cloud()
+    idx = o.subsample_uniformly(ns_req, seed=seed)
+    o.compute_normals()
+    o.lenet_load(w)
+    wsel, _ = o.detect(sample_idx=idx, seed=seed, do_prune=True)
+
+    buf = open(outp, "rb").read()
+    (gm,) = struct.unpack_from("<q", buf, 0)
+    off = 8
+    assert gm == m
+    xyz = np.frombuffer(buf, dtype="<f4", count=3 * gm, offset=off).reshape(gm, 3)
+    off += 12 * gm
+    assert xyz.tobytes() == want_xyz.tobytes()
+    (gk,) = struct.unpack_from("<q", buf, off)
+    off += 8
+    got_idx = np.frombuffer(buf, dtype="<i4", count=gk, offset=off)
+    off += 4 * gk
+    assert np.array_equal(got_idx, idx)
+    (gs,) = struct.unpack_from("<q", buf, off)
+    off += 8
+    assert gs == len(wsel) and gs > 0
+    rec = np.frombuffer(buf, dtype=np.dtype([("slot", "<i4"), ("orient", "<i4"), ("score", "<f8")]), count=gs, offset=off)
+    key = {(int(h["sample_slot"]), int(h["orientation"])): float(h["score"]) for h in wsel}
+    assert sorted(zip(rec["slot"].tolist(), rec["orient"].tolist())) == sorted(key)
+    tol = 1e-4 * max(abs(v) for v in key.values()) + 2e-3
+    for s, q, sc in zip(rec["slot"].tolist(), rec["orient"].tolist(), rec["score"].tolist()):
+        assert abs(sc - key[(s, q)]) <= tol
