@@ -272,6 +272,52 @@ def main():
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu:
+        # Untimed side legs (never `value`):
+        # (1) the same step with the cloud handed over in HOST memory (PCIe-inclusive rate);
+        def timed(fn, reps=10):
+            fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            tot = 0
+            for _ in range(reps):
+                tot += fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / reps, tot / reps
+
+        def host_step():
+            d.set_cloud(xyz)
+            d.compute_normals()
+            return d.detect(sample_idx=idx, seed=args.seed, do_prune=True, want_all=False)[1]
+
+        dt, sc = timed(host_step)
+        out["pcie_inclusive"] = {"value": sc / dt, "unit": "hypotheses/s", "ms_per_step": dt * 1e3,
+                                 "note": f"cloud ({xyz.nbytes / 1e6:.1f} MB) uploaded from pageable host memory every step"}
+        # (2) the step with the GPU front end in front of it: raw (un-voxelised) cloud resident in
+        # HBM -> workspace filter + 3 mm voxel grid + uniform sub-sampling -> normals -> detect with
+        # the sample indices never leaving the device.
+        if voxelised:
+            raw, ws_raw = scene.make_scene(args.seed, int(2.55 * n_points), kind=kind, voxel=None, spacing=0.0015)
+            df = capi.Detector(device=local_rank, **launch_params(ws_raw, R))
+            df.set_stream(torch.cuda.current_stream().cuda_stream)
+            df.lenet_load(weights)
+            raw_dev = torch.from_numpy(raw).cuda()
+            torch.cuda.synchronize()
+            fe = {}
+
+            def front_step():
+                fe["n_vox"] = df.preprocess_cloud_device(raw_dev.data_ptr(), raw.shape[0], 12,
+                                                         voxel_size=scene.VOXEL)
+                ns = df.subsample_uniformly(S, seed=args.seed, want_indices=False)
+                df.compute_normals()
+                n_sc = df.detect(n_resident=ns, seed=args.seed, do_prune=True, want_all=False)[1]
+                fe["pre_ms"] = df.times().preprocess_ms
+                return n_sc
+
+            dt, sc = timed(front_step)
+            out["with_front_end"] = {"value": sc / dt, "unit": "hypotheses/s", "ms_per_step": dt * 1e3,
+                                     "raw_points": int(raw.shape[0]), "voxels": int(fe["n_vox"]),
+                                     "preprocess_ms": round(fe["pre_ms"], 4)}
+            df.close()
         out["cpu_baseline"] = cpu_baseline(xyz, ws, idx, R, weights)
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
