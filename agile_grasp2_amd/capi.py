@@ -22,6 +22,7 @@ SYMBOLS = [
     "ag2_lenet_load", "ag2_lenet_forward", "ag2_detect", "ag2_export_candidates_device",
     "ag2_get_counters", "ag2_get_stage_times",
     "ag2_preprocess_cloud", "ag2_preprocess_cloud_device", "ag2_get_cloud", "ag2_subsample_uniformly",
+    "ag2_find_clusters", "ag2_set_min_inliers",
 ]
 
 
@@ -315,6 +316,20 @@ class Detector:
                                    _ptr(allh) if want_all else None,
                                    C.c_size_t(cap if want_all else 0), C.byref(na)))
         return sel[: ns.value].copy(), (allh[: na.value].copy() if want_all else na.value)
+
+    def set_min_inliers(self, k: int):
+        """HandleSearch::setMinInliers: > 0 makes detect() cluster before the top-k."""
+        self._ck(self.L.ag2_set_min_inliers(self.h, C.c_int(k)))
+
+    def find_clusters(self, hands, min_inliers: int):
+        """HandleSearch::findClusters(hand_list) on the GPU; hands: HYP_DTYPE array."""
+        hands = np.ascontiguousarray(hands, dtype=HYP_DTYPE)
+        out = np.zeros(max(1, len(hands)), dtype=HYP_DTYPE)
+        n = C.c_size_t(0)
+        self._ck(self.L.ag2_find_clusters(self.h, _ptr(hands), C.c_size_t(len(hands)),
+                                          C.c_int(min_inliers), _ptr(out), C.c_size_t(len(out)),
+                                          C.byref(n)))
+        return out[: n.value].copy()
 
     def export_candidates_device(self, dptr: int, nbytes: int):
         self._ck(self.L.ag2_export_candidates_device(self.h, C.c_void_p(dptr), C.c_size_t(nbytes)))

@@ -42,7 +42,7 @@ struct DevStats {
   unsigned int err_flags;            // bit0 arena overflow, bit3 global sweep scratch overflow
   unsigned int n_list;               // hypotheses that go on to be scored (after the prune)
   unsigned int n_sel;                // scored hypotheses with score >= min_score_diff
-  unsigned int pad0;
+  unsigned int n_clu;                // selected hypotheses that survive the clustering
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
   unsigned int pad1;
@@ -141,6 +141,9 @@ struct ag2_ctx {
   ag2::DevBuf d_tmp;       // misc staging
   ag2::DevBuf d_flags;     // uint32 flags / prefix for slot compaction
   ag2::DevBuf d_desc;      // image descriptors: int64 arena offset[n] then int32 count[n]
+  ag2::DevBuf d_cluster;   // ag2_hypothesis: clustered hands, compacted (k_cluster.hip)
+  ag2::DevBuf d_cluster_tmp;  // ag2_hypothesis: moved hands before the compaction
+  int min_inliers = 0;     // HandleSearch::setMinInliers; 0 = no clustering inside ag2_detect
   std::vector<ag2_hypothesis> h_hyps;   // compacted hypotheses of the last generate call
   std::vector<int32_t> h_slots;         // their slot ids
   std::vector<int64_t> h_offsets;       // their arena offsets
@@ -183,6 +186,9 @@ int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned
 int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypothesis>& recs,
                    std::vector<int64_t>* offs, std::vector<uint8_t>* keep);
 int make_image_descs(ag2_ctx* c, const int* d_list, size_t n);
+// k_cluster.hip
+int cluster_async(ag2_ctx* c, const ag2_hypothesis* d_in, size_t n_max, const unsigned* d_n,
+                  int min_inliers, unsigned* d_count);
 int launch_scatter_scores(ag2_ctx* c, const int* d_list, size_t n_img);
 // k_image.hip
 int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, const int* d_cnt,

@@ -295,6 +295,16 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   unsigned* d_nsel = &c->d_stats.as<DevStats>()->n_sel;
   rc = score_and_select_async(c, c->d_list2.as<int>(), n_img, d_nsel);
   if (rc) return rc;
+  // 4b. grasp clusters (grasp_detector.cpp:228-236), only when HandleSearch::setMinInliers > 0
+  const void* d_res = c->d_tmp.p;
+  const unsigned* d_nres = d_nsel;
+  if (c->min_inliers > 0) {
+    unsigned* d_nclu = &c->d_stats.as<DevStats>()->n_clu;
+    rc = cluster_async(c, c->d_tmp.as<ag2_hypothesis>(), n_img, d_nsel, c->min_inliers, d_nclu);
+    if (rc) return rc;
+    d_res = c->d_cluster.p;
+    d_nres = d_nclu;
+  }
   AG2_HIP(c, hipEventRecord(c->ev[7], c->stream));
   std::vector<ag2_hypothesis> anti;
   {
@@ -302,14 +312,14 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
     const bool small = n_img * sizeof(ag2_hypothesis) <= ((size_t)2 << 20);
     if (small && n_img) {
       anti.resize(n_img);
-      AG2_HIP(c, hipMemcpyAsync(anti.data(), c->d_tmp.p, n_img * sizeof(ag2_hypothesis),
+      AG2_HIP(c, hipMemcpyAsync(anti.data(), d_res, n_img * sizeof(ag2_hypothesis),
                                 hipMemcpyDeviceToHost, c->stream));
     }
-    AG2_HIP(c, hipMemcpyAsync(&n_anti, d_nsel, 4, hipMemcpyDeviceToHost, c->stream));
+    AG2_HIP(c, hipMemcpyAsync(&n_anti, d_nres, 4, hipMemcpyDeviceToHost, c->stream));
     AG2_HIP(c, hipStreamSynchronize(c->stream));
     if (!small && n_anti) {
       anti.resize(n_anti);
-      AG2_HIP(c, hipMemcpy(anti.data(), c->d_tmp.p, (size_t)n_anti * sizeof(ag2_hypothesis),
+      AG2_HIP(c, hipMemcpy(anti.data(), d_res, (size_t)n_anti * sizeof(ag2_hypothesis),
                            hipMemcpyDeviceToHost));
     }
     anti.resize(n_anti);

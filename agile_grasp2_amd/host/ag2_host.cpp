@@ -16,6 +16,7 @@
 #include "agile_grasp2/grasp_detector.h"
 #include "agile_grasp2/grasp_hypothesis.h"
 #include "agile_grasp2/hand_search.h"
+#include "agile_grasp2/handle_search.h"
 #include "agile_grasp2/learning.h"
 
 using ag2::Matrix3Xd;
@@ -339,6 +340,118 @@ GraspHypothesis::GraspHypothesis(const ag2_hypothesis& r)
       grasp_bottom_(r.bottom[0], r.bottom[1], r.bottom[2]), grasp_top_(r.top[0], r.top[1], r.top[2]),
       grasp_width_(r.width), score_(r.score), full_antipodal_(r.full_antipodal != 0),
       half_antipodal_(r.half_antipodal != 0), sample_slot_(r.sample_slot), orientation_(r.orientation) {}
+
+ag2_hypothesis GraspHypothesis::toRecord() const {
+  ag2_hypothesis r;
+  memset(&r, 0, sizeof(r));
+  for (int k = 0; k < 3; k++) {
+    r.axis[k] = axis_(k);
+    r.approach[k] = approach_(k);
+    r.binormal[k] = binormal_(k);
+    r.surface[k] = grasp_surface_(k);
+    r.bottom[k] = grasp_bottom_(k);
+    r.top[k] = grasp_top_(k);
+  }
+  r.width = grasp_width_;
+  r.score = score_;
+  r.sample_slot = sample_slot_;
+  r.orientation = orientation_;
+  r.half_antipodal = half_antipodal_ ? 1 : 0;
+  r.full_antipodal = full_antipodal_ ? 1 : 0;
+  r.n_points = points_for_learning_.cols();
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HandleSearch
+// ------------------------------------------------------------------------------------------------
+std::vector<GraspHypothesis> HandleSearch::findClusters(const std::vector<GraspHypothesis>& hand_list,
+                                                        bool remove_inliers) {
+  std::vector<GraspHypothesis> out;
+  const size_t n = hand_list.size();
+  if (n == 0) return out;
+  if (min_inliers_ < 1) {
+    fprintf(stderr, "HandleSearch::findClusters: min_inliers must be >= 1 (the reference divides by the inlier "
+                    "count, handle_search.cpp:66)\n");
+    return out;
+  }
+  auto moved = [&](size_t i, const double delta[3], double score) {
+    GraspHypothesis h = hand_list[i];  // :69-75
+    h.setGraspSurface(Vector3d(h.getGraspSurface()(0) + delta[0], h.getGraspSurface()(1) + delta[1],
+                               h.getGraspSurface()(2) + delta[2]));
+    h.setGraspBottom(Vector3d(h.getGraspBottom()(0) + delta[0], h.getGraspBottom()(1) + delta[1],
+                              h.getGraspBottom()(2) + delta[2]));
+    h.setGraspTop(Vector3d(h.getGraspTop()(0) + delta[0], h.getGraspTop()(1) + delta[1],
+                           h.getGraspTop()(2) + delta[2]));
+    h.setScore(score);
+    return h;
+  };
+  if (!remove_inliers) {  // every caller in the reference: on the GPU
+    if (!ctx_) {
+      ag2_params p;
+      ag2_default_params(&p);
+      ctx_.reset(new ag2::Context(p, 0));
+    }
+    if (!ctx_->ok()) {
+      fprintf(stderr, "HandleSearch: could not create a GPU context (no CPU fallback)\n");
+      return out;
+    }
+    std::vector<ag2_hypothesis> recs(n), res(n);
+    for (size_t i = 0; i < n; i++) {
+      recs[i] = hand_list[i].toRecord();
+      recs[i].n_points = (int32_t)i;  // carried through verbatim: position in hand_list
+    }
+    size_t k = 0;
+    if (ag2_find_clusters(ctx_->get(), recs.data(), n, min_inliers_, res.data(), n, &k)) {
+      fprintf(stderr, "HandleSearch::findClusters: %s\n", ag2_last_error(ctx_->get()));
+      return out;
+    }
+    out.reserve(k);
+    for (size_t q = 0; q < k; q++) {
+      const size_t i = (size_t)res[q].n_points;
+      const double delta[3] = {0.0, 0.0, 0.0};
+      GraspHypothesis h = moved(i, delta, res[q].score);
+      h.setGraspSurface(Vector3d(res[q].surface[0], res[q].surface[1], res[q].surface[2]));
+      h.setGraspBottom(Vector3d(res[q].bottom[0], res[q].bottom[1], res[q].bottom[2]));
+      h.setGraspTop(Vector3d(res[q].top[0], res[q].top[1], res[q].top[2]));
+      out.push_back(h);
+    }
+    return out;
+  }
+  // remove_inliers = true: has_used couples the iterations (handle_search.cpp:14-22,31,58-59)
+  const double cos_thresh = std::cos(15.0 * M_PI / 180.0);
+  std::vector<char> has_used(n, 0);
+  for (size_t i = 0; i < n; i++) {
+    const Vector3d &a = hand_list[i].getAxis(), &b = hand_list[i].getGraspBottom();
+    double P[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) P[r][c] = ((r == c) ? 1.0 : 0.0) - a(r) * a(c);
+    int cnt = 0;
+    double sum[3] = {0.0, 0.0, 0.0}, ssum = 0.0;
+    for (size_t j = 0; j < n; j++) {
+      if (i == j || has_used[j]) continue;
+      const Vector3d &t = hand_list[j].getAxis(), &u = hand_list[j].getGraspBottom();
+      const double aligned = (a(0) * t(0) + a(1) * t(1)) + a(2) * t(2);
+      const double d0 = b(0) - u(0), d1 = b(1) - u(1), d2 = b(2) - u(2);
+      const double mag = std::sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+      const double p0 = (P[0][0] * d0 + P[0][1] * d1) + P[0][2] * d2;
+      const double p1 = (P[1][0] * d0 + P[1][1] * d1) + P[1][2] * d2;
+      const double p2 = (P[2][0] * d0 + P[2][1] * d1) + P[2][2] * d2;
+      const double pm = std::sqrt((p0 * p0 + p1 * p1) + p2 * p2);
+      if (std::fabs(aligned) > cos_thresh && mag <= 0.05 && pm <= 0.005) {
+        cnt++;
+        sum[0] += u(0); sum[1] += u(1); sum[2] += u(2);
+        ssum += hand_list[j].getScore();
+        has_used[j] = 1;
+      }
+    }
+    if (cnt >= min_inliers_) {
+      const double delta[3] = {sum[0] / cnt - b(0), sum[1] / cnt - b(1), sum[2] / cnt - b(2)};
+      out.push_back(moved(i, delta, ssum / cnt));
+    }
+  }
+  return out;
+}
 
 agile_grasp2::GraspMsg GraspHypothesis::convertToGraspMsg() const {
   agile_grasp2::GraspMsg m;
@@ -742,8 +855,9 @@ std::shared_ptr<ag2::Context> GraspDetector::contextFor(int n_cams) {
   return ctx_;
 }
 
-std::vector<GraspHypothesis> GraspDetector::detectGraspPoses(const CloudCamera& cloud_cam, bool) {
+std::vector<GraspHypothesis> GraspDetector::detectGraspPoses(const CloudCamera& cloud_cam, bool clusters_grasps) {
   std::vector<GraspHypothesis> out;
+  const int min_inliers = (clusters_grasps && p_.min_inliers > 0) ? p_.min_inliers : 0;  // :228-236
   if (cloud_cam.getCloudOriginal()->size() == 0) {  // grasp_detector.cpp:86-91
     fprintf(stderr, "Point cloud is empty!\n");
     return out;
@@ -786,6 +900,7 @@ std::vector<GraspHypothesis> GraspDetector::detectGraspPoses(const CloudCamera& 
       rc = ag2_lenet_load(c, classifier_->blob(0).data(), classifier_->blob(1).data(), classifier_->blob(2).data(),
                           classifier_->blob(3).data(), classifier_->blob(4).data(), classifier_->blob(5).data(),
                           classifier_->blob(6).data(), classifier_->blob(7).data());
+      if (!rc) rc = ag2_set_min_inliers(c, min_inliers);  // clustering between threshold and top-k, on the GPU
       if (!rc) rc = ag2_detect(c, pidx, pxyz, s, 0, p_.seed, do_prune ? 1 : 0, recs.data(), cap, &n, nullptr, 0, nullptr);
     } else {
       rc = ag2_generate_hypotheses(c, pidx, pxyz, s, 0, p_.seed, recs.data(), cap, &n);
@@ -798,6 +913,13 @@ std::vector<GraspHypothesis> GraspDetector::detectGraspPoses(const CloudCamera& 
           if (sel) recs[m++] = recs[h];
         }
         n = m;
+        if (min_inliers > 0 && n) {  // 4. grasp clusters, :228-236
+          std::vector<ag2_hypothesis> clustered(n);
+          size_t k = 0;
+          rc = ag2_find_clusters(c, recs.data(), n, min_inliers, clustered.data(), n, &k);
+          if (!rc) std::copy(clustered.begin(), clustered.begin() + (long)k, recs.begin());
+          if (!rc) n = k;
+        }
         if (p_.antipodal_mode == GEOMETRIC) {  // :239-252 (scores are all zero: stable order kept)
           if ((int)n > p_.num_selected) n = (size_t)p_.num_selected;
         }

@@ -202,6 +202,20 @@ int ag2_get_cloud(ag2_ctx* c, float* xyz_nx3, int32_t* cam_source, size_t cap, s
 int ag2_subsample_uniformly(ag2_ctx* c, size_t num_samples, uint64_t seed, int32_t* idx_out,
                             size_t cap, size_t* n_out);
 
+/* ---- the step behind the scoring: HandleSearch::findClusters(hand_list, remove_inliers = false),
+ * handle_search.cpp:4-80 ----
+ * A hand is kept when at least min_inliers other hands have an axis within 15 degrees, a bottom
+ * within 5 cm and within 5 mm in the plane orthogonal to its axis; it is moved by (mean inlier
+ * bottom - own bottom) and takes the mean inlier score.  Output in input order.  min_inliers >= 1.
+ * (remove_inliers = true is order-dependent and has no caller in the reference; the host mirror
+ * keeps it as plain C++.) */
+int ag2_find_clusters(ag2_ctx* c, const ag2_hypothesis* hands, size_t n, int min_inliers,
+                      ag2_hypothesis* out, size_t cap, size_t* n_out);
+/* HandleSearch::setMinInliers (handle_search.h:83-86; GraspDetector reads the ROS parameter
+ * min_inliers, default 0, grasp_detector.cpp:59-65).  > 0 makes ag2_detect cluster the hands that
+ * passed min_score_diff before the top num_selected are taken (grasp_detector.cpp:228-236). */
+int ag2_set_min_inliers(ag2_ctx* c, int min_inliers);
+
 int ag2_get_counters(ag2_ctx* c, ag2_counters* out);
 int ag2_get_stage_times(ag2_ctx* c, ag2_times* out);
 

@@ -41,7 +41,7 @@ class GraspDetector {
     std::string model_file, trained_file, label_file;
     double min_score_diff = 500.0;
     int batch_size = 10;               // accepted; the GPU path scores all images in one batch
-    int min_inliers = 0;               // clustering (HandleSearch) is listed under "next"
+    int min_inliers = 0;               // > 0: HandleSearch::findClusters before the top-k (grasp_detector.cpp:59-65,228-236)
     double min_length = 0.005;
     bool reuse_inliers = true;
     int num_selected = 50;

@@ -23,6 +23,7 @@ class GraspHypothesis {
         normals_for_learning_(normals_for_learning), camera_source_for_learning_(camera_source_for_learning) {}
   // from a C-ABI record (+ optional point lists)
   explicit GraspHypothesis(const ag2_hypothesis& r);
+  ag2_hypothesis toRecord() const;  // the fixed part, for C-ABI calls that take hypotheses
 
   agile_grasp2::GraspMsg convertToGraspMsg() const;  // grasp_hypothesis.cpp:40-52
 

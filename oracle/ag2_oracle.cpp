@@ -233,6 +233,7 @@ struct ag2o_ctx {
   double fs[20], fsr[20];              // finger_spacing_(i), finger_spacing_(i) + finger_width_
   std::vector<double> cos_t, sin_t;    // per orientation
   std::vector<double> depths;          // deepenHand depth sequence
+  int min_inliers = 0;                 // HandleSearch::setMinInliers; grasp_detector.cpp:59-65
 };
 
 namespace {
@@ -1072,6 +1073,13 @@ int ag2o_detect(ag2o_ctx* c, const int32_t* sample_idx, const double* sample_xyz
   }
   if (n_scored) *n_scored = kept.size();
   c->cnt.n_scored = (int64_t)kept.size();
+  if (c->min_inliers > 0) {  // grasp_detector.cpp:228-236
+    std::vector<ag2o_hypothesis> clustered(anti.size());
+    size_t nc = 0;
+    ag2o_find_clusters(anti.data(), anti.size(), c->min_inliers, 0, clustered.data(), clustered.size(), &nc);
+    clustered.resize(nc);
+    anti.swap(clustered);
+  }
   // :239-252 top num_selected by score, descending; ties broken by position (stable)
   std::stable_sort(anti.begin(), anti.end(),
                    [](const ag2o_hypothesis& a, const ag2o_hypothesis& b) { return a.score > b.score; });
@@ -1090,6 +1098,66 @@ int ag2o_detect(ag2o_ctx* c, const int32_t* sample_idx, const double* sample_xyz
 int ag2o_get_counters(ag2o_ctx* c, ag2o_counters* out) {
   if (!c) return -1;
   *out = c->cnt;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grasp clustering: HandleSearch::findClusters, handle_search.cpp:4-80.
+// Eigen's fixed-size dot / norm / 3x3 product reduce as ((x0 + x1) + x2).
+// ------------------------------------------------------------------------------------------------
+int ag2o_find_clusters(const ag2o_hypothesis* hands, size_t n, int min_inliers, int remove_inliers,
+                       ag2o_hypothesis* out, size_t cap, size_t* n_out) {
+  if (!n_out || min_inliers < 1) return -1;
+  const double cos_thresh = std::cos(15.0 * M_PI / 180.0);  // :7
+  std::vector<char> has_used(n, 0);                          // :14-22
+  size_t k = 0;
+  for (size_t i = 0; i < n; i++) {
+    const double* a = hands[i].axis;
+    const double* b = hands[i].bottom;
+    double P[3][3];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) P[r][c] = ((r == c) ? 1.0 : 0.0) - a[r] * a[c];  // :27,47
+    int cnt = 0;
+    double sum[3] = {0.0, 0.0, 0.0}, ssum = 0.0;
+    for (size_t j = 0; j < n; j++) {
+      if (i == j || (remove_inliers && has_used[j])) continue;                       // :31
+      const double* t = hands[j].axis;
+      const double* u = hands[j].bottom;
+      const double aligned = (a[0] * t[0] + a[1] * t[1]) + a[2] * t[2];              // :35
+      const double d0 = b[0] - u[0], d1 = b[1] - u[1], d2 = b[2] - u[2];             // :39
+      const double mag = std::sqrt((d0 * d0 + d1 * d1) + d2 * d2);                   // :40
+      const double p0 = (P[0][0] * d0 + P[0][1] * d1) + P[0][2] * d2;                // :48
+      const double p1 = (P[1][0] * d0 + P[1][1] * d1) + P[1][2] * d2;
+      const double p2 = (P[2][0] * d0 + P[2][1] * d1) + P[2][2] * d2;
+      const double pm = std::sqrt((p0 * p0 + p1 * p1) + p2 * p2);                    // :49
+      if (std::fabs(aligned) > cos_thresh && mag <= 0.05 && pm <= 0.005) {           // :36,41,50,52
+        cnt++;
+        sum[0] = sum[0] + u[0]; sum[1] = sum[1] + u[1]; sum[2] = sum[2] + u[2];      // :56
+        ssum = ssum + hands[j].score;                                                // :57
+        if (remove_inliers) has_used[j] = 1;                                         // :58-59
+      }
+    }
+    if (cnt >= min_inliers) {                                                        // :64
+      ag2o_hypothesis h = hands[i];
+      const double nn = (double)cnt;
+      for (int c = 0; c < 3; c++) {
+        const double delta = sum[c] / nn - b[c];                                     // :66
+        h.surface[c] = h.surface[c] + delta;                                         // :71-73
+        h.bottom[c] = h.bottom[c] + delta;
+        h.top[c] = h.top[c] + delta;
+      }
+      h.score = ssum / nn;                                                           // :67,74
+      if (k < cap && out) out[k] = h;
+      k++;
+    }
+  }
+  *n_out = k;
+  return (k > cap) ? -2 : 0;
+}
+
+int ag2o_set_min_inliers(ag2o_ctx* c, int min_inliers) {
+  if (!c || min_inliers < 0) return -1;
+  c->min_inliers = min_inliers;
   return 0;
 }
 

@@ -118,6 +118,13 @@ int ag2o_detect(ag2o_ctx* c, const int32_t* sample_idx, const double* sample_xyz
                 size_t* n_scored);
 int ag2o_get_counters(ag2o_ctx* c, ag2o_counters* out);
 
+/* HandleSearch::findClusters(hand_list, remove_inliers), handle_search.cpp:4-80.  Output in input
+ * order; returns -2 (with *n_out set) when cap is too small.  min_inliers >= 1. */
+int ag2o_find_clusters(const ag2o_hypothesis* hands, size_t n, int min_inliers, int remove_inliers,
+                       ag2o_hypothesis* out, size_t cap, size_t* n_out);
+/* HandleSearch::setMinInliers: > 0 makes ag2o_detect cluster before the top-k (grasp_detector.cpp:228-236) */
+int ag2o_set_min_inliers(ag2o_ctx* c, int min_inliers);
+
 /* Preprocessing in front of the path (GraspDetector::preprocessPointCloud, grasp_detector.cpp:285-335):
  * CloudCamera::filterWorkspace (cloud_camera.cpp:89-121, bounds = params.workspace) and
  * CloudCamera::voxelizeCloud (:124-168); the result becomes the context's cloud.  flags bit 0:

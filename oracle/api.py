@@ -276,6 +276,20 @@ class Oracle:
                                     C.byref(na)))
         return sel[: ns.value].copy(), allh[: na.value].copy()
 
+    def set_min_inliers(self, k):
+        self._ck(self.L.ag2o_set_min_inliers(self.h, C.c_int(k)))
+
+    def find_clusters(self, hands, min_inliers, remove_inliers=False):
+        hands = np.ascontiguousarray(hands, dtype=HYP_DTYPE)
+        out = np.zeros(max(1, len(hands)), dtype=HYP_DTYPE)
+        n = C.c_size_t(0)
+        rc = self.L.ag2o_find_clusters(_ptr(hands), C.c_size_t(len(hands)), C.c_int(min_inliers),
+                                       C.c_int(int(remove_inliers)), _ptr(out), C.c_size_t(len(out)),
+                                       C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"oracle: find_clusters rc={rc}")
+        return out[: n.value].copy()
+
     def counters(self) -> Counters:
         c = Counters()
         self._ck(self.L.ag2o_get_counters(self.h, C.byref(c)))

@@ -205,9 +205,11 @@ int main(int argc, char** argv) {
 
 
 @pytest.mark.gpu
-def test_cpp_preprocess_then_detect_matches_oracle(tmp_path):
+@pytest.mark.parametrize("min_inliers", [0, 1])
+def test_cpp_preprocess_then_detect_matches_oracle(tmp_path, min_inliers):
     """GraspDetector::preprocessPointCloud (GPU front end behind the reference's method name) followed
-    by detectGraspPoses on a raw cloud == oracle preprocess -> subsample -> detect."""
+    by detectGraspPoses on a raw cloud == oracle preprocess -> subsample -> detect [-> findClusters when
+    the min_inliers parameter is set, grasp_detector.cpp:228-236]."""
     from oracle import api
     tmp = str(tmp_path)
     exe = build_driver(tmp)
@@ -217,8 +219,9 @@ def test_cpp_preprocess_then_detect_matches_oracle(tmp_path):
     save_ag2w(wpath, w)
     open(lpath, "w").write("0\n1\n")
     raw.astype("<f4").tofile(os.path.join(tmp, "raw.f32"))
-    seed, ns_req = 5, 120
-    text = params_text(ws, wpath, lpath, seed) + f"num_samples = {ns_req}\nvoxelize = true\n"
+    seed, ns_req = 5, 400
+    text = params_text(ws, wpath, lpath, seed) + (f"num_samples = {ns_req}\nvoxelize = true\n"
+                                                  f"min_inliers = {min_inliers}\n")
     open(os.path.join(tmp, "params.txt"), "w").write(text)
     outp = os.path.join(tmp, "out.bin")
     r = subprocess.run([exe, "--preprocess", os.path.join(tmp, "raw.f32"), os.path.join(tmp, "params.txt"), outp],
@@ -232,6 +235,7 @@ def test_cpp_preprocess_then_detect_matches_oracle(tmp_path):
     idx = o.subsample_uniformly(ns_req, seed=seed)
     o.compute_normals()
     o.lenet_load(w)
+    o.set_min_inliers(min_inliers)
     wsel, _ = o.detect(sample_idx=idx, seed=seed, do_prune=True)
 
     buf = open(outp, "rb").read()
