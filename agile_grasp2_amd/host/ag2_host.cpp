@@ -17,6 +17,7 @@
 #include "agile_grasp2/grasp_hypothesis.h"
 #include "agile_grasp2/hand_search.h"
 #include "agile_grasp2/handle_search.h"
+#include "agile_grasp2/importance_sampling.h"
 #include "agile_grasp2/learning.h"
 
 using ag2::Matrix3Xd;
@@ -593,6 +594,137 @@ std::vector<ag2::Image> Learning::createGraspImages(const std::vector<GraspHypot
 // ------------------------------------------------------------------------------------------------
 static const size_t kBlobSizes[8] = {20 * 3 * 25, 20, 50 * 20 * 25, 50, 500 * 7200, 500, 2 * 500, 2};
 
+// ---- .caffemodel reader: a walker over the protobuf wire format (protoc is not needed) ---------------
+// Field numbers from BVLC caffe.proto: NetParameter.layer = 100 (LayerParameter: name = 1, blobs = 7),
+// legacy NetParameter.layers = 2 (V1LayerParameter: name = 4, blobs = 6); BlobProto: data = 5 (float,
+// packed or not), double_data = 8, shape = 7, legacy num/channels/height/width = 1..4 (ignored: only
+// the element count is checked against the fixed architecture caffe/test_1batch2.prototxt).
+namespace {
+struct Pb {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  Pb(const uint8_t* b, const uint8_t* e) : p(b), end(e) {}
+  bool more() const { return ok && p < end; }
+  uint64_t varint() {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      if (p >= end) { ok = false; return 0; }
+      const uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7F) << shift;
+      if (!(b & 0x80)) return v;
+    }
+    ok = false;
+    return 0;
+  }
+  Pb sub() {  // length-delimited payload
+    const uint64_t len = varint();
+    if (!ok || len > (uint64_t)(end - p)) { ok = false; return Pb(end, end); }
+    Pb s(p, p + len);
+    p += len;
+    return s;
+  }
+  void skip(int wire) {
+    if (wire == 0) (void)varint();
+    else if (wire == 1) { if (end - p < 8) ok = false; else p += 8; }
+    else if (wire == 2) (void)sub();
+    else if (wire == 5) { if (end - p < 4) ok = false; else p += 4; }
+    else ok = false;  // groups are not used by caffe.proto
+  }
+};
+
+bool parse_blob(Pb b, std::vector<float>* out) {
+  out->clear();
+  while (b.more()) {
+    const uint64_t key = b.varint();
+    const int field = (int)(key >> 3), wire = (int)(key & 7);
+    if (field == 5 && wire == 2) {         // packed repeated float
+      Pb d = b.sub();
+      const size_t n = (size_t)(d.end - d.p) / 4;
+      const size_t at = out->size();
+      out->resize(at + n);
+      if (n) std::memcpy(out->data() + at, d.p, n * 4);  // little-endian host (x86-64)
+    } else if (field == 5 && wire == 5) {  // one unpacked float
+      if (b.end - b.p < 4) return false;
+      float v;
+      std::memcpy(&v, b.p, 4);
+      b.p += 4;
+      out->push_back(v);
+    } else if (field == 8 && wire == 2) {  // packed double_data
+      Pb d = b.sub();
+      for (; d.end - d.p >= 8; d.p += 8) {
+        double v;
+        std::memcpy(&v, d.p, 8);
+        out->push_back((float)v);
+      }
+    } else if (field == 8 && wire == 1) {
+      if (b.end - b.p < 8) return false;
+      double v;
+      std::memcpy(&v, b.p, 8);
+      b.p += 8;
+      out->push_back((float)v);
+    } else {
+      b.skip(wire);
+    }
+  }
+  return b.ok;
+}
+
+bool parse_layer(Pb l, int name_field, int blobs_field, std::string* name, std::vector<std::vector<float>>* blobs) {
+  while (l.more()) {
+    const uint64_t key = l.varint();
+    const int field = (int)(key >> 3), wire = (int)(key & 7);
+    if (field == name_field && wire == 2) {
+      Pb s = l.sub();
+      name->assign((const char*)s.p, (size_t)(s.end - s.p));
+    } else if (field == blobs_field && wire == 2) {
+      blobs->emplace_back();
+      if (!parse_blob(l.sub(), &blobs->back())) return false;
+    } else {
+      l.skip(wire);
+    }
+  }
+  return l.ok;
+}
+}  // namespace
+
+bool Classifier::readCaffeModel(const std::string& path, std::vector<float> blobs[8], std::string* err) {
+  std::ifstream f(path.c_str(), std::ios::binary);
+  if (!f) { *err = "cannot open " + path; return false; }
+  const std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  Pb net((const uint8_t*)raw.data(), (const uint8_t*)raw.data() + raw.size());
+  static const char* kLayers[4] = {"conv1", "conv2", "ip1", "ip2"};
+  bool seen[4] = {false, false, false, false};
+  while (net.more()) {
+    const uint64_t key = net.varint();
+    const int field = (int)(key >> 3), wire = (int)(key & 7);
+    if ((field == 100 || field == 2) && wire == 2) {
+      std::string name;
+      std::vector<std::vector<float>> lb;
+      if (!parse_layer(net.sub(), field == 100 ? 1 : 4, field == 100 ? 7 : 6, &name, &lb)) {
+        *err = "malformed layer record in " + path;
+        return false;
+      }
+      for (int k = 0; k < 4; k++) {
+        if (name != kLayers[k] || lb.empty()) continue;  // pooling / relu / softmax carry no blobs
+        if (lb.size() != 2 || lb[0].size() != kBlobSizes[2 * k] || lb[1].size() != kBlobSizes[2 * k + 1]) {
+          *err = "layer " + name + " does not have the blob sizes of caffe/test_1batch2.prototxt";
+          return false;
+        }
+        blobs[2 * k] = lb[0];
+        blobs[2 * k + 1] = lb[1];
+        seen[k] = true;
+      }
+    } else {
+      net.skip(wire);
+    }
+  }
+  if (!net.ok) { *err = "not a protobuf NetParameter: " + path; return false; }
+  for (int k = 0; k < 4; k++)
+    if (!seen[k]) { *err = std::string("layer ") + kLayers[k] + " with weights not found in " + path; return false; }
+  return true;
+}
+
 Classifier::Classifier(const std::string& model_file, const std::string& trained_file,
                        const std::string& label_file) {
   if (!model_file.empty()) {
@@ -601,15 +733,20 @@ Classifier::Classifier(const std::string& model_file, const std::string& trained
   }
   std::ifstream f(trained_file.c_str(), std::ios::binary);
   char magic[4] = {0, 0, 0, 0};
-  if (!f || !f.read(magic, 4) || std::memcmp(magic, "AG2W", 4) != 0) {
-    err_ = "cannot read weights (expected an .ag2w container): " + trained_file;
+  if (!f || !f.read(magic, 4)) {
+    err_ = "cannot read weights file " + trained_file;
     return;
   }
-  for (int b = 0; b < 8; b++) {
-    blobs_[b].resize(kBlobSizes[b]);
-    if (!f.read(reinterpret_cast<char*>(blobs_[b].data()), (std::streamsize)(kBlobSizes[b] * 4))) {
-      err_ = "truncated weights file " + trained_file;
-      return;
+  if (std::memcmp(magic, "AG2W", 4) != 0) {  // CopyTrainedLayersFrom, caffe_classifier.cpp:14
+    f.close();
+    if (!readCaffeModel(trained_file, blobs_, &err_)) return;
+  } else {
+    for (int b = 0; b < 8; b++) {
+      blobs_[b].resize(kBlobSizes[b]);
+      if (!f.read(reinterpret_cast<char*>(blobs_[b].data()), (std::streamsize)(kBlobSizes[b] * 4))) {
+        err_ = "truncated weights file " + trained_file;
+        return;
+      }
     }
   }
   std::ifstream l(label_file.c_str());
@@ -856,6 +993,11 @@ std::shared_ptr<ag2::Context> GraspDetector::contextFor(int n_cams) {
 }
 
 std::vector<GraspHypothesis> GraspDetector::detectGraspPoses(const CloudCamera& cloud_cam, bool clusters_grasps) {
+  return detectImpl(cloud_cam, clusters_grasps, nullptr, false);
+}
+
+std::vector<GraspHypothesis> GraspDetector::detectImpl(const CloudCamera& cloud_cam, bool clusters_grasps,
+                                                       const Matrix3Xd* samples_xyz, bool cloud_is_resident) {
   std::vector<GraspHypothesis> out;
   const int min_inliers = (clusters_grasps && p_.min_inliers > 0) ? p_.min_inliers : 0;  // :228-236
   if (cloud_cam.getCloudOriginal()->size() == 0) {  // grasp_detector.cpp:86-91
@@ -870,20 +1012,30 @@ std::vector<GraspHypothesis> GraspDetector::detectGraspPoses(const CloudCamera& 
   }
   ag2_ctx* c = ctx->get();
   int rc = 0;
-  if (c == resident_ctx_ && cloud_cam.getCloudProcessed().get() == resident_cloud_ &&
-      cloud_cam.getCloudProcessed()->size() == resident_n_) {
+  const bool same_cloud = c == resident_ctx_ && cloud_cam.getCloudProcessed().get() == resident_cloud_ &&
+                          cloud_cam.getCloudProcessed()->size() == resident_n_;
+  if (same_cloud && cloud_is_resident && resident_normals_) {
+    // ImportanceSampling re-entry: grid and normals of this cloud are already in the context
+  } else if (same_cloud && !cloud_is_resident && !resident_uploaded_here_) {
     // preprocessPointCloud left exactly this cloud (and its grid) in the context
     if (!resident_normals_) rc = ag2_compute_normals(c);  // hand_search.cpp:20-29
     resident_normals_ = true;
   } else {
-    resident_ctx_ = nullptr;
     rc = HandSearch::uploadCloud(c, cloud_cam);
+    resident_ctx_ = rc ? nullptr : c;
+    resident_cloud_ = cloud_cam.getCloudProcessed().get();
+    resident_n_ = cloud_cam.getCloudProcessed()->size();
+    resident_normals_ = true;
+    resident_uploaded_here_ = true;  // a public detectGraspPoses call always uploads again
   }
-  const bool use_samples = use_incoming_samples_;
-  const size_t s = use_samples ? (size_t)cloud_cam.getSamples().cols() : cloud_cam.getSampleIndices().size();
+  const bool use_samples = samples_xyz ? true : use_incoming_samples_;
+  const Matrix3Xd& sample_mat = samples_xyz ? *samples_xyz : cloud_cam.getSamples();
+  const size_t s = use_samples ? (size_t)sample_mat.cols() : cloud_cam.getSampleIndices().size();
   std::vector<int32_t> idx(cloud_cam.getSampleIndices().begin(), cloud_cam.getSampleIndices().end());
   const int32_t* pidx = use_samples ? nullptr : idx.data();
-  const double* pxyz = use_samples ? cloud_cam.getSamples().data() : nullptr;
+  const double* pxyz = use_samples ? sample_mat.data() : nullptr;
+  const double dummy_xyz[3] = {0.0, 0.0, 0.0};
+  if (use_samples && s == 0) pxyz = dummy_xyz;
   const int32_t dummy = 0;
   if (!use_samples && idx.empty()) pidx = &dummy;  // zero samples: a valid (empty) request
   const bool do_prune = indices_.empty();          // grasp_detector.cpp:149-160
@@ -984,6 +1136,7 @@ bool GraspDetector::preprocessOnDevice(CloudCamera& cloud_cam) {
   resident_n_ = m;
   resident_ctx_ = c;
   resident_normals_ = carry_normals && m;
+  resident_uploaded_here_ = false;
   return true;
 }
 
@@ -1089,4 +1242,80 @@ bool GraspDetector::findGrasps(const CloudCamera& cloud_in, const agile_grasp2::
   num_samples_ = saved_n;
   if (resp) resp->grasps_msg = createGraspListMsg(hands);  // filled (the reference leaves it empty, :196)
   return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ImportanceSampling
+// ------------------------------------------------------------------------------------------------
+ImportanceSampling::ImportanceSampling(const Params& params)
+    : GraspDetector(params), num_iterations_(NUM_ITERATIONS), num_samples_is_(NUM_SAMPLES),
+      num_init_samples_(NUM_INIT_SAMPLES), prob_rand_samples_(PROB_RAND_SAMPLES), radius_(RADIUS),
+      sampling_method_(METHOD) {}
+
+// standard normal deviate (Box-Muller) from the counter-based generator, stream = round
+double ImportanceSampling::gaussian(uint64_t round, uint64_t* counter) const {
+  const uint64_t stream = 0xFFFFFFFFFFFF0000ull + round;
+  const double u1 = (double)((draw_u64(params().seed, stream, (*counter)++) >> 11) + 1ull) * (1.0 / 9007199254740992.0);
+  const double u2 = (double)(draw_u64(params().seed, stream, (*counter)++) >> 11) * (1.0 / 9007199254740992.0);
+  return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
+}
+
+std::vector<GraspHypothesis> ImportanceSampling::detectGraspPoses(const CloudCamera& cloud_cam_in) {
+  const CloudCamera& cloud_cam = cloud_cam_in;
+  rounds_.clear();
+  // 1. initial grasp hypotheses (importance_sampling.cpp:38)
+  std::vector<GraspHypothesis> hands = detectImpl(cloud_cam, false, nullptr, false);
+  n_initial_ = (int)hands.size();
+  if (hands.empty()) return hands;  // :40-43
+  const PointCloudRGB::Ptr& cloud = cloud_cam.getCloudProcessed();
+  // 2. (:50-62)
+  const int num_rand_samples = (int)(prob_rand_samples_ * num_samples_is_);
+  const int num_gauss_samples = num_samples_is_ - num_rand_samples;
+  const double sigma = radius_;
+  const double term = 1.0 / std::sqrt(std::pow(2.0 * M_PI, 3.0) * std::pow(sigma, 3.0));
+  for (int it = 0; it < num_iterations_; it++) {  // 3. (:65-101)
+    Matrix3Xd samples(3, num_samples_is_);
+    uint64_t counter = 0;
+    const uint64_t stream = 0xFFFFFFFFFFFF0000ull + (uint64_t)it;
+    auto pick = [&](size_t n) { return (size_t)(draw_u64(params().seed, stream, counter++) % (uint64_t)n); };
+    int j = 0, guard = 0;
+    while (j < num_gauss_samples && guard < 1000000) {
+      guard++;
+      const size_t idx = pick(hands.size());  // :125 / :139
+      double x[3];
+      for (int k = 0; k < 3; k++) x[k] = hands[idx].getGraspSurface()(k) + gaussian((uint64_t)it, &counter) * sigma;
+      bool accept = true;
+      if (sampling_method_ == MAX) {  // rejection sampling, :135-165
+        auto dens = [&](const GraspHypothesis& h) {
+          const double d0 = x[0] - h.getGraspSurface()(0), d1 = x[1] - h.getGraspSurface()(1),
+                       d2 = x[2] - h.getGraspSurface()(2);
+          return term * std::exp((-1.0 / (2.0 * sigma)) * ((d0 * d0 + d1 * d1) + d2 * d2));
+        };
+        double maxp = 0.0;
+        for (const GraspHypothesis& h : hands) maxp = std::max(maxp, dens(h));
+        accept = dens(hands[idx]) >= maxp;
+      }
+      if (accept) {
+        for (int k = 0; k < 3; k++) samples(k, j) = x[k];
+        j++;
+      }
+    }
+    for (int q = num_samples_is_ - num_rand_samples; q < num_samples_is_; q++) {  // 3.2 (:83-90)
+      const ag2::PointXYZRGBA& p = cloud->points[pick(cloud->size())];
+      samples(0, q) = (double)p.x;
+      samples(1, q) = (double)p.y;
+      samples(2, q) = (double)p.z;
+    }
+    rounds_.push_back(samples);
+    // 3.3 (:93-95): one ag2_detect on the resident cloud, grid and normals
+    const std::vector<GraspHypothesis> hands_new = detectImpl(cloud_cam, false, &samples, true);
+    hands.insert(hands.end(), hands_new.begin(), hands_new.end());
+  }
+  if (params().min_inliers > 0) {  // :107-111
+    HandleSearch hs;
+    hs.setMinInliers(params().min_inliers);
+    hs.setContext(context());
+    hands = hs.findClusters(hands);
+  }
+  return hands;
 }

@@ -16,13 +16,16 @@ typedef std::pair<std::string, float> Prediction;  // caffe_classifier.h:55
 class Classifier {
  public:
   // caffe_classifier.cpp:4-35.  model_file: the prototxt is only checked for existence when given
-  // (the architecture is fixed: caffe/test_1batch2.prototxt).  trained_file: weights in the flat
+  // (the architecture is fixed: caffe/test_1batch2.prototxt).  trained_file: either a Caffe
+  // ".caffemodel" (binary NetParameter, read with a hand-written protobuf wire-format walker: new
+  // `layer` and legacy V1 `layers` records, packed or unpacked float / double blobs) or the flat
   // ".ag2w" container (magic "AG2W", then the eight blobs conv1 w,b / conv2 w,b / ip1 w,b /
-  // ip2 w,b as little-endian float32 in Caffe blob order) -- a .caffemodel reader is listed under
-  // "next" in DESIGN.md.  label_file: one label per line (caffe/labels.txt).
-  // Never aborts: on failure ok() is false and ClassifyBatch returns an empty vector.
+  // ip2 w,b as little-endian float32 in Caffe blob order).  label_file: one label per line
+  // (caffe/labels.txt).  Never aborts: on failure ok() is false and ClassifyBatch returns an empty vector.
   Classifier(const std::string& model_file, const std::string& trained_file,
              const std::string& label_file);
+  // The reader by itself: layers conv1, conv2, ip1, ip2 -> blobs[0..7]; false + *err on any mismatch.
+  static bool readCaffeModel(const std::string& path, std::vector<float> blobs[8], std::string* err);
 
   // caffe_classifier.cpp:70-91: per image [(label_0, ip2[0]), (label_1, ip2[1])], raw logits.
   std::vector<std::vector<Prediction>> ClassifyBatch(const std::vector<ag2::Image>& imgs, int num_classes);

@@ -89,6 +89,15 @@ class GraspDetector {
   const ag2_counters& lastCounters() const { return counters_; }
   const std::string& lastError() const { return err_; }
 
+ protected:
+  // detectGraspPoses with the two things ImportanceSampling needs: samples given as xyz regardless
+  // of use_incoming_samples_, and "the context already holds this cloud and its normals" (the
+  // reference rebuilds the kd-tree and recomputes every normal on each re-entry, hand_search.cpp:11-29)
+  std::vector<GraspHypothesis> detectImpl(const CloudCamera& cloud_cam, bool clusters_grasps,
+                                          const ag2::Matrix3Xd* samples_xyz, bool cloud_is_resident);
+  const Params& params() const { return p_; }
+  std::shared_ptr<ag2::Context> context() const { return ctx_; }
+
  private:
   std::vector<GraspHypothesis> pruneGraspsOnHandParameters(const std::vector<GraspHypothesis>& hands,
                                                            float min_x, float max_x, float min_y,
@@ -112,6 +121,7 @@ class GraspDetector {
   size_t resident_n_ = 0;
   const ag2_ctx* resident_ctx_ = nullptr;
   bool resident_normals_ = false;
+  bool resident_uploaded_here_ = false;  // by detectImpl (re-entries only), not by preprocessPointCloud
   ag2_times times_{};
   ag2_counters counters_{};
   std::string err_;

@@ -18,6 +18,7 @@
 #include "agile_grasp2/cloud_camera.h"
 #include "agile_grasp2/grasp_detector.h"
 #include "agile_grasp2/hand_search.h"
+#include "agile_grasp2/importance_sampling.h"
 #include "agile_grasp2/learning.h"
 
 template <class T>
@@ -80,8 +81,84 @@ static int run_preprocess(const char* raw_path, const char* params_path, const c
   return 0;
 }
 
+// test_host_api --importance <cloud.f32> <idx.i32> <params.txt> <out.bin>:
+// ImportanceSampling::detectGraspPoses (importance_sampling.cpp:30-118) on a preprocessed cloud
+static int run_importance(const char* cloud_path, const char* idx_path, const char* params_path,
+                          const char* out_path) {
+  const std::vector<float> xyz = read_all<float>(cloud_path);
+  const std::vector<int32_t> idx = read_all<int32_t>(idx_path);
+  std::ifstream pf(params_path);
+  const std::string ptext((std::istreambuf_iterator<char>(pf)), std::istreambuf_iterator<char>());
+  GraspDetector::Params prm;
+  std::string err;
+  if (!GraspDetector::Params::fromKeyValueText(ptext, &prm, &err)) {
+    fprintf(stderr, "params: %s\n", err.c_str());
+    return 2;
+  }
+  PointCloudRGB::Ptr cloud(new PointCloudRGB);
+  cloud->points.resize(xyz.size() / 3);
+  for (size_t i = 0; i < cloud->size(); i++) {
+    cloud->points[i].x = xyz[3 * i];
+    cloud->points[i].y = xyz[3 * i + 1];
+    cloud->points[i].z = xyz[3 * i + 2];
+  }
+  CloudCamera cc(cloud, (int)cloud->size());
+  cc.setSampleIndices(std::vector<int>(idx.begin(), idx.end()));
+  ImportanceSampling is(prm);
+  is.setNumIterations(3);
+  is.setNumSamplesPerIteration(40);
+  const std::vector<GraspHypothesis> hands = is.detectGraspPoses(cc);
+  std::ofstream out(out_path, std::ios::binary);
+  const int64_t n0 = is.lastInitialCount(), nr = (int64_t)is.lastSampleRounds().size(), nh = (int64_t)hands.size();
+  put(out, &n0, 1);
+  put(out, &nr, 1);
+  for (const ag2::Matrix3Xd& m : is.lastSampleRounds()) {
+    const int64_t s = m.cols();
+    put(out, &s, 1);
+    put(out, m.data(), (size_t)(3 * s));
+  }
+  put(out, &nh, 1);
+  for (const GraspHypothesis& h : hands) {
+    const int32_t so[2] = {h.getSampleSlot(), h.getOrientation()};
+    const double v[4] = {h.getScore(), h.getGraspBottom()(0), h.getGraspBottom()(1), h.getGraspBottom()(2)};
+    put(out, so, 2);
+    put(out, v, 4);
+  }
+  printf("importance ok: %lld initial, %lld rounds, %lld hands\n", (long long)n0, (long long)nr, (long long)nh);
+  return 0;
+}
+
+// test_host_api --caffemodel <file> <out.bin>: the eight blobs, concatenated float32
+static int run_caffemodel(const char* path, const char* out_path) {
+  std::vector<float> blobs[8];
+  std::string err;
+  if (!Classifier::readCaffeModel(path, blobs, &err)) {
+    fprintf(stderr, "caffemodel: %s\n", err.c_str());
+    return 3;
+  }
+  std::ofstream out(out_path, std::ios::binary);
+  for (int b = 0; b < 8; b++) put(out, blobs[b].data(), blobs[b].size());
+  return 0;
+}
+
+// test_host_api --pcd <file> <out.bin>: int64 n, then n x (x, y, z) float32 (CloudCamera(filename))
+static int run_pcd(const char* path, const char* out_path) {
+  CloudCamera cc{std::string(path)};
+  std::ofstream out(out_path, std::ios::binary);
+  const int64_t n = (int64_t)cc.getCloudProcessed()->size();
+  put(out, &n, 1);
+  for (const ag2::PointXYZRGBA& p : cc.getCloudProcessed()->points) put(out, &p.x, 3);
+  const int64_t rows = cc.getCameraSource().rows(), cols = cc.getCameraSource().cols();
+  put(out, &rows, 1);
+  put(out, &cols, 1);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc == 5 && std::string(argv[1]) == "--preprocess") return run_preprocess(argv[2], argv[3], argv[4]);
+  if (argc == 4 && std::string(argv[1]) == "--caffemodel") return run_caffemodel(argv[2], argv[3]);
+  if (argc == 4 && std::string(argv[1]) == "--pcd") return run_pcd(argv[2], argv[3]);
+  if (argc == 6 && std::string(argv[1]) == "--importance") return run_importance(argv[2], argv[3], argv[4], argv[5]);
   if (argc != 5) {
     fprintf(stderr, "usage: %s cloud.f32 idx.i32 params.txt out.bin | --preprocess raw.f32 params.txt out.bin\n",
             argv[0]);

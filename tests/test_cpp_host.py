@@ -65,14 +65,19 @@ def params_text(ws, wpath, lpath, seed):
 
 
 @pytest.mark.gpu
-def test_cpp_host_matches_oracle(tmp_path, small_scene):
+@pytest.mark.parametrize("weights_format", ["ag2w", "caffemodel"])
+def test_cpp_host_matches_oracle(tmp_path, small_scene, weights_format):
     from oracle import api
     tmp = str(tmp_path)
     exe = build_driver(tmp)
     xyz, ws, idx = small_scene
     w = make_lenet_weights(7)
-    wpath, lpath = os.path.join(tmp, "w.ag2w"), os.path.join(tmp, "labels.txt")
-    save_ag2w(wpath, w)
+    wpath, lpath = os.path.join(tmp, "w." + weights_format), os.path.join(tmp, "labels.txt")
+    if weights_format == "ag2w":
+        save_ag2w(wpath, w)
+    else:  # Classifier's trained_file as the reference passes it (caffe_classifier.cpp:13-14)
+        from test_formats import net_new
+        open(wpath, "wb").write(net_new(w))
     open(lpath, "w").write("0\n1\n")  # caffe/labels.txt
     xyz.astype("<f4").tofile(os.path.join(tmp, "cloud.f32"))
     idx.astype("<i4").tofile(os.path.join(tmp, "idx.i32"))
@@ -259,3 +264,70 @@ def test_cpp_preprocess_then_detect_matches_oracle(tmp_path, min_inliers):
     tol = 1e-4 * max(abs(v) for v in key.values()) + 2e-3
     for s, q, sc in zip(rec["slot"].tolist(), rec["orient"].tolist(), rec["score"].tolist()):
         assert abs(sc - key[(s, q)]) <= tol
+
+
+@pytest.mark.gpu
+def test_cpp_importance_sampling_rounds_match_oracle(tmp_path, small_scene):
+    """ImportanceSampling::detectGraspPoses (importance_sampling.cpp:30-118): the initial round on the
+    sample indices, then rounds of xyz samples drawn around the grasps found so far, every round on the
+    cloud / grid / normals already resident on the GPU.  The driver dumps each round's samples; the
+    oracle, fed the same samples, must return the same hands (the xyz-sample frame path,
+    hand_search.cpp:238-317)."""
+    from oracle import api
+    tmp = str(tmp_path)
+    exe = build_driver(tmp)
+    xyz, ws, idx = small_scene
+    w = make_lenet_weights(7)
+    wpath, lpath = os.path.join(tmp, "w.ag2w"), os.path.join(tmp, "labels.txt")
+    save_ag2w(wpath, w)
+    open(lpath, "w").write("0\n1\n")
+    xyz.astype("<f4").tofile(os.path.join(tmp, "cloud.f32"))
+    idx.astype("<i4").tofile(os.path.join(tmp, "idx.i32"))
+    seed = 9
+    open(os.path.join(tmp, "params.txt"), "w").write(params_text(ws, wpath, lpath, seed))
+    outp = os.path.join(tmp, "out.bin")
+    r = subprocess.run([exe, "--importance", os.path.join(tmp, "cloud.f32"), os.path.join(tmp, "idx.i32"),
+                        os.path.join(tmp, "params.txt"), outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "importance ok" in r.stdout
+
+    buf = open(outp, "rb").read()
+    n0, nr = struct.unpack_from("<qq", buf, 0)
+    off = 16
+    rounds = []
+    for _ in range(nr):
+        (s,) = struct.unpack_from("<q", buf, off)
+        off += 8
+        rounds.append(np.frombuffer(buf, dtype="<f8", count=3 * s, offset=off).reshape(s, 3).T.copy())
+        off += 24 * s
+    (nh,) = struct.unpack_from("<q", buf, off)
+    off += 8
+    rec = np.frombuffer(buf, dtype=np.dtype([("slot", "<i4"), ("orient", "<i4"), ("score", "<f8"),
+                                             ("bottom", "<f8", 3)]), count=nh, offset=off)
+    assert nr == 3 and all(m.shape == (3, 40) for m in rounds) and n0 > 0
+
+    o = api.Oracle(**scene_params(ws, min_score_diff=-1e30, num_selected=1000, num_threads=4))
+    o.set_cloud(xyz)
+    o.compute_normals()
+    o.lenet_load(w)
+    want = [o.detect(sample_idx=idx, seed=seed)[0]] + [o.detect(sample_xyz=m, seed=seed)[0] for m in rounds]
+    assert len(want[0]) == n0
+    assert sum(len(x) for x in want) == nh and sum(len(x) for x in want[1:]) > 0
+    tol = 1e-4 * max(np.abs(x["score"]).max() for x in want if len(x)) + 2e-3
+    pos = 0
+    for x in want:  # per round: same set of hands, bit-equal positions, scores within the fp32 tolerance
+        got = rec[pos: pos + len(x)]
+        pos += len(x)
+        kg = np.lexsort((got["orient"], got["slot"]))
+        kw = np.lexsort((x["orientation"], x["sample_slot"]))
+        assert np.array_equal(got["slot"][kg], x["sample_slot"][kw])
+        assert np.array_equal(got["orient"][kg], x["orientation"][kw])
+        assert np.array_equal(got["bottom"][kg], x["bottom"][kw])
+        assert np.abs(got["score"][kg] - x["score"][kw]).max() <= tol
+    # samples: 70 % around known grasp surfaces (sigma = 0.02), 30 % cloud points (importance_sampling.cpp:50-90)
+    for m in rounds:
+        d = np.linalg.norm(m[:, 28:, None] - xyz.T[:, None, :].astype(np.float64), axis=0).min(axis=1)
+        assert np.all(d == 0.0)
+        assert np.all(np.isfinite(m))
+        lo, hi = xyz.min(axis=0) - 0.2, xyz.max(axis=0) + 0.2
+        assert np.all(m[:, :28].T > lo) and np.all(m[:, :28].T < hi)
