@@ -213,7 +213,8 @@ void ag2_destroy(ag2_ctx* c) {
                     &c->d_logits, &c->d_act1, &c->d_fcpart, &c->d_tmp, &c->d_flags, &c->d_desc,
                     &c->d_raw, &c->d_raw_nrm, &c->d_pre, &c->d_pflags, &c->d_bitmap, &c->d_wrank,
                     &c->d_first, &c->d_prestats, &c->d_hist, &c->d_samples, &c->d_cluster, &c->d_cluster_tmp, &c->net.w1p, &c->net.b1,
-                    &c->net.w2p, &c->net.b2, &c->net.w3p, &c->net.b3, &c->net.w4, &c->net.b4};
+                    &c->net.w2p, &c->net.b2, &c->net.w3p, &c->net.b3, &c->net.w4, &c->net.b4,
+                    &c->net.w1x, &c->net.w2x};
   for (DevBuf* b : bufs) b->release();
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);

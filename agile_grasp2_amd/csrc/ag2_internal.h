@@ -74,6 +74,8 @@ struct PreStats {
 struct LeNetDev {
   bool loaded = false;
   DevBuf w1p, b1, w2p, b2, w3p, b3, w4, b4;  // packed for the MFMA lane layout (k_lenet.hip)
+  DevBuf w1x, w2x;                           // conv weights split into 3 bf16 terms (k_lenet_x3.hip)
+  bool use_x3 = true;                        // false: the f32-input MFMA convolutions (AG2_LENET_F32=1)
 };
 
 }  // namespace ag2
@@ -186,6 +188,9 @@ int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned
 int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypothesis>& recs,
                    std::vector<int64_t>* offs, std::vector<uint8_t>* keep);
 int make_image_descs(ag2_ctx* c, const int* d_list, size_t n);
+// k_lenet_x3.hip
+int lenet_pack_weights_x3(ag2_ctx* c, const float* conv1_w, const float* conv2_w);
+int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_pooled2);
 // k_cluster.hip
 int cluster_async(ag2_ctx* c, const ag2_hypothesis* d_in, size_t n_max, const unsigned* d_n,
                   int min_inliers, unsigned* d_count);

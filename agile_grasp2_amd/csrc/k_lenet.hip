@@ -309,6 +309,9 @@ int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const flo
     AG2_HIP(c, hipMemcpyAsync(u.b->p, u.p, u.n * 4, hipMemcpyHostToDevice, c->stream));
   }
   AG2_HIP(c, hipStreamSynchronize(c->stream));
+  const int rc = lenet_pack_weights_x3(c, c1w, c2w);
+  if (rc) return rc;
+  d.use_x3 = getenv("AG2_LENET_F32") == nullptr;
   d.loaded = true;
   return 0;
 }
@@ -327,10 +330,15 @@ int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const int grid = (int)std::min<size_t>(n, 512);
-  hipLaunchKernelGGL(k_lenet_conv, dim3(grid), dim3(kConvThreads), lds, c->stream, d_images, (int)n,
-                     d.w1p.as<float>(), d.b1.as<float>(), d.w2p.as<float>(), d.b2.as<float>(),
-                     c->d_act1.as<float>());
+  if (d.use_x3) {  // bf16 matrix cores, operands split into three exact bf16 terms (k_lenet_x3.hip)
+    const int rc = launch_lenet_conv_x3(c, d_images, n, c->d_act1.as<float>());
+    if (rc) return rc;
+  } else {
+    const int grid = (int)std::min<size_t>(n, 512);
+    hipLaunchKernelGGL(k_lenet_conv, dim3(grid), dim3(kConvThreads), lds, c->stream, d_images, (int)n,
+                       d.w1p.as<float>(), d.b1.as<float>(), d.w2p.as<float>(), d.b2.as<float>(),
+                       c->d_act1.as<float>());
+  }
   if (ev_mid) AG2_HIP(c, hipEventRecord(ev_mid, c->stream));
   const int mtiles = (int)((n + kFcBM - 1) / kFcBM);
   const int n_pad = mtiles * kFcBM;

@@ -1,0 +1,342 @@
+// k_lenet_x3.hip -- K5 convolutions on the bf16 matrix cores with fp32-accurate split operands.
+//
+// Same layers as k_lenet.hip's k_lenet_conv (conv1 20@5x5 -> max 2/2 -> conv2 50@5x5 -> max 2/2 of
+// caffe/test_1batch2.prototxt; Classifier::PredictBatch, caffe_classifier.cpp:94-127), but every
+// fp32 operand is written as the EXACT sum of three bf16 terms (x = h + m + l, each the truncation
+// of the running remainder to 8 significant bits) and the products are formed on
+// v_mfma_f32_32x32x16_bf16 (32 cycles for 16 k, vs 64 cycles for 2 k on the f32-input form) with
+// fp32 accumulation:
+//   * conv1: the inputs are u8 pixels, exact in bf16, so  x * w = x*wh + x*wm + x*wl  holds exactly
+//     (8 bit x 8 bit products are exact in fp32): 3 MFMAs per 16 k, no approximation at all;
+//   * conv2: x * w ~ xh*wh + xh*wm + xm*wh + xm*wm + xh*wl + xl*wh; the three dropped terms are
+//     below 2^-23 |x w|, i.e. under the rounding of a single fp32 product: 6 MFMAs per 16 k.
+// Only the order of the fp32 additions differs from k_lenet_conv; both are held to the same
+// tolerance against the oracle (tests/test_gpu_lenet_detect.py).
+//
+// One 512-thread workgroup per image (one per CU: 148 KB of LDS).  The u8 image and the pooled conv1
+// map stay in LDS; the map is stored already split and channel-interleaved, so a lane's A fragment
+// needs no VALU work:
+//   pa[term][group][y * 40 + x][8]  channels 0-7 / 8-15: 8 k-values = ONE ds_read_b128
+//   pc[term][y * 48 + x][4]         channels 16-19:      4 k-values = one ds_read_b64
+// The row pitches (40 = 8 mod 16 slots of 16 B, 48 = 16 mod 32 slots of 8 B) put the two pixel
+// rows of a tile's pooling windows on disjoint LDS banks.  K order of conv2: 25 taps x channels
+// 0-15 (lanes 0-31 take channels 0-7, lanes 32-63 channels 8-15), then 7 blocks that cover four
+// taps each for channels 16-19 (half h of the wave takes taps 4i + 2h and 4i + 2h + 1).  Weights are
+// pre-split and pre-packed on the host in B-fragment order.
+#include <string.h>
+
+#include "ag2_internal.h"
+
+namespace ag2 {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kXThreads = 512;
+constexpr int kXWaves = kXThreads / 64;
+constexpr int kXImgRow = 60;
+constexpr int kXImgPlane = 61 * 60;  // one zero row appended per channel
+constexpr int kXPA = 40;             // row pitch of pa
+constexpr int kXPC = 48;             // row pitch of pc
+constexpr int kXC1Blocks = 8;        // 15 (channel, ky) rows two per block, kx 0..4 (+3 zero taps)
+constexpr int kXC2Main = 25;
+constexpr int kXC2Blocks = kXC2Main + 7;
+
+struct X3Shared {
+  unsigned short pa[3][2][28 * kXPA][8];
+  unsigned short pc[3][28 * kXPC][4];
+  unsigned char img[3 * kXImgPlane + 16];
+};
+static_assert(sizeof(X3Shared) <= 160 * 1024, "k_lenet_conv_x3: LDS");
+
+__host__ __device__ __forceinline__ void split3(float v, unsigned short t[3]) {
+  unsigned b;
+  __builtin_memcpy(&b, &v, 4);
+  const unsigned hb = b & 0xFFFF0000u;
+  float h;
+  __builtin_memcpy(&h, &hb, 4);
+  const float r1 = v - h;  // exact
+  unsigned b1;
+  __builtin_memcpy(&b1, &r1, 4);
+  const unsigned mb = b1 & 0xFFFF0000u;
+  float m;
+  __builtin_memcpy(&m, &mb, 4);
+  const float r2 = r1 - m;  // exact
+  unsigned b2;
+  __builtin_memcpy(&b2, &r2, 4);
+  t[0] = (unsigned short)(hb >> 16);
+  t[1] = (unsigned short)(mb >> 16);
+  t[2] = (unsigned short)(b2 >> 16);
+}
+
+__device__ __forceinline__ bf16x8 as_frag(const uint4& u) { return __builtin_bit_cast(bf16x8, u); }
+
+// conv2 + bias + max-pool for the NT tiles mgrp, mgrp + 4, ... of this wave, one channel half
+template <int NT>
+__device__ __forceinline__ void x3_conv2(const X3Shared& S, const uint4* __restrict__ w2x,
+                                         float* __restrict__ dst, float bias2, int nh, int mgrp,
+                                         int lane) {
+  const int h = lane >> 5, r = lane & 31;
+  const int g = r >> 2, q = r & 3;
+  v16f acc[NT];
+  int pa0[NT], pc0[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int w = 8 * (mgrp + 4 * t) + g;
+    const int wy = w / 12, wx = w - wy * 12;
+    const int y = 2 * wy + (q >> 1), x = 2 * wx + (q & 1);
+    pa0[t] = y * kXPA + x;
+    pc0[t] = y * kXPC + x;
+  }
+  const uint4* wl = w2x + (size_t)nh * 3 * 64 + lane;
+  // B fragments of block b + 1 are requested from L2 before the MFMAs of block b are issued
+  uint4 nb0 = wl[0], nb1 = wl[64], nb2 = wl[128];
+  auto mfma6 = [&](v16f a, const bf16x8& Ah, const bf16x8& Am, const bf16x8& Al, const bf16x8& Bh,
+                   const bf16x8& Bm, const bf16x8& Bl) {
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, a, 0, 0, 0);
+    return a;
+  };
+#pragma unroll 1
+  for (int b = 0; b < kXC2Main; b++) {  // rolled: one k-block's B fragments in flight at a time
+    const bf16x8 Bh = as_frag(nb0), Bm = as_frag(nb1), Bl = as_frag(nb2);
+    {
+      const uint4* wn = wl + (size_t)(b + 1) * (2 * 3 * 64);
+      nb0 = wn[0];
+      nb1 = wn[64];
+      nb2 = wn[128];
+    }
+    const int ky = b / 5, kx = b - 5 * ky;
+    const int off = ky * kXPA + kx;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int p = pa0[t] + off;
+      const bf16x8 Ah = as_frag(*reinterpret_cast<const uint4*>(&S.pa[0][h][p][0]));
+      const bf16x8 Am = as_frag(*reinterpret_cast<const uint4*>(&S.pa[1][h][p][0]));
+      const bf16x8 Al = as_frag(*reinterpret_cast<const uint4*>(&S.pa[2][h][p][0]));
+      acc[t] = mfma6(acc[t], Ah, Am, Al, Bh, Bm, Bl);
+    }
+  }
+#pragma unroll 1
+  for (int i = 0; i < kXC2Blocks - kXC2Main; i++) {
+    const bf16x8 Bh = as_frag(nb0), Bm = as_frag(nb1), Bl = as_frag(nb2);
+    {
+      const uint4* wn = wl + (size_t)min(kXC2Main + i + 1, kXC2Blocks - 1) * (2 * 3 * 64);
+      nb0 = wn[0];
+      nb1 = wn[64];
+      nb2 = wn[128];
+    }
+    // taps 4i + 2h and 4i + 2h + 1; a tap past the 25th carries zero weights and re-reads tap 24
+    const int ta = min(4 * i + 2 * h, 24), tb = min(4 * i + 2 * h + 1, 24);
+    const int offa = (ta / 5) * kXPC + ta % 5, offb = (tb / 5) * kXPC + tb % 5;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      uint4 u[3];
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(&S.pc[s][pc0[t] + offa][0]);
+        const uint2 hi = *reinterpret_cast<const uint2*>(&S.pc[s][pc0[t] + offb][0]);
+        u[s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+      acc[t] = mfma6(acc[t], as_frag(u[0]), as_frag(u[1]), as_frag(u[2]), Bh, Bm, Bl);
+    }
+  }
+  const int oc = nh * 32 + r;
+  if (oc < 50) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float m = fmaxf(fmaxf(acc[t][4 * j], acc[t][4 * j + 1]),
+                              fmaxf(acc[t][4 * j + 2], acc[t][4 * j + 3]));
+        const int wdw = 8 * (mgrp + 4 * t) + 2 * j + h;
+        dst[wdw * 50 + oc] = m + bias2;  // K' order of ip1: window-major, channel-minor
+      }
+    }
+  }
+}
+
+// conv1 + bias + max-pool for NT tiles (T0, T0 + 8, ...): 8 windows x 32 channels each; the pooled
+// values are split into three bf16 terms on the way into LDS
+template <int NT>
+__device__ __forceinline__ void x3_conv1(X3Shared& S, const uint4* __restrict__ w1x, float bias1,
+                                         int T0, int lane) {
+  const int h = lane >> 5, r = lane & 31;
+  const int g = r >> 2, q = r & 3;
+  v16f acc[NT];
+  int a0[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int w = 8 * (T0 + t * kXWaves) + g;
+    const int wy = w / 28, wx = w - wy * 28;
+    a0[t] = (2 * wy + (q >> 1)) * kXImgRow + 2 * wx + (q & 1);
+  }
+  uint4 nb0 = w1x[lane], nb1 = w1x[64 + lane], nb2 = w1x[128 + lane];
+#pragma unroll 1
+  for (int b = 0; b < kXC1Blocks; b++) {
+    const bf16x8 Bh = as_frag(nb0), Bm = as_frag(nb1), Bl = as_frag(nb2);
+    {  // next block's weights are in flight during this block's MFMAs
+      const uint4* wn = w1x + (size_t)min(b + 1, kXC1Blocks - 1) * (3 * 64) + lane;
+      nb0 = wn[0];
+      nb1 = wn[64];
+      nb2 = wn[128];
+    }
+    // image offset of this lane's (channel, ky) row; row 15 is the zero row under channel 2
+    const int rr = 2 * b + h;
+    const int cc = (rr * 13) >> 6;  // rr / 5 for rr < 16
+    const int c1off = (rr < 15) ? cc * kXImgPlane + (rr - 5 * cc) * kXImgRow
+                                : 2 * kXImgPlane + 5 * kXImgRow;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const unsigned char* px = &S.img[a0[t] + c1off];
+      // u8 -> float -> bf16 (exact): the high half of the float is the bf16
+      const unsigned f0 = __float_as_uint((float)px[0]), f1 = __float_as_uint((float)px[1]),
+                     f2 = __float_as_uint((float)px[2]), f3 = __float_as_uint((float)px[3]),
+                     f4 = __float_as_uint((float)px[4]);
+      uint4 au;
+      au.x = (f1 & 0xFFFF0000u) | (f0 >> 16);
+      au.y = (f3 & 0xFFFF0000u) | (f2 >> 16);
+      au.z = f4 >> 16;
+      au.w = 0u;
+      const bf16x8 Af = as_frag(au);
+      v16f a = acc[t];
+      a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af, Bl, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af, Bm, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af, Bh, a, 0, 0, 0);
+      acc[t] = a;
+    }
+  }
+  if (r < 20) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int T = T0 + t * kXWaves;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float m = fmaxf(fmaxf(acc[t][4 * j], acc[t][4 * j + 1]),
+                              fmaxf(acc[t][4 * j + 2], acc[t][4 * j + 3])) + bias1;
+        unsigned short s3[3];
+        split3(m, s3);
+        const int p = 8 * T + 2 * j + h;  // pooled position, row-major on the 28 x 28 map
+        const int y = p / 28, x = p - 28 * y;
+        if (r < 16) {
+#pragma unroll
+          for (int s = 0; s < 3; s++) S.pa[s][r >> 3][y * kXPA + x][r & 7] = s3[s];
+        } else {
+#pragma unroll
+          for (int s = 0; s < 3; s++) S.pc[s][y * kXPC + x][r & 3] = s3[s];
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kXThreads, 2)
+k_lenet_conv_x3(const unsigned char* __restrict__ images, int n_img, const uint4* __restrict__ w1x,
+                const float* __restrict__ b1, const uint4* __restrict__ w2x,
+                const float* __restrict__ b2, float* __restrict__ pooled2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  X3Shared& S = *reinterpret_cast<X3Shared*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31;
+  const float bias1 = b1[r];
+  const int nh = wid & 1;     // conv2: which 32 output channels
+  const int mgrp = wid >> 1;  // conv2: tiles mgrp, mgrp + 4, ...
+  const float bias2 = b2[nh * 32 + r];
+
+  for (int im = blockIdx.x; im < n_img; im += gridDim.x) {
+    __syncthreads();  // previous image's conv2 readers of the pooled map are done
+    {  // stage the image: HWC u8 -> planar u8 (+ one zero row per channel)
+      const unsigned* src = reinterpret_cast<const unsigned*>(images + (size_t)im * 10800);
+      for (int i = tid; i < 2700; i += kXThreads) {
+        const unsigned v = src[i];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const int e = i * 4 + b;  // byte index = pixel * 3 + ch
+          const int pix = e / 3, ch = e - pix * 3;
+          S.img[ch * kXImgPlane + pix] = (unsigned char)((v >> (8 * b)) & 255u);
+        }
+      }
+      if (tid < 180) S.img[(tid / 60) * kXImgPlane + 3600 + (tid % 60)] = 0;
+      if (tid < 16) S.img[3 * kXImgPlane + tid] = 0;
+    }
+    __syncthreads();
+    // conv1: 98 tiles; wave w takes tiles w, w + 8, ... (12 each, waves 0 and 1 a 13th)
+    for (int k0 = 0; k0 < 12; k0 += 4) x3_conv1<4>(S, w1x, bias1, wid + 8 * k0, lane);
+    if (wid < 2) x3_conv1<1>(S, w1x, bias1, wid + 96, lane);
+    __syncthreads();
+    // conv2: 18 tiles x 2 channel halves over 8 waves
+    {
+      float* dst = pooled2 + (size_t)im * 7200;
+      if (mgrp < 2) x3_conv2<5>(S, w2x, dst, bias2, nh, mgrp, lane);   // tiles mgrp, +4, .., +16
+      else x3_conv2<4>(S, w2x, dst, bias2, nh, mgrp, lane);            // tiles mgrp, +4, .., +12
+    }
+  }
+}
+
+// host: split and pack the conv weights in B-fragment order
+int lenet_pack_weights_x3(ag2_ctx* c, const float* c1w, const float* c2w) {
+  std::vector<unsigned short> w1x((size_t)kXC1Blocks * 3 * 64 * 8, 0), w2x((size_t)kXC2Blocks * 2 * 3 * 64 * 8, 0);
+  unsigned short s3[3];
+  for (int b = 0; b < kXC1Blocks; b++)
+    for (int l = 0; l < 64; l++) {
+      const int h = l >> 5, oc = l & 31, rr = 2 * b + h;
+      if (oc >= 20 || rr >= 15) continue;
+      const int ch = rr / 5, ky = rr % 5;
+      for (int kx = 0; kx < 5; kx++) {
+        split3(c1w[((oc * 3 + ch) * 5 + ky) * 5 + kx], s3);
+        for (int t = 0; t < 3; t++) w1x[(((size_t)b * 3 + t) * 64 + l) * 8 + kx] = s3[t];
+      }
+    }
+  for (int b = 0; b < kXC2Blocks; b++)
+    for (int nh = 0; nh < 2; nh++)
+      for (int l = 0; l < 64; l++) {
+        const int h = l >> 5, oc = nh * 32 + (l & 31);
+        if (oc >= 50) continue;
+        for (int j = 0; j < 8; j++) {
+          int ch, tap;
+          if (b < kXC2Main) {
+            ch = 8 * h + j;
+            tap = b;
+          } else {
+            tap = 4 * (b - kXC2Main) + 2 * h + (j >> 2);
+            if (tap >= 25) continue;
+            ch = 16 + (j & 3);
+          }
+          const int ky = tap / 5, kx = tap % 5;
+          split3(c2w[((oc * 20 + ch) * 5 + ky) * 5 + kx], s3);
+          for (int t = 0; t < 3; t++) w2x[((((size_t)b * 2 + nh) * 3 + t) * 64 + l) * 8 + j] = s3[t];
+        }
+      }
+  LeNetDev& d = c->net;
+  AG2_HIP(c, d.w1x.reserve(w1x.size() * 2));
+  AG2_HIP(c, d.w2x.reserve(w2x.size() * 2));
+  AG2_HIP(c, hipMemcpyAsync(d.w1x.p, w1x.data(), w1x.size() * 2, hipMemcpyHostToDevice, c->stream));
+  AG2_HIP(c, hipMemcpyAsync(d.w2x.p, w2x.data(), w2x.size() * 2, hipMemcpyHostToDevice, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_pooled2) {
+  LeNetDev& d = c->net;
+  const size_t lds = sizeof(X3Shared);
+  static bool attr_set = false;
+  if (!attr_set) {
+    AG2_HIP(c, hipFuncSetAttribute((const void*)k_lenet_conv_x3,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int grid = (int)std::min<size_t>(n, 256);
+  hipLaunchKernelGGL(k_lenet_conv_x3, dim3(grid), dim3(kXThreads), lds, c->stream, d_images, (int)n,
+                     d.w1x.as<uint4>(), d.b1.as<float>(), d.w2x.as<uint4>(), d.b2.as<float>(),
+                     d_pooled2);
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+}  // namespace ag2

@@ -284,6 +284,12 @@ struct Red {
 };
 
 constexpr int kMaxPieces = 1024;
+#ifndef AG2_SWEEP_GROUP
+#define AG2_SWEEP_GROUP 8
+#endif
+constexpr int kGrp = AG2_SWEEP_GROUP;  // lanes that share one piece in the crop passes (tuning knob)
+constexpr int kGpw = kWave / kGrp;     // pieces per wave-wide load
+static_assert(kGrp >= 4 && kGrp <= 64 && (kGrp & (kGrp - 1)) == 0, "lane group must be a power of two");
 constexpr int kRowsPerThread = (kMaxRows + kSweepThreads - 1) / kSweepThreads;
 constexpr int kPiecesPerThread = (kMaxPieces + kSweepThreads - 1) / kSweepThreads;
 
@@ -301,6 +307,7 @@ struct SweepShared {
   int wave_cnt[kSweepWaves + 1];
   long long arena_off;
   int flag;
+  unsigned dead;                 // pass A: orientations known to have a point behind the hand
 };
 
 // Cropped points resident in LDS (16 B + a 2-B in-box index each): whatever two workgroups per CU
@@ -458,7 +465,7 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
         kcand += S.red.i[0][k][0];
       }
     }
-    int PL = 32;  // piece length; grows only if the table would overflow (dense clouds)
+    int PL = kGrp;  // piece length; grows only if the table would overflow (dense clouds)
     while (kcand / PL + nrows_c > kMaxPieces) PL <<= 1;
     int n_pieces = 0;
     {
@@ -507,39 +514,40 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
       const double zf = (F[0][2] * p0 + F[1][2] * p1) + F[2][2] * p2;
       return (zf > -1.0 * hh && zf < hh) ? 3 : 1;
     };
-    // pass 1: survivors per piece.  Each HALF-wave (32 lanes) takes one piece, so one load
-    // instruction covers two pieces with 16-B-per-lane contiguous reads, and four such
+    // pass 1: survivors per piece.  A GROUP of kGrp lanes takes one piece (rows of a surface-sheet
+    // cloud hold ~8-10 candidates after the culling, so wider groups would idle most lanes), one
+    // load instruction covers 64 / kGrp pieces with 16-B-per-lane contiguous reads, and four such
     // instructions are issued before the first result is needed (the path is latency-bound).
-    const int half = lane >> 5, l31 = lane & 31;
-    const unsigned long long half_mask = half ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
-    const int n_pairs = (n_pieces + 1) >> 1;
+    const int grp = lane / kGrp, lg = lane % kGrp;
+    const unsigned long long grp_mask = ((kGrp == 64) ? ~0ull : ((1ull << kGrp) - 1ull)) << (grp * kGrp);
+    const int n_sets = (n_pieces + kGpw - 1) / kGpw;  // one set = the pieces of one wave-wide load
     int my_k2 = 0;
-    for (int pp0 = wid; pp0 < n_pairs; pp0 += 4 * kSweepWaves) {
+    for (int pp0 = wid; pp0 < n_sets; pp0 += 4 * kSweepWaves) {
       int pb[4], pl[4];
       float4 pv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int pc = 2 * (pp0 + u * kSweepWaves) + half;
+        const int pc = kGpw * (pp0 + u * kSweepWaves) + grp;
         const bool ok = pc < n_pieces;
         pb[u] = ok ? S.piece_start[pc] : 0;
         pl[u] = ok ? (int)(S.piece_lc[pc] & 0xFFFFu) : 0;
         pv[u] = make_float4(0, 0, 0, 0);
-        if (l31 < pl[u]) pv[u] = A.pts[pb[u] + l31];
+        if (lg < pl[u]) pv[u] = A.pts[pb[u] + lg];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int pc = 2 * (pp0 + u * kSweepWaves) + half;
+        const int pc = kGpw * (pp0 + u * kSweepWaves) + grp;
         float4 d;
-        int cls = (l31 < pl[u]) ? classify(pv[u], d) : 0;
-        int keep = __popcll(__ballot(cls == 3) & half_mask);
+        int cls = (lg < pl[u]) ? classify(pv[u], d) : 0;
+        int keep = __popcll(__ballot(cls == 3) & grp_mask);
         my_k2 += (cls != 0) ? 1 : 0;
-        for (int o = 32; o < pl[u]; o += 32) {  // pieces longer than 32 (dense clouds)
-          const int j = o + l31;
+        for (int o = kGrp; o < pl[u]; o += kGrp) {  // pieces longer than a group (dense clouds)
+          const int j = o + lg;
           cls = (j < pl[u]) ? classify(A.pts[pb[u] + j], d) : 0;
-          keep += __popcll(__ballot(cls == 3) & half_mask);
+          keep += __popcll(__ballot(cls == 3) & grp_mask);
           my_k2 += (cls != 0) ? 1 : 0;
         }
-        if (l31 == 0 && pc < n_pieces) S.piece_lc[pc] = (unsigned)pl[u] | ((unsigned)keep << 16);
+        if (lg == 0 && pc < n_pieces) S.piece_lc[pc] = (unsigned)pl[u] | ((unsigned)keep << 16);
       }
     }
     my_k2 = wave_sum_i(my_k2);
@@ -597,42 +605,43 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
       // K2 (all radius neighbours) is only visited when row tightening is off (debug_flags bit 0)
       if (!tighten) atomicAdd(&A.st->sum_k2, (unsigned long long)k2);
       atomicAdd(&A.st->sum_kcrop, (unsigned long long)K);
+      S.dead = 0u;  // read in pass A, two barriers further down
     }
     if (K == 0) continue;  // hand_search.cpp:201 (no neighbours) / no cropped points => no fingers
     __syncthreads();
     // pass 2: write the survivors of each piece at its offset (order within a piece preserved)
-    const unsigned long long lt_half = lt_mask & half_mask;  // lower lanes of my half-wave
-    for (int pp0 = wid; pp0 < n_pairs; pp0 += 4 * kSweepWaves) {
+    const unsigned long long lt_grp = lt_mask & grp_mask;  // lower lanes of my lane group
+    for (int pp0 = wid; pp0 < n_sets; pp0 += 4 * kSweepWaves) {
       int pb[4], pl[4], po[4];
       float4 pv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int pc = 2 * (pp0 + u * kSweepWaves) + half;
+        const int pc = kGpw * (pp0 + u * kSweepWaves) + grp;
         const bool ok = pc < n_pieces;
         const unsigned lc = ok ? S.piece_lc[pc] : 0u;
         pb[u] = ok ? S.piece_start[pc] : 0;
         pl[u] = (int)(lc & 0xFFFFu);
         po[u] = (int)(lc >> 16);
         pv[u] = make_float4(0, 0, 0, 0);
-        if (l31 < pl[u]) pv[u] = A.pts[pb[u] + l31];
+        if (lg < pl[u]) pv[u] = A.pts[pb[u] + lg];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         int dst0 = po[u];
         float4 d;
-        int j = l31;
+        int j = lg;
         int cls = (j < pl[u]) ? classify(pv[u], d) : 0;
         for (int o = 0;;) {
           const unsigned long long mask = __ballot(cls == 3);
           if (cls == 3) {
-            const int dst = dst0 + __popcll(mask & lt_half);
+            const int dst = dst0 + __popcll(mask & lt_grp);
             PX[dst] = d.x; PY[dst] = d.y; PZ[dst] = d.z;
             POS[dst] = pb[u] + j;
           }
-          dst0 += __popcll(mask & half_mask);
-          o += 32;
+          dst0 += __popcll(mask & grp_mask);
+          o += kGrp;
           if (o >= pl[u]) break;
-          j = o + l31;
+          j = o + lg;
           cls = (j < pl[u]) ? classify(A.pts[pb[u] + j], d) : 0;
         }
       }
@@ -704,43 +713,74 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
       // < 2e-5 slot spacings.  Margins: 1e-6 m on y, 1e-4 spacings (~9e-7 m) on x.
       const float mY = 1.0e-6f, eX = 1.0e-4f;
       const float invs = (float)slot_inv_step, rm1 = (float)(slot_ratio - 1.0);
-      const float baseL = (float)slot_base0, baseR = (float)slot_base1;
-      // fast classification is only set up for the usual geometry: 1 < finger width / spacing < 2
-      const bool fast_ok = (slot_span <= 2) && slot_ratio > 1.001 && slot_ratio < 1.999;
-      for (int j = tid; j < K; j += kSweepThreads) {
-        const float px = PX[j], py = PY[j], pz = PZ[j];
+      // The two finger blocks share one lattice: left slot k starts at (k - 9) spacings, right slot k
+      // at k spacings (finger_hand.cpp:9-12: fs_half = LinSpaced(10, 0, od - fw), left = fs_half -
+      // (od - fw)), so ONE position p = floor(x / spacing) serves both: left slot p + 9 for p in
+      // [-9, 0], right slot p for p in [0, 9].  (The f64 thresholds of the two blocks differ in the
+      // last ulp; a point that close to an edge takes the exact path anyway.)
+      // Only set up for the usual geometry: 1 < finger width / spacing < 2.
+      const bool fast_ok = (slot_span <= 2) && slot_ratio > 1.001 && slot_ratio < 1.999 &&
+                           __builtin_fabs((slot_base1 - slot_base0) * slot_inv_step - 9.0) < 1.0e-9;
+      // Orientations for which some point is already known to lie behind the hand (y < bottom:
+      // evaluateFingers returns with every finger blocked, finger_hand.cpp:27-38) need no further
+      // work; the set is shared across the workgroup through S.dead (an optimisation only: a late
+      // reader just does redundant work).
+      unsigned alive = (R >= 32) ? 0xFFFFFFFFu : ((1u << R) - 1u);
+      for (int j0 = 0; j0 < K; j0 += kSweepThreads) {
+        alive = (unsigned)__builtin_amdgcn_readfirstlane((int)(alive & ~S.dead));
+        if (alive == 0u) break;
+        const int j = j0 + tid;
+        const bool valid = j < K;
+        const float px = valid ? PX[j] : 0.f, py = valid ? PY[j] : 0.f, pz = valid ? PZ[j] : 0.f;
         const float u = (n0 * px + n1 * py) + n2 * pz;
         const float v = (b0 * px + b1 * py) + b2 * pz;
+        unsigned need_exact = 0;  // orientations whose estimate is too close to a threshold
+        unsigned behind = 0;      // orientations for which THIS point has y < bottom
 #pragma unroll
         for (int i = 0; i < RMAX; i++) {
-          if (i < R) {
+          if (i < R && ((alive >> i) & 1u)) {  // wave-uniform
             const float cf = S.cosf_t[i], sf = S.sinf_t[i];
             const float xa = cf * u + sf * v, ya = cf * v - sf * u;
             const bool near_y = (__builtin_fabsf(ya - top0f) < mY) | (__builtin_fabsf(ya - bot0f) < mY);
-            bool near = false;  // near a slot edge (matters only for points below the fingertips)
-            unsigned bits = 0;
-#pragma unroll
-            for (int blk = 0; blk < 2; blk++) {
-              float rel = (xa - (blk ? baseR : baseL)) * invs;
-              rel = __builtin_fminf(__builtin_fmaxf(rel, -4.5f), 14.5f);
-              const float kff = __builtin_floorf(rel);
-              const float frac = rel - kff;
-              const int kf = (int)kff;
-              near |= (frac < eX) | (frac > 1.f - eX) | (__builtin_fabsf(frac - rm1) < eX);
-              // slot kf holds x (0 < frac < 1 < width); slot kf - 1 holds it iff frac + 1 < width
-              bits |= ((unsigned)kf < 10u) ? (1u << ((blk * 10 + kf) & 31)) : 0u;
-              bits |= ((frac < rm1) & ((unsigned)(kf - 1) < 10u)) ? (1u << ((blk * 10 + kf - 1) & 31)) : 0u;
-            }
+            float rel = xa * invs;
+            rel = __builtin_fminf(__builtin_fmaxf(rel, -13.5f), 13.5f);
+            const float kff = __builtin_floorf(rel);
+            const float frac = rel - kff;
+            const int kb = (int)kff + 9;  // bit of position p in the 19-bit position mask
+            const bool near = (frac < eX) | (frac > 1.f - eX) | (__builtin_fabsf(frac - rm1) < eX);
+            // position p holds x (0 < frac < 1 < width); position p - 1 holds it iff frac + 1 < width
+            unsigned pm = ((unsigned)kb < 19u) ? (1u << (kb & 31)) : 0u;
+            pm |= ((frac < rm1) & ((unsigned)(kb - 1) < 19u)) ? (1u << ((kb - 1) & 31)) : 0u;
             const bool below = ya < top0f;
             if (fast_ok && !near_y && !(near && below)) {
-              if (below) {
-                flg_acc[i] |= (ya < bot0f) ? 3u : 1u;
-                blk_acc[i] |= bits;
+              if (below && valid) {
+                const bool bh = ya < bot0f;
+                flg_acc[i] |= bh ? 3u : 1u;
+                behind |= bh ? (1u << i) : 0u;
+                blk_acc[i] |= (pm & 0x3FFu) | ((pm >> 9) << 10);
               }
-            } else {
-              exact_A(i, px, py, pz, flg_acc[i], blk_acc[i]);
+            } else if (valid) {
+              need_exact |= 1u << i;
             }
           }
+        }
+        // the rare exact evaluations sit outside the unrolled loop: one copy of the f64 code
+        while (need_exact) {
+          const int ie = __ffs((int)need_exact) - 1;
+          need_exact &= need_exact - 1u;
+          unsigned flg = 0, bits = 0;
+          exact_A(ie, px, py, pz, flg, bits);
+          behind |= (flg & 2u) ? (1u << ie) : 0u;
+#pragma unroll
+          for (int i = 0; i < RMAX; i++) {
+            flg_acc[i] |= (i == ie) ? flg : 0u;
+            blk_acc[i] |= (i == ie) ? bits : 0u;
+          }
+        }
+        const unsigned newly = wave_or_u(behind);
+        if (newly) {
+          alive &= ~newly;
+          if (lane == 0) atomicOr(&S.dead, newly);
         }
       }
     }

@@ -44,6 +44,10 @@ PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 CONV_FLOP = 2.0 * (20 * 56 * 56 * 75 + 50 * 24 * 24 * 500)   # 38.208 MFLOP / image
 FC_FLOP = 2.0 * (500 * 7200 + 2 * 500)                        # 7.202 MFLOP / image
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16)
+# k_lenet_conv_x3: v_mfma_f32_32x32x16_bf16 issued per image = conv1 98 tiles x 8 k-blocks x 3 terms
+# + conv2 18 tiles x 2 channel halves x 32 k-blocks x 6 terms; 32*32*16*2 flop each
+CONV_X3_ISSUED_FLOP = (98 * 8 * 3 + 18 * 2 * 32 * 6) * 32768.0
 
 
 def launch_params(ws, R):
@@ -217,7 +221,15 @@ def main():
                         ms=ms["sweep_ms"] + ms["sweep_overflow_ms"]),  # both instantiations
         "k_render": dict(bound="hbm", work=c.sum_p * 24 * (n_img / max(1, c.n_hypotheses)) + n_img * 10800,
                          ms=ms["render_ms"]),
-        "k_lenet_conv": dict(bound="mfma", work=n_img * CONV_FLOP, ms=ms["lenet_conv_ms"]),
+        # the convolutions run on the bf16 matrix cores with every fp32 operand split into three exact
+        # bf16 terms (k_lenet_x3.hip): priced by the bf16 MFMA work actually ISSUED (3 terms for conv1,
+        # 6 for conv2, padding included) against the dense bf16 peak; AG2_LENET_F32=1 selects the
+        # f32-input MFMA kernel, priced by the useful fp32 flops against the fp32 MFMA peak
+        "k_lenet_conv": (dict(bound="mfma", work=n_img * CONV_FLOP, ms=ms["lenet_conv_ms"])
+                         if os.environ.get("AG2_LENET_F32") else
+                         dict(bound="mfma", work=n_img * CONV_X3_ISSUED_FLOP, ms=ms["lenet_conv_ms"],
+                              peak=PEAK_BF16_MFMA_TFLOPS,
+                              fp32_equivalent_tflops=n_img * CONV_FLOP / (ms["lenet_conv_ms"] * 1e-3) / 1e12)),
         "k_lenet_fc": dict(bound="mfma", work=n_img * FC_FLOP, ms=ms["lenet_fc_ms"]),
     }
     for k in kernels.values():
@@ -226,7 +238,7 @@ def main():
             k["peak"], k["unit"] = PEAK_HBM_GBS, "GB/s"
         else:
             k["achieved"] = k["work"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-            k["peak"], k["unit"] = PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+            k["peak"], k["unit"] = k.get("peak", PEAK_F32_MFMA_TFLOPS), "TFLOP/s"
         k["frac"] = k["achieved"] / k["peak"]
     dom = max(kernels, key=lambda n: kernels[n]["ms"])
     # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of the same command
@@ -245,15 +257,21 @@ def main():
                 "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
                 "traffic": traffic, "launch_ms": kernels[dom]["ms"],
                 "algorithmic_work_per_launch": kernels[dom]["work"],
-                "all_kernels": {n: {"ms": round(k["ms"], 4), "achieved": round(k["achieved"], 3),
-                                    "unit": k["unit"], "frac": round(k["frac"], 4)}
+                "all_kernels": {n: dict({"ms": round(k["ms"], 4), "achieved": round(k["achieved"], 3),
+                                         "unit": k["unit"], "peak": k["peak"], "frac": round(k["frac"], 4)},
+                                        **({"fp32_equivalent_tflops": round(k["fp32_equivalent_tflops"], 2)}
+                                           if "fp32_equivalent_tflops" in k else {}))
                                 for n, k in kernels.items()}}
     out = {
         "metric": "grasp hypotheses scored/sec on 300k-pt cloud; end-to-end detect latency",
         "value": total_scored / elapsed, "unit": "hypotheses/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64 geometry + f32 LeNet (fp32 MFMA)", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": ("f64 geometry + f32 LeNet (fp32 MFMA)" if os.environ.get("AG2_LENET_F32") else
+                  "f64 geometry + f32 LeNet (convolutions: fp32 operands as 3 exact bf16 terms on bf16 MFMA, "
+                  "fp32 accumulate; inner products: fp32 MFMA)"),
+        "data": "synthetic",
         "config": {
             "workload": (f"{args.config}: {xyz.shape[0]}-pt {'voxelised (3 mm)' if voxelised else 'un-voxelised'} "
                          f"synthetic tabletop cloud, num_samples={S}/GPU, {R} orientations, launch-file hand "

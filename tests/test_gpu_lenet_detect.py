@@ -160,3 +160,31 @@ def test_missing_state_errors():
     with pytest.raises(RuntimeError):
         d.detect(sample_idx=np.arange(5, dtype=np.int32))               # no weights
     d.close()
+
+
+def test_split_bf16_convolutions_are_as_accurate_as_the_fp32_mfma_path(monkeypatch):
+    """k_lenet_conv_x3 writes every fp32 operand as three exact bf16 terms and multiplies on the bf16
+    matrix cores (conv1: exact products; conv2: terms below 2^-23 |x w| dropped).  Its deviation from
+    the oracle (sequential fp32) must be of the size of the f32-input MFMA kernel's own deviation --
+    both only re-order fp32 additions -- and far inside the tolerance the other tests use."""
+    from agile_grasp2_amd import capi
+    from oracle import api
+    rng = np.random.default_rng(3)
+    imgs = random_images(rng, 300)
+    w = make_lenet_weights(9)
+    o = api.Oracle()
+    o.lenet_load(w)
+    want = o.lenet_forward(imgs).astype(np.float64)
+    err = {}
+    for mode in ("x3", "f32"):
+        if mode == "f32":
+            monkeypatch.setenv("AG2_LENET_F32", "1")
+        else:
+            monkeypatch.delenv("AG2_LENET_F32", raising=False)
+        d = capi.Detector()
+        d.lenet_load(w)  # the environment is read when the weights are packed
+        err[mode] = np.abs(d.lenet_forward(imgs).astype(np.float64) - want).max()
+        d.close()
+    scale = np.abs(want).max()
+    assert err["f32"] <= 2e-5 * scale and err["x3"] <= 2e-5 * scale, (err, scale)
+    assert err["x3"] <= 4.0 * err["f32"] + 1e-6 * scale, (err, scale)
