@@ -114,6 +114,19 @@ int collect_normals_stats(ag2_ctx* c) {
   return 0;
 }
 
+int pin_reserve(ag2_ctx* c, size_t bulk_bytes) {
+  const size_t need = kPinSmall + bulk_bytes;
+  if (need <= c->h_pin_bytes) return 0;
+  if (c->stream) AG2_HIP(c, hipStreamSynchronize(c->stream));  // nothing may still be copying
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  c->h_pin = nullptr;
+  c->h_pin_bytes = 0;
+  const size_t want = need + need / 2 + 65536;
+  AG2_HIP(c, hipHostMalloc(&c->h_pin, want, hipHostMallocDefault));
+  c->h_pin_bytes = want;
+  return 0;
+}
+
 // d_xyz_in / n hold a new cloud: drop everything derived from the previous one, build the grid.
 int after_cloud(ag2_ctx* c) {
   memset(&c->cnt, 0, sizeof(c->cnt));
@@ -194,7 +207,8 @@ ag2_ctx* ag2_create(const ag2_params* p, int device_id) {
   c->own_stream = true;
   for (auto& e : c->ev) (void)hipEventCreate(&e);
   derive_constants(c);
-  if (c->d_stats.reserve(sizeof(DevStats)) != hipSuccess || upload_constants(c) != 0) {
+  if (c->d_stats.reserve(sizeof(DevStats)) != hipSuccess || upload_constants(c) != 0 ||
+      pin_reserve(c, (size_t)1 << 20) != 0) {
     fprintf(stderr, "ag2_create: device allocation failed\n");
     ag2_destroy(c);
     return nullptr;
@@ -216,6 +230,7 @@ void ag2_destroy(ag2_ctx* c) {
                     &c->net.w2p, &c->net.b2, &c->net.w3p, &c->net.b3, &c->net.w4, &c->net.b4,
                     &c->net.w1x, &c->net.w2x};
   for (DevBuf* b : bufs) b->release();
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -302,7 +317,10 @@ int ag2_compute_normals(ag2_ctx* c) {
   if (!c->has_cloud) return set_err(c, AG2_ERR_STATE, "no cloud set");
   // asynchronous: the kernel time and the K1 counter are collected at the next point that
   // synchronises anyway (ag2::collect_normals_stats)
-  AG2_HIP(c, hipMemsetAsync((char*)c->d_stats.p + offsetof(DevStats, sum_k1), 0, 8, c->stream));
+  // sum_k1 was zeroed with the rest of the per-cloud block when the grid was built (k_init_stats);
+  // only a repeated call on the same cloud has to clear it again
+  if (c->has_normals)
+    AG2_HIP(c, hipMemsetAsync((char*)c->d_stats.p + offsetof(DevStats, sum_k1), 0, 8, c->stream));
   AG2_HIP(c, hipEventRecord(c->ev[9], c->stream));
   const int rc = launch_normals(c);
   if (rc) return rc;

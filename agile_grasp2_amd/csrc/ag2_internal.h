@@ -146,6 +146,10 @@ struct ag2_ctx {
   ag2::DevBuf d_cluster;   // ag2_hypothesis: clustered hands, compacted (k_cluster.hip)
   ag2::DevBuf d_cluster_tmp;  // ag2_hypothesis: moved hands before the compaction
   int min_inliers = 0;     // HandleSearch::setMinInliers; 0 = no clustering inside ag2_detect
+  // page-locked host staging (small read-backs, sample indices, result records): copies from / to it
+  // are true asynchronous DMA, so the host keeps enqueueing while the GPU works
+  void* h_pin = nullptr;
+  size_t h_pin_bytes = 0;
   std::vector<ag2_hypothesis> h_hyps;   // compacted hypotheses of the last generate call
   std::vector<int32_t> h_slots;         // their slot ids
   std::vector<int64_t> h_offsets;       // their arena offsets
@@ -170,6 +174,12 @@ int set_err(ag2_ctx* c, int code, const std::string& msg);
 // ag2_context.hip
 int collect_normals_stats(ag2_ctx* c);
 int after_cloud(ag2_ctx* c);
+// page-locked staging of at least `bytes` (+ kPinSmall bytes in front for small read-backs); growing
+// synchronises the stream first.  Layout: [0, kPinSmall) small area, [kPinSmall, ...) bulk area.
+constexpr size_t kPinSmall = 4096;
+int pin_reserve(ag2_ctx* c, size_t bulk_bytes);
+inline char* pin_small(ag2_ctx* c) { return (char*)c->h_pin; }
+inline char* pin_bulk(ag2_ctx* c) { return (char*)c->h_pin + kPinSmall; }
 // k_grid.hip
 int build_grid(ag2_ctx* c);
 int gather_normals(ag2_ctx* c);  // d_tmp (float4, original order) -> d_nrm (sorted order)

@@ -31,8 +31,9 @@ int reset_stats(ag2_ctx* c) {
 }
 
 int read_stats(ag2_ctx* c, DevStats* hs) {
-  AG2_HIP(c, hipMemcpyAsync(hs, c->d_stats.p, sizeof(DevStats), hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipMemcpyAsync(pin_small(c), c->d_stats.p, sizeof(DevStats), hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
+  memcpy(hs, pin_small(c), sizeof(DevStats));
   return 0;
 }
 
@@ -308,21 +309,28 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   AG2_HIP(c, hipEventRecord(c->ev[7], c->stream));
   std::vector<ag2_hypothesis> anti;
   {
+    // The records are followed by their count (trailer written by the gather / cluster kernel), so
+    // for the usual small lists ONE copy into page-locked memory brings both.
     unsigned n_anti = 0;
-    const bool small = n_img * sizeof(ag2_hypothesis) <= ((size_t)2 << 20);
+    const size_t rec_bytes = n_img * sizeof(ag2_hypothesis);
+    const bool small = rec_bytes <= ((size_t)2 << 20);
     if (small && n_img) {
-      anti.resize(n_img);
-      AG2_HIP(c, hipMemcpyAsync(anti.data(), d_res, n_img * sizeof(ag2_hypothesis),
-                                hipMemcpyDeviceToHost, c->stream));
-    }
-    AG2_HIP(c, hipMemcpyAsync(&n_anti, d_nres, 4, hipMemcpyDeviceToHost, c->stream));
-    AG2_HIP(c, hipStreamSynchronize(c->stream));
-    if (!small && n_anti) {
+      rc = pin_reserve(c, rec_bytes + 16);
+      if (rc) return rc;
+      AG2_HIP(c, hipMemcpyAsync(pin_bulk(c), d_res, rec_bytes + 4, hipMemcpyDeviceToHost, c->stream));
+      AG2_HIP(c, hipStreamSynchronize(c->stream));
+      memcpy(&n_anti, pin_bulk(c) + rec_bytes, 4);
       anti.resize(n_anti);
-      AG2_HIP(c, hipMemcpy(anti.data(), d_res, (size_t)n_anti * sizeof(ag2_hypothesis),
-                           hipMemcpyDeviceToHost));
+      if (n_anti) memcpy(anti.data(), pin_bulk(c), (size_t)n_anti * sizeof(ag2_hypothesis));
+    } else {
+      AG2_HIP(c, hipMemcpyAsync(pin_small(c), d_nres, 4, hipMemcpyDeviceToHost, c->stream));
+      AG2_HIP(c, hipStreamSynchronize(c->stream));
+      memcpy(&n_anti, pin_small(c), 4);
+      anti.resize(n_anti);
+      if (n_anti)
+        AG2_HIP(c, hipMemcpy(anti.data(), d_res, (size_t)n_anti * sizeof(ag2_hypothesis),
+                             hipMemcpyDeviceToHost));
     }
-    anti.resize(n_anti);
   }
   // 5. top num_selected by score, descending (grasp_detector.cpp:239-252); ties by position
   std::stable_sort(anti.begin(), anti.end(),

@@ -107,7 +107,10 @@ __global__ void k_cluster_scatter(const ag2_hypothesis* __restrict__ moved,
                                   const unsigned* __restrict__ pref, int n_max,
                                   ag2_hypothesis* __restrict__ out, unsigned* __restrict__ n_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *n_out = pref[n_max];
+  if (i == 0) {
+    *n_out = pref[n_max];
+    *reinterpret_cast<unsigned*>(out + n_max) = pref[n_max];  // trailer: one copy brings records + count
+  }
   if (i >= n_max) return;
   const unsigned p = pref[i];
   if (pref[i + 1] != p) out[p] = moved[i];
@@ -116,7 +119,7 @@ __global__ void k_cluster_scatter(const ag2_hypothesis* __restrict__ moved,
 // d_in: up to n_max records, *d_n of them valid.  Result: d_cluster (records), *d_count.
 int cluster_async(ag2_ctx* c, const ag2_hypothesis* d_in, size_t n_max, const unsigned* d_n,
                   int min_inliers, unsigned* d_count) {
-  AG2_HIP(c, c->d_cluster.reserve(std::max<size_t>(n_max, 1) * sizeof(ag2_hypothesis)));
+  AG2_HIP(c, c->d_cluster.reserve(std::max<size_t>(n_max, 1) * sizeof(ag2_hypothesis) + 16));
   AG2_HIP(c, c->d_cluster_tmp.reserve(std::max<size_t>(n_max, 1) * sizeof(ag2_hypothesis)));
   AG2_HIP(c, c->d_flags.reserve((n_max + 1) * 4));
   if (n_max == 0) {

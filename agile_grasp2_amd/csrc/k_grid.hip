@@ -213,8 +213,9 @@ int build_grid(ag2_ctx* c) {
   const int nb = std::min((n + 255) / 256, 512);
   hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, c->stream, xyz, n, st);
   DevStats hs;
-  AG2_HIP(c, hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipMemcpyAsync(pin_small(c), st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
+  __builtin_memcpy(&hs, pin_small(c), sizeof(hs));
   c->n_valid = hs.bounds[6];
   if (c->n_valid == 0) return 0;
   GridDesc g{};
@@ -233,15 +234,16 @@ int build_grid(ag2_ctx* c) {
   g.n_valid = (int)c->n_valid;
   c->grid = g;
   AG2_HIP(c, c->d_key.reserve((size_t)n * 4));
-  AG2_HIP(c, c->d_cell.reserve(((size_t)ncells + 1) * 4));
-  AG2_HIP(c, c->d_fill.reserve(((size_t)ncells + 1) * 4));
+  // cell_start and the per-cell cursors share one buffer so that ONE fill (a multiple of 16 bytes:
+  // no tail kernel) clears both
+  const size_t cell_words = (((size_t)ncells + 1) + 3) & ~size_t(3);
+  AG2_HIP(c, c->d_cell.reserve(2 * cell_words * 4));
   AG2_HIP(c, c->d_perm.reserve((size_t)n * 4));
   AG2_HIP(c, c->d_sorted.reserve((size_t)n * 16));
   AG2_HIP(c, c->d_nrm.reserve((size_t)n * 16));
   unsigned* cell = c->d_cell.as<unsigned>();
-  unsigned* fill = c->d_fill.as<unsigned>();
-  AG2_HIP(c, hipMemsetAsync(cell, 0, ((size_t)ncells + 1) * 4, c->stream));
-  AG2_HIP(c, hipMemsetAsync(fill, 0, ((size_t)ncells + 1) * 4, c->stream));
+  unsigned* fill = cell + cell_words;
+  AG2_HIP(c, hipMemsetAsync(cell, 0, 2 * cell_words * 4, c->stream));
   const int g256 = (n + 255) / 256;
   hipLaunchKernelGGL(k_cell_count, dim3(g256), dim3(256), 0, c->stream, xyz, n, g,
                      c->d_key.as<int>(), cell);

@@ -91,7 +91,10 @@ __global__ void k_gather_selected(const unsigned* __restrict__ pref, const int* 
                                   int n, const ag2_hypothesis* __restrict__ table,
                                   ag2_hypothesis* __restrict__ out, unsigned* __restrict__ count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *count = pref[n];
+  if (i == 0) {
+    *count = pref[n];
+    *reinterpret_cast<unsigned*>(out + n) = pref[n];  // trailer: one copy brings records + count
+  }
   if (i >= n) return;
   if (pref[i + 1] != pref[i]) {
     ag2_hypothesis h = table[list[i]];
@@ -107,7 +110,7 @@ int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned
     return 0;
   }
   AG2_HIP(c, c->d_flags.reserve((n_img + 1) * 4));
-  AG2_HIP(c, c->d_tmp.reserve(n_img * sizeof(ag2_hypothesis)));
+  AG2_HIP(c, c->d_tmp.reserve(n_img * sizeof(ag2_hypothesis) + 16));  // + the count trailer
   unsigned* fl = c->d_flags.as<unsigned>();
   const int nb = ((int)n_img + 1 + 255) / 256;
   hipLaunchKernelGGL(k_score_flags, dim3(nb), dim3(256), 0, c->stream, c->d_logits.as<float>(), d_list,

@@ -1105,12 +1105,17 @@ int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
   AG2_HIP(c, c->d_frames.reserve(std::max<size_t>(s, 1) * 12 * 8));
   AG2_HIP(c, c->d_frame_ok.reserve(std::max<size_t>(s, 1) * 4));
   if (s == 0) return 0;
-  AG2_HIP(c, hipMemsetAsync(c->d_frame_ok.p, 0, s * 4, c->stream));
+  // (frame_ok needs no clearing: k_frames writes it for every sample)
   if (sample_idx || !sample_xyz) {
     const int* d_idx = c->d_samples.as<int>();  // left by ag2_subsample_uniformly
     if (sample_idx) {
+      // through page-locked staging: the copy is a real asynchronous DMA, so the host goes on
+      // enqueueing the frames / sweep kernels while k_normals is still running
       AG2_HIP(c, c->d_tmp.reserve(s * 4));
-      AG2_HIP(c, hipMemcpyAsync(c->d_tmp.p, sample_idx, s * 4, hipMemcpyHostToDevice, c->stream));
+      const int rc = pin_reserve(c, s * 4);
+      if (rc) return rc;
+      __builtin_memcpy(pin_bulk(c), sample_idx, s * 4);
+      AG2_HIP(c, hipMemcpyAsync(c->d_tmp.p, pin_bulk(c), s * 4, hipMemcpyHostToDevice, c->stream));
       d_idx = c->d_tmp.as<int>();  // consumed before d_tmp can be reused: same stream
     }
     hipLaunchKernelGGL(k_sample_queries_idx, dim3(((unsigned)s + 255) / 256), dim3(256), 0, c->stream,
