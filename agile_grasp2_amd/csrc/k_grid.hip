@@ -165,18 +165,44 @@ __global__ void k_scatter(const int* __restrict__ key, int n, const unsigned* __
 // Within a cell the scatter order is whatever the atomics produced; restore ascending original
 // index so the layout is deterministic ((key, index) order).  Cells hold ~10-30 points on a 3 mm
 // voxel cloud: one thread per cell, insertion sort.
-__global__ void k_cell_sort(const unsigned* __restrict__ cell, int ncells, int* __restrict__ perm) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncells) return;
-  const int b = (int)cell[c], e = (int)cell[c + 1];
-  for (int i = b + 1; i < e; i++) {
-    const int v = perm[i];
-    int j = i - 1;
-    while (j >= b && perm[j] > v) {
-      perm[j + 1] = perm[j];
-      j--;
+// The 256 cells of a workgroup own one contiguous span of perm: it is staged in LDS (coalesced load
+// and store), so the dependent compares and moves of the insertion sorts never touch global memory.
+constexpr int kSortStage = 6144;
+__global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ cell, int ncells,
+                                                   int* __restrict__ perm) {
+  __shared__ int stage[kSortStage];
+  const int c0 = blockIdx.x * 256, c = c0 + threadIdx.x;
+  const int lo = (int)cell[c0], hi = (int)cell[min(c0 + 256, ncells)];
+  const int b = (c < ncells) ? (int)cell[c] : 0, e = (c < ncells) ? (int)cell[c + 1] : 0;
+  if ((hi - lo) <= kSortStage) {  // uniform: LDS path (ds_ instructions, no generic pointers)
+    for (int i = lo + threadIdx.x; i < hi; i += 256) stage[i - lo] = perm[i];
+    __syncthreads();
+    const int sb = b - lo, se = e - lo;
+    for (int i = sb + 1; i < se; i++) {
+      const int v = stage[i];
+      int j = i - 1;
+      while (j >= sb) {
+        const int u = stage[j];
+        if (!(u > v)) break;
+        stage[j + 1] = u;
+        j--;
+      }
+      stage[j + 1] = v;
     }
-    perm[j + 1] = v;
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += 256) perm[i] = stage[i - lo];
+  } else {  // dense cells: in place in global memory
+    for (int i = b + 1; i < e; i++) {
+      const int v = perm[i];
+      int j = i - 1;
+      while (j >= b) {
+        const int u = perm[j];
+        if (!(u > v)) break;
+        perm[j + 1] = u;
+        j--;
+      }
+      perm[j + 1] = v;
+    }
   }
 }
 
@@ -210,7 +236,7 @@ int build_grid(ag2_ctx* c) {
   c->grid = GridDesc{};
   if (n == 0) return 0;
   const float4* xyz = c->d_xyz_in.as<float4>();
-  const int nb = std::min((n + 255) / 256, 512);
+  const int nb = std::min((n + 255) / 256, 128);  // 7 contended atomics per workgroup: keep them few
   hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, c->stream, xyz, n, st);
   DevStats hs;
   AG2_HIP(c, hipMemcpyAsync(pin_small(c), st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));

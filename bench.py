@@ -250,7 +250,10 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get(args.config, {}).get(dom)
+            per_kernel = json.load(open(pmc_path)).get(args.config, {})
+            traffic = per_kernel.get(dom)
+            if dom == "k_sweep" and traffic is not None:  # both instantiations, like the duration
+                traffic += per_kernel.get("k_sweep_overflow", 0)
         except Exception:
             traffic = None
     roofline = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
