@@ -2,14 +2,17 @@
 //
 // Replaces Learning::createGraspImages / convertToImageRGB (src/agile_grasp2/learning.cpp:4-33,
 // :143-209) and the convertTo(CV_8UC3, 255.0) at :16.  The reference scans all P points for each of
-// the 3600 cells; here every cell is owned by one thread (cell % 256), which adds the normals of
-// its points in list order -- the same per-cell summation order as the reference's inner loop, with
-// no atomics, so the f64 sums (and therefore the bytes) are deterministic.
+// the 3600 cells; here the per-cell f64 sums are formed in the SAME order (list order within a cell)
+// without atomics, so the bytes are deterministic and equal to the oracle's.
 //
-// One 256-thread workgroup per image.  The image is accumulated in two halves of 30 rows so that the
-// f64 accumulators take 43 KB instead of 86 KB and two workgroups fit a CU (76 KB each): 1800 x 3
-// f64 accumulators, a 4096-entry chunk of cell ids, the packed pre-dilation image and the staged
-// output.  Quantisation to u8 happens BEFORE the 3x3 dilate: v -> sat(rint(255 v)) is monotone, so
+// k_render_sparse (P <= 1024, the usual case: P ~ 250 << 3600 cells): every point finds, among the
+// earlier points, how many share its cell (its rank) and the first that does (the cell's leader).
+// Round r then adds the normals of all rank-r points to their leader's accumulator -- distinct
+// cells within a round, list order across rounds -- and only the leaders quantise a pixel.  43 KB of
+// LDS: three workgroups per CU.
+// k_render (any P): every cell is owned by one thread (cell % 256) which adds the normals of its
+// points in list order; two passes of 30 image rows, 76 KB of LDS.
+// Quantisation to u8 happens BEFORE the 3x3 dilate: v -> sat(rint(255 v)) is monotone, so
 // max-then-quantise == quantise-then-max, bit for bit.
 #include "ag2_internal.h"
 
@@ -19,6 +22,7 @@ constexpr int kImgThreads = 256;
 constexpr int kCidChunk = 4096;
 constexpr int kCells = kImg * kImg;
 constexpr int kHalfCells = kCells / 2;
+constexpr int kSparseMax = 1024;  // points per image the sparse kernel takes
 
 struct ImgShared {
   double acc[kHalfCells * 3];
@@ -29,33 +33,108 @@ struct ImgShared {
 };
 static_assert(sizeof(ImgShared) * 2 <= 160 * 1024, "k_render: two workgroups per CU");
 
+// learning.cpp:152-156: cell = floor(x / cellsize) + floor((y - min y) / cellsize) * 60; ids outside
+// 0..3599 are dropped, x-cells >= 60 alias into the next row (replicated)
+__device__ __forceinline__ short cell_id(double ux, double uy, double miny) {
+  const double cellsize = 1.0 / (double)kImg;
+  const double fx = __builtin_floor(ux / cellsize);
+  const double fy = __builtin_floor((uy - miny) / cellsize);
+  if (__builtin_fabs(fx) < 1.0e9 && __builtin_fabs(fy) < 1.0e9) {
+    const long long cl = (long long)fx + (long long)fy * kImg;
+    if (cl >= 0 && cl < kCells) return (short)cl;
+  }
+  return (short)-1;
+}
+
+// :181-190 avg <- |avg / ||avg|||, then convertTo(.., 255.0) (:16) with cvRound (half to even),
+// channels packed b0 | b1 << 8 | b2 << 16.  An all-zero sum gives the 0/0 -> NaN -> 0 pixel.
+__device__ __forceinline__ unsigned quantise(double ax, double ay, double az) {
+  unsigned packed = 0;
+  if (ax != 0.0 || ay != 0.0 || az != 0.0) {
+    const double s = 1.0 / __builtin_sqrt((ax * ax + ay * ay) + az * az);
+    const double v[3] = {__builtin_fabs(s * ax), __builtin_fabs(s * ay), __builtin_fabs(s * az)};
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      const float f = (float)v[ch];
+      const float tq = f * 255.0f;
+      unsigned u = 0;
+      if (tq == tq) {
+        const float r = __builtin_rintf(tq);
+        u = (unsigned)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+      }
+      packed |= u << (8 * ch);
+    }
+  }
+  return packed;
+}
+
+// :202-203 3x3 rect dilate (border taps ignored), :206 BGR2RGB swap; staged so that the global
+// store is coalesced dwords
+__device__ __forceinline__ void dilate_store(const unsigned* __restrict__ pix,
+                                             unsigned char* __restrict__ obuf,
+                                             unsigned char* __restrict__ out_img, int tid) {
+  for (int p = tid; p < kCells; p += kImgThreads) {
+    const int r = p / kImg, cc = p % kImg;
+    unsigned m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+    for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
+      for (int dc = -1; dc <= 1; dc++) {
+        const int rr = r + dr, c2 = cc + dc;
+        if (rr >= 0 && rr < kImg && c2 >= 0 && c2 < kImg) {
+          const unsigned v = pix[rr * kImg + c2];
+          m0 = max(m0, v & 255u);
+          m1 = max(m1, (v >> 8) & 255u);
+          m2 = max(m2, (v >> 16) & 255u);
+        }
+      }
+    obuf[p * 3 + 2] = (unsigned char)m0;
+    obuf[p * 3 + 1] = (unsigned char)m1;
+    obuf[p * 3 + 0] = (unsigned char)m2;
+  }
+  __syncthreads();
+  unsigned* dst = reinterpret_cast<unsigned*>(out_img);
+  const unsigned* src = reinterpret_cast<const unsigned*>(obuf);
+  for (int i = tid; i < kCells * 3 / 4; i += kImgThreads) dst[i] = src[i];
+}
+
+__device__ __forceinline__ double block_min_y(const double* __restrict__ pts, int P, double* red, int tid) {
+  double miny = __builtin_inf();  // learning.cpp:148-149  y <- y - min y
+  for (int b = tid; b < P; b += kImgThreads) {
+    const double y = pts[(size_t)b * 6 + 1];
+    miny = (y < miny) ? y : miny;
+  }
+  miny = wave_min_d(miny);
+  if (lane_id() == 0) red[wave_id()] = miny;
+  __syncthreads();
+  miny = red[0];
+#pragma unroll
+  for (int k = 1; k < kImgThreads / kWave; k++) miny = (red[k] < miny) ? red[k] : miny;
+  return miny;
+}
+
 __global__ void __launch_bounds__(kImgThreads) k_render(const double* __restrict__ arena,
                                                         const long long* __restrict__ desc_off,
                                                         const int* __restrict__ desc_cnt, int n_img,
-                                                        unsigned char* __restrict__ out) {
+                                                        int p_min, unsigned char* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ImgShared& S = *reinterpret_cast<ImgShared*>(smem_raw);
-  const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+  const int tid = threadIdx.x;
+  {  // nothing to do for this workgroup (the usual case: the sparse kernel took every image)?
+    bool any = false;
+    for (int im = blockIdx.x; im < n_img; im += gridDim.x)
+      any = any || (desc_off[im] >= 0 && desc_cnt[im] >= p_min);
+    if (!any) return;  // uniform
+  }
   // accumulators are zeroed once; every quantisation pass re-zeroes the cells it consumed
   for (int i = tid; i < kHalfCells * 3; i += kImgThreads) S.acc[i] = 0.0;
   for (int im = blockIdx.x; im < n_img; im += gridDim.x) {
     const long long off = desc_off[im];
     const int P = (off >= 0) ? desc_cnt[im] : 0;
+    if (P < p_min) continue;  // taken by k_render_sparse (uniform)
     const double* pts = arena + (size_t)(off >= 0 ? off : 0) * 6;
     __syncthreads();
-    // learning.cpp:148-149  y <- y - min y
-    double miny = __builtin_inf();
-    for (int b = tid; b < P; b += kImgThreads) {
-      const double y = pts[(size_t)b * 6 + 1];
-      miny = (y < miny) ? y : miny;
-    }
-    miny = wave_min_d(miny);
-    if (lane == 0) S.red[wid] = miny;
-    __syncthreads();
-    miny = S.red[0];
-#pragma unroll
-    for (int k = 1; k < kImgThreads / kWave; k++) miny = (S.red[k] < miny) ? S.red[k] : miny;
-    const double cellsize = 1.0 / (double)kImg;  // :152
+    const double miny = block_min_y(pts, P, S.red, tid);
     const bool one_chunk = P <= kCidChunk;       // usual case: cell ids computed once for both halves
     for (int half = 0; half < 2; half++) {
       const int cell_lo = half * kHalfCells;
@@ -63,19 +142,9 @@ __global__ void __launch_bounds__(kImgThreads) k_render(const double* __restrict
         const int cn = min(kCidChunk, P - c0);
         if (!(one_chunk && half == 1)) {
           __syncthreads();
-          for (int b = tid; b < ((cn + 7) & ~7); b += kImgThreads) {
-            short cell = -1;  // also pads the chunk to a multiple of 8 ids
-            if (b < cn) {
-              const double ux = pts[(size_t)(c0 + b) * 6], uy = pts[(size_t)(c0 + b) * 6 + 1];
-              const double fx = __builtin_floor(ux / cellsize);           // :153-156
-              const double fy = __builtin_floor((uy - miny) / cellsize);
-              if (__builtin_fabs(fx) < 1.0e9 && __builtin_fabs(fy) < 1.0e9) {
-                const long long cl = (long long)fx + (long long)fy * kImg;  // x-cells >= 60 alias
-                if (cl >= 0 && cl < kCells) cell = (short)cl;
-              }
-            }
-            S.cid[b] = cell;
-          }
+          for (int b = tid; b < ((cn + 7) & ~7); b += kImgThreads)  // pads the chunk to 8 ids
+            S.cid[b] = (b < cn) ? cell_id(pts[(size_t)(c0 + b) * 6], pts[(size_t)(c0 + b) * 6 + 1], miny)
+                                : (short)-1;
           __syncthreads();
         }
         // every thread scans the chunk, 8 ids per LDS read, and adds only to cells it owns
@@ -95,61 +164,129 @@ __global__ void __launch_bounds__(kImgThreads) k_render(const double* __restrict
           }
         }
       }
-      // :181-190 avg <- |avg / ||avg|||, written at (59 - row, col).  Only the owner of a cell ever
-      // touches its accumulator, so no barrier is needed between accumulation and this pass.
-      // An all-zero sum is either an empty cell (image.setTo(0)) or the 0/0 -> NaN -> 0 case.
+      // written at (59 - row, col).  Only the owner of a cell ever touches its accumulator, so no
+      // barrier is needed between accumulation and this pass.
       for (int hc = tid; hc < kHalfCells; hc += kImgThreads) {
         const double ax = S.acc[3 * hc], ay = S.acc[3 * hc + 1], az = S.acc[3 * hc + 2];
-        unsigned packed = 0;
         if (ax != 0.0 || ay != 0.0 || az != 0.0) {
           S.acc[3 * hc] = 0.0;
           S.acc[3 * hc + 1] = 0.0;
           S.acc[3 * hc + 2] = 0.0;
-          const double s = 1.0 / __builtin_sqrt((ax * ax + ay * ay) + az * az);
-          const double v[3] = {__builtin_fabs(s * ax), __builtin_fabs(s * ay), __builtin_fabs(s * az)};
-#pragma unroll
-          for (int ch = 0; ch < 3; ch++) {
-            const float f = (float)v[ch];
-            const float tq = f * 255.0f;                               // convertTo(.., 255.0), :16
-            unsigned u = 0;
-            if (tq == tq) {
-              const float r = __builtin_rintf(tq);                     // cvRound: half to even
-              u = (unsigned)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
-            }
-            packed |= u << (8 * ch);
-          }
         }
         const int cell = hc + cell_lo;
         const int row = kImg - 1 - cell / kImg, col = cell % kImg;
-        S.pix[row * kImg + col] = packed;
+        S.pix[row * kImg + col] = quantise(ax, ay, az);
       }
     }
     __syncthreads();
-    // :202-203 3x3 rect dilate (border taps ignored), :206 BGR2RGB swap; staged in LDS so the
-    // global store is coalesced dwords
-    for (int p = tid; p < kCells; p += kImgThreads) {
-      const int r = p / kImg, cc = p % kImg;
-      unsigned m0 = 0, m1 = 0, m2 = 0;
+    dilate_store(S.pix, S.obuf, out + (size_t)im * (kCells * 3), tid);
+  }
+}
+
+struct SparseShared {
+  double acc[kSparseMax * 3];     // per leader point; the staged output image aliases it afterwards
+  unsigned pix[kCells];
+  short cid[kSparseMax];
+  short lead[kSparseMax];
+  unsigned char rank[kSparseMax];
+  double red[kImgThreads / kWave];
+  int max_rank;
+};
+static_assert(sizeof(SparseShared) * 3 <= 160 * 1024, "k_render_sparse: three workgroups per CU");
+static_assert(kSparseMax * 3 * 8 >= kCells * 3, "output staging must fit the accumulator area");
+
+__global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __restrict__ arena,
+                                                               const long long* __restrict__ desc_off,
+                                                               const int* __restrict__ desc_cnt,
+                                                               int n_img, unsigned char* __restrict__ out) {
+  __shared__ SparseShared S;
+  const int tid = threadIdx.x;
+  constexpr int kPer = kSparseMax / kImgThreads;  // points per thread
+  for (int im = blockIdx.x; im < n_img; im += gridDim.x) {
+    const long long off = desc_off[im];
+    const int P = (off >= 0) ? desc_cnt[im] : 0;
+    if (P > kSparseMax) continue;  // taken by k_render (uniform)
+    const double* pts = arena + (size_t)(off >= 0 ? off : 0) * 6;
+    __syncthreads();  // previous image's readers of S are done
+    const double miny = block_min_y(pts, P, S.red, tid);
+    double yv[kPer][3];
 #pragma unroll
-      for (int dr = -1; dr <= 1; dr++)
-#pragma unroll
-        for (int dc = -1; dc <= 1; dc++) {
-          const int rr = r + dr, c2 = cc + dc;
-          if (rr >= 0 && rr < kImg && c2 >= 0 && c2 < kImg) {
-            const unsigned v = S.pix[rr * kImg + c2];
-            m0 = max(m0, v & 255u);
-            m1 = max(m1, (v >> 8) & 255u);
-            m2 = max(m2, (v >> 16) & 255u);
-          }
-        }
-      S.obuf[p * 3 + 2] = (unsigned char)m0;
-      S.obuf[p * 3 + 1] = (unsigned char)m1;
-      S.obuf[p * 3 + 0] = (unsigned char)m2;
+    for (int k = 0; k < kPer; k++) {
+      const int b = tid + k * kImgThreads;
+      short c = -1;
+      yv[k][0] = yv[k][1] = yv[k][2] = 0.0;
+      if (b < P) {
+        const double* p = pts + (size_t)b * 6;
+        c = cell_id(p[0], p[1], miny);
+        yv[k][0] = p[3]; yv[k][1] = p[4]; yv[k][2] = p[5];
+      }
+      S.cid[b] = c;
     }
+    for (int i = tid; i < kCells; i += kImgThreads) S.pix[i] = 0u;  // image.setTo(0)
+    if (tid == 0) S.max_rank = 0;
     __syncthreads();
-    unsigned* dst = reinterpret_cast<unsigned*>(out + (size_t)im * (kCells * 3));
-    const unsigned* src = reinterpret_cast<const unsigned*>(S.obuf);
-    for (int i = tid; i < kCells * 3 / 4; i += kImgThreads) dst[i] = src[i];
+    // rank of every point among the earlier points of its cell, and the cell's first point
+    int my_rank[kPer], my_lead[kPer], mx = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int b = tid + k * kImgThreads;
+      my_rank[k] = 0;
+      my_lead[k] = b;
+      if (b < P) {
+        const int c = S.cid[b];
+        if (c >= 0) {
+          int r = 0, first = b;
+          for (int b0 = 0; b0 < b; b0 += 8) {  // 8 ids per LDS read; entries >= b are masked off
+            const uint4 w = *reinterpret_cast<const uint4*>(&S.cid[b0]);
+            const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const int id = (int)(short)((ww[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+              if (id == c && b0 + j < b) {
+                first = min(first, b0 + j);
+                r++;
+              }
+            }
+          }
+          my_rank[k] = r;
+          my_lead[k] = first;
+          mx = max(mx, r);
+        } else {
+          my_rank[k] = -1;  // dropped point (:156)
+        }
+      } else {
+        my_rank[k] = -1;
+      }
+      if (b < kSparseMax) {  // every leader starts from 0.0 like the reference's running sum
+        S.acc[3 * b] = 0.0;
+        S.acc[3 * b + 1] = 0.0;
+        S.acc[3 * b + 2] = 0.0;
+      }
+    }
+    if (mx > 0) atomicMax(&S.max_rank, mx);
+    __syncthreads();
+    const int rounds = S.max_rank;
+    for (int r = 0; r <= rounds; r++) {  // :166-179, list order within each cell
+#pragma unroll
+      for (int k = 0; k < kPer; k++)
+        if (my_rank[k] == r) {
+          const int l = my_lead[k];
+          S.acc[3 * l] = S.acc[3 * l] + yv[k][0];
+          S.acc[3 * l + 1] = S.acc[3 * l + 1] + yv[k][1];
+          S.acc[3 * l + 2] = S.acc[3 * l + 2] + yv[k][2];
+        }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; k++)
+      if (my_rank[k] == 0) {  // leaders: written at (59 - row, col)
+        const int b = tid + k * kImgThreads;
+        const int cell = S.cid[b];
+        const int row = kImg - 1 - cell / kImg, col = cell % kImg;
+        S.pix[row * kImg + col] = quantise(S.acc[3 * b], S.acc[3 * b + 1], S.acc[3 * b + 2]);
+      }
+    __syncthreads();
+    dilate_store(S.pix, reinterpret_cast<unsigned char*>(S.acc), out + (size_t)im * (kCells * 3), tid);
   }
 }
 
@@ -163,9 +300,12 @@ int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, con
                                    (int)lds));
     attr_set = true;
   }
-  const int grid = (int)std::min<size_t>(n_img, 256 * 8);
-  hipLaunchKernelGGL(k_render, dim3(grid), dim3(kImgThreads), lds, c->stream, d_arena, d_off, d_cnt,
-                     (int)n_img, d_out);
+  // images with at most kSparseMax points (nearly all) ...
+  hipLaunchKernelGGL(k_render_sparse, dim3((int)std::min<size_t>(n_img, 256 * 12)), dim3(kImgThreads), 0,
+                     c->stream, d_arena, d_off, d_cnt, (int)n_img, d_out);
+  // ... the rest; each kernel skips the other's images by the point count alone
+  hipLaunchKernelGGL(k_render, dim3((int)std::min<size_t>(n_img, 256 * 2)), dim3(kImgThreads), lds, c->stream,
+                     d_arena, d_off, d_cnt, (int)n_img, kSparseMax + 1, d_out);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }

@@ -798,20 +798,30 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
     AG2_PROF(3);
 
     // ---- orientations -----------------------------------------------------------------------
-    for (int oi = 0; oi < R; oi++) {
-      AG2_PROF(7);
-      unsigned blocked = 0, flags = 0;
+    // Lane i of every wave combines the waves' pass-A results for orientation i and applies the
+    // gates; the loop below then visits only the orientations that pass (usually none or one).
+    unsigned hand_l = 0;
+    {
+      unsigned cb = 0, cf = 0;
+      if (lane < R) {
 #pragma unroll
-      for (int k = 0; k < kSweepWaves; k++) {
-        blocked |= S.res_a[k][oi][0];
-        flags |= S.res_a[k][oi][1];
+        for (int k = 0; k < kSweepWaves; k++) {
+          cb |= S.res_a[k][lane][0];
+          cf |= S.res_a[k][lane][1];
+        }
       }
-      if ((flags & 2u) || !(flags & 1u)) continue;                  // finger_hand.cpp:35-36, :41-42
-      const unsigned free_ = (~blocked) & 0xFFFFFu;
-      if (!(__popc(free_) > 2)) continue;                           // hand_search.cpp:366
-      const unsigned hand = free_ & (free_ >> 10) & 0x3FFu;         // finger_hand.cpp:313-325
+      const unsigned free_ = (~cb) & 0xFFFFFu;
+      const bool open = (lane < R) && !(cf & 2u) && (cf & 1u)       // finger_hand.cpp:35-36, :41-42
+                        && (__popc(free_) > 2);                      // hand_search.cpp:366
+      hand_l = open ? (free_ & (free_ >> 10) & 0x3FFu) : 0u;        // finger_hand.cpp:313-325
+    }
+    unsigned long long todo = __ballot(hand_l != 0u);               // hand_search.cpp:370
+    while (todo) {
+      AG2_PROF(7);
+      const int oi = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const unsigned hand = (unsigned)__builtin_amdgcn_readlane((int)hand_l, oi);
       const int nvalid = __popc(hand);
-      if (!(nvalid > 0)) continue;                                  // hand_search.cpp:370
       // From here on everything is the reference's f64 arithmetic, for the few orientations that
       // pass the gates.  rot = [c -s 0; s c 0; 0 0 1], frame_rot = frame * rot, hand_search.cpp:356-357
       const double cs = S.cosd[oi], sn = S.sind[oi];

@@ -175,6 +175,14 @@ def test_images_from_points_edge_cases():
     lists.append((u, rng.normal(size=(3, 5000))))
     u2 = rng.uniform(-0.5, 1.5, size=(3, 300))
     lists.append((u2, rng.normal(size=(3, 300))))
+    # the sparse renderer's limit (1024 points, many per cell: dozens of accumulation rounds; zero
+    # normal sums) and the first size the dense renderer takes
+    for npts in (1024, 1025, 7, 64, 257):
+        u3 = rng.uniform(0.2, 0.8, size=(3, npts))
+        u3[:2, : npts // 2] = np.round(u3[:2, : npts // 2] * 6) / 6.0
+        n3 = rng.normal(size=(3, npts))
+        n3[:, 1::7] = -n3[:, 0:-1:7][:, : n3[:, 1::7].shape[1]]   # pairs that cancel where they share a cell
+        lists.append((u3, n3))
     got = d.render_images_from_points([a for a, _ in lists], [b for _, b in lists])
     for k, (a, b) in enumerate(lists):
         want = o.render_image_from_points(a, b) if a.shape[1] else np.zeros((60, 60, 3), np.uint8)
