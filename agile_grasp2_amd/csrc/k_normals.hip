@@ -29,29 +29,85 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
       hi[a] = min(cell_of(qq[a] + rq, g.o[a], g.inv), g.dims[a] - 1);
     }
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
-    for (int cz = lo[2]; cz <= hi[2]; cz++)
-      for (int cy = lo[1]; cy <= hi[1]; cy++) {
-        const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
-        const int b = (int)cell[rowbase + lo[0]];
-        const int e = (int)cell[rowbase + hi[0] + 1];
-        for (int j = b; j < e; j++) {
-          const float4 p = pts[j];
-          const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-          const float d2 = (dx * dx + dy * dy) + dz * dz;
-          if (d2 < r2f) {
-            a0 = a0 + p.x * p.x;
-            a1 = a1 + p.x * p.y;
-            a2 = a2 + p.x * p.z;
-            a3 = a3 + p.y * p.y;
-            a4 = a4 + p.y * p.z;
-            a5 = a5 + p.z * p.z;
-            a6 = a6 + p.x;
-            a7 = a7 + p.y;
-            a8 = a8 + p.z;
-            cnt++;
+    // The kernel is bound by the latency of each thread's chain of dependent loads (one wave per
+    // SIMD slot, every wave runs once), so the chain is kept short: the span bounds of ALL stencil
+    // rows (<= 4 x 4: q +- 1.001 r reaches 3, rarely 4, cells per axis) are requested first, and a
+    // row is walked four points per step with the four loads issued together.  The moments are
+    // still accumulated one point at a time in canonical order (cz, cy, then sorted position).
+    constexpr int kRows = 16;
+    int nrows = (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+    if (nrows > kRows) {  // normals_radius much larger than grid_cell: plain nested walk, same order
+      for (int cz = lo[2]; cz <= hi[2]; cz++)
+        for (int cy = lo[1]; cy <= hi[1]; cy++) {
+          const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
+          const int e = (int)cell[rowbase + hi[0] + 1];
+          for (int j = (int)cell[rowbase + lo[0]]; j < e; j++) {
+            const float4 p = pts[j];
+            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < r2f) {
+              a0 = a0 + p.x * p.x;
+              a1 = a1 + p.x * p.y;
+              a2 = a2 + p.x * p.z;
+              a3 = a3 + p.y * p.y;
+              a4 = a4 + p.y * p.z;
+              a5 = a5 + p.z * p.z;
+              a6 = a6 + p.x;
+              a7 = a7 + p.y;
+              a8 = a8 + p.z;
+              cnt++;
+            }
+          }
+        }
+      nrows = 0;
+    }
+    int rb[kRows], re[kRows];
+    {
+      int cy = lo[1], cz = lo[2];
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        rb[r] = 0;
+        re[r] = 0;
+        if (r < nrows) {
+          const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
+          rb[r] = (int)cell[rowbase + lo[0]];
+          re[r] = (int)cell[rowbase + hi[0] + 1];
+          if (++cy > hi[1]) {
+            cy = lo[1];
+            cz++;
           }
         }
       }
+    }
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (r < nrows) {
+        const int e = re[r];
+        for (int j = rb[r]; j < e; j += 4) {
+          float4 p4[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) p4[k] = pts[min(j + k, e - 1)];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float4 p = p4[k];
+            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (j + k < e && d2 < r2f) {
+              a0 = a0 + p.x * p.x;
+              a1 = a1 + p.x * p.y;
+              a2 = a2 + p.x * p.z;
+              a3 = a3 + p.y * p.y;
+              a4 = a4 + p.y * p.z;
+              a5 = a5 + p.z * p.z;
+              a6 = a6 + p.x;
+              a7 = a7 + p.y;
+              a8 = a8 + p.z;
+              cnt++;
+            }
+          }
+        }
+      }
+    }
     float4 out;
     if (cnt < 3) {
       const float nanv = __builtin_nanf("");

@@ -83,9 +83,64 @@ __global__ void __launch_bounds__(64) k_frames(const float4* __restrict__ pts,
   QueryRange qr = query_range(g, q.x, q.y, q.z, hc->rq_taubin);
   const bool usable = (q.w != 0.f) && !qr.empty;
   const float r2 = hc->r2_taubin;
-  // pass 1: count neighbours with a finite normal (NaN-normal neighbours never enter the draw)
+  // Fast path (the usual neighbourhood of <= 256 candidates in <= 64 stencil rows): the kernel is
+  // bound by its chain of dependent loads, so the chain is cut to three -- all row bounds at once
+  // (one row per lane), all candidate points at once (one per lane), their normals -- and the
+  // finite-normal neighbours are kept in LDS in canonical order, which makes the resolution of the
+  // drawn ranks a table lookup instead of a second walk.
+  __shared__ int nbuf[256];
+  __shared__ int row_first[64], row_begin[64];
   int k1f = 0;
+  bool fast = false;
   if (usable) {
+    const int ny = qr.hi[1] - qr.lo[1] + 1, nz = qr.hi[2] - qr.lo[2] + 1;
+    const int nrows = ny * nz;
+    if (nrows <= 64) {
+      int rb = 0, rl = 0;
+      if (lane < nrows) {
+        const int cz = qr.lo[2] + lane / ny, cy = qr.lo[1] + lane % ny;  // canonical row order
+        const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
+        rb = (int)cell[rowbase + qr.lo[0]];
+        rl = (int)cell[rowbase + qr.hi[0] + 1] - rb;
+      }
+      int inc = rl;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+      }
+      const int total = __builtin_amdgcn_readlane(inc, 63);
+      if (total <= 256) {
+        fast = true;
+        row_first[lane] = inc - rl;
+        row_begin[lane] = rb;
+        __syncthreads();
+        for (int c0 = 0; c0 < total; c0 += 64) {
+          const int cidx = c0 + lane;
+          bool pred = false;
+          int j = 0;
+          if (cidx < total) {
+            int row = 0;
+            for (int r = 1; r < nrows; r++) row = (row_first[r] <= cidx) ? r : row;
+            j = row_begin[row] + (cidx - row_first[row]);
+            const float4 p = pts[j];
+            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < r2) {
+              const float4 nn = nrm[j];
+              pred = finite3(nn.x, nn.y, nn.z);
+            }
+          }
+          const unsigned long long mask = __ballot(pred);
+          if (pred) nbuf[k1f + __popcll(mask & lt_mask)] = j;
+          k1f += __popcll(mask);
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // pass 1: count neighbours with a finite normal (NaN-normal neighbours never enter the draw)
+  if (usable && !fast) {
     for (int cz = qr.lo[2]; cz <= qr.hi[2]; cz++)
       for (int cy = qr.lo[1]; cy <= qr.hi[1]; cy++) {
         const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
@@ -117,6 +172,9 @@ __global__ void __launch_bounds__(64) k_frames(const float4* __restrict__ pts,
   // pass 2: resolve the drawn ranks to sorted positions
   int pick = -1;
   int base = 0;
+  if (fast) {
+    if (lane < m) pick = nbuf[(int)rj];
+  } else
   for (int cz = qr.lo[2]; cz <= qr.hi[2]; cz++)
     for (int cy = qr.lo[1]; cy <= qr.hi[1]; cy++) {
       const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
@@ -196,8 +254,40 @@ __global__ void __launch_bounds__(64) k_frames(const float4* __restrict__ pts,
   }
   if (!(best_v > -1.0)) best_i = 0;
   __syncthreads();
+  // The rest -- a 3x3 eigen-solve and a dozen vector operations -- is serial per sample: done here it
+  // would cost a whole wave per sample (the kernel was issue-bound on exactly that), so the
+  // intermediate (M, n_max, majority camera) is parked in the sample's frame slot and
+  // k_frames_finish completes it with one THREAD per sample.
+  if (lane == 0) {
+    double* f = frames + (size_t)t * 12;
+#pragma unroll
+    for (int k = 0; k < 6; k++) f[k] = Msh[k];
+    f[6] = Nsh[best_i][0];
+    f[7] = Nsh[best_i][1];
+    f[8] = Nsh[best_i][2];
+    f[9] = (double)majority;
+    frame_ok[t] = 1;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_frames_finish(const HandConst* __restrict__ hc,
+                                                      const float4* __restrict__ sample_q, int s,
+                                                      double* __restrict__ frames,
+                                                      const int* __restrict__ frame_ok, DevStats* st) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = (t < s) && frame_ok[t] != 0;
+  const unsigned long long lm = __ballot(live);
+  if (lane_id() == 0 && lm) atomicAdd(&st->n_frames, (unsigned)__popcll(lm));
+  if (!live) return;
+  const float4 q = sample_q[t];
+  double* fio = frames + (size_t)t * 12;
   Sym3 M;
-  M.a00 = Msh[0]; M.a01 = Msh[1]; M.a02 = Msh[2]; M.a11 = Msh[3]; M.a12 = Msh[4]; M.a22 = Msh[5];
+  M.a00 = fio[0]; M.a01 = fio[1]; M.a02 = fio[2]; M.a11 = fio[3]; M.a12 = fio[4]; M.a22 = fio[5];
+  const double nsel[3] = {fio[6], fio[7], fio[8]};
+  const int majority = (int)fio[9];
+  const int lane = 0, best_i = 0;
+  const double (*Nsh)[3] = &nsel;  // Nsh[best_i] below reads the parked n_max
+  (void)lane;
   const Eig3 e = jacobi3(M);
   const int mi = argmin3(e.d);                                        // :36-38
   V3 cv{mi == 0 ? e.v[0][0] : (mi == 1 ? e.v[0][1] : e.v[0][2]),
@@ -226,15 +316,10 @@ __global__ void __launch_bounds__(64) k_frames(const float4* __restrict__ pts,
   if (dot3(normal, v) > 0.0) normal = neg3(normal);                   // :52-53
   if (dot3(binormal, v) > 0.0) binormal = neg3(binormal);             // :54-55
   const V3 curv = cross3(normal, binormal);                           // :58
-  if (lane == 0) {
-    double* f = frames + (size_t)t * 12;
-    f[0] = sample.x; f[1] = sample.y; f[2] = sample.z;
-    f[3] = normal.x; f[4] = normal.y; f[5] = normal.z;
-    f[6] = binormal.x; f[7] = binormal.y; f[8] = binormal.z;
-    f[9] = curv.x; f[10] = curv.y; f[11] = curv.z;
-    frame_ok[t] = 1;
-    atomicAdd(&st->n_frames, 1u);
-  }
+  fio[0] = sample.x; fio[1] = sample.y; fio[2] = sample.z;
+  fio[3] = normal.x; fio[4] = normal.y; fio[5] = normal.z;
+  fio[6] = binormal.x; fio[7] = binormal.y; fio[8] = binormal.z;
+  fio[9] = curv.x; fio[10] = curv.y; fio[11] = curv.z;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1106,6 +1191,9 @@ int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed) {
                      c->d_hc.as<HandConst>(), c->d_sample_q.as<float4>(), (int)s,
                      (unsigned long long)slot_base, (unsigned long long)seed,
                      c->d_frames.as<double>(), c->d_frame_ok.as<int>(), c->d_stats.as<DevStats>());
+  hipLaunchKernelGGL(k_frames_finish, dim3(((unsigned)s + 63) / 64), dim3(64), 0, c->stream,
+                     c->d_hc.as<HandConst>(), c->d_sample_q.as<float4>(), (int)s, c->d_frames.as<double>(),
+                     c->d_frame_ok.as<int>(), c->d_stats.as<DevStats>());
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
