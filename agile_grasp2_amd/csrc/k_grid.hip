@@ -174,7 +174,24 @@ __global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ 
   const int c0 = blockIdx.x * 256, c = c0 + threadIdx.x;
   const int lo = (int)cell[c0], hi = (int)cell[min(c0 + 256, ncells)];
   const int b = (c < ncells) ? (int)cell[c] : 0, e = (c < ncells) ? (int)cell[c + 1] : 0;
-  if ((hi - lo) <= kSortStage) {  // uniform: LDS path (ds_ instructions, no generic pointers)
+  if ((hi - lo) <= kSortStage / 2) {  // uniform: LDS path (ds_ instructions, no generic pointers)
+    // Rank sort, one thread per ELEMENT: every element counts the smaller indices in its own cell
+    // (independent compares, no dependent insertion chains) and is written to (cell start + rank).
+    // stage[0, n) = values; stage[n, 2n) = packed (cell start - lo) | (cell length << 16).
+    const int n = hi - lo;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) stage[i - lo] = perm[i];
+    for (int i = b; i < e; i++)  // lengths fit 16 bits: n <= kSortStage / 2
+      stage[n + (i - lo)] = (b - lo) | ((e - b) << 16);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int v = stage[i];
+      const int be = stage[n + i];
+      const int cb = be & 0xFFFF, cl = be >> 16;
+      int rank = 0;
+      for (int k = 0; k < cl; k++) rank += (stage[cb + k] < v) ? 1 : 0;
+      perm[lo + cb + rank] = v;  // indices within a cell are distinct: ranks are a permutation
+    }
+  } else if ((hi - lo) <= kSortStage) {  // staged insertion sort
     for (int i = lo + threadIdx.x; i < hi; i += 256) stage[i - lo] = perm[i];
     __syncthreads();
     const int sb = b - lo, se = e - lo;
