@@ -19,9 +19,10 @@ __global__ void k_slot_flags(const ag2_hypothesis* __restrict__ table,
   if (i > n_slots) return;
   unsigned f = 0;
   if (i < n_slots) {
+    // state byte: 0 empty, 1 survives the prune, 2 scored, 4 pruned away
     const bool valid = table[i].n_points > 0;
     if (mode == 0) f = valid;
-    else if (mode == 1) f = valid && keep[i];
+    else if (mode == 1) f = valid && (keep[i] == 1 || keep[i] == 2);
     else f = valid && keep[i] == 2 && table[i].score >= thr;
   }
   flags[i] = f;
@@ -34,14 +35,70 @@ __global__ void k_slot_scatter(const unsigned* __restrict__ pref, int n_slots,
   if (pref[i + 1] != pref[i]) list[pref[i]] = i;
 }
 
+// The same in ONE launch for tables of up to 64 Ki slots (modes 0 and 1): a single 1024-thread
+// workgroup, each thread a contiguous run of <= 64 slots whose flags it keeps in a 64-bit mask
+// between the counting and the writing pass.  Five launches (flags, 3 x scan, scatter) and a copy
+// become one; at S*R = 40 000 slots the table is latency-, not bandwidth-sized.
+// Only the per-slot state byte is read (k_sweep: 0 empty, 1 hypothesis that survives the prune,
+// 4 hypothesis pruned away), 16 slots per load, never the 176-byte records.
+__global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __restrict__ keep,
+                                                        int n_slots, int mode, int* __restrict__ list,
+                                                        unsigned* __restrict__ count) {
+  __shared__ unsigned wsum[16];
+  const int t = threadIdx.x;
+  const int per = (((n_slots + 1023) / 1024) + 15) & ~15;  // 16 .. 64, a multiple of 16
+  const int s0 = t * per;
+  unsigned long long mask = 0ull;
+  for (int i = 0; i < per; i += 16) {
+    if (s0 + i < n_slots) {  // the buffer is 16-byte padded past n_slots (DevBuf slack)
+      const uint4 v = *reinterpret_cast<const uint4*>(keep + s0 + i);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const unsigned b = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+        const bool f = (s0 + i + k < n_slots) && (mode == 1 ? (b == 1u) : (b != 0u));
+        mask |= f ? (1ull << (i + k)) : 0ull;
+      }
+    }
+  }
+  const unsigned tot = (unsigned)__popcll(mask);
+  unsigned inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = (unsigned)__shfl_up((int)inc, o, 64);
+    if (lane_id() >= o) inc += v;
+  }
+  if (lane_id() == 63) wsum[wave_id()] = inc;
+  __syncthreads();
+  unsigned woff = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) {
+    if (w < wave_id()) woff += wsum[w];
+    all += wsum[w];
+  }
+  unsigned pos = woff + inc - tot;
+  while (mask) {
+    const int b = __ffsll((long long)mask) - 1;
+    mask &= mask - 1ull;
+    list[pos++] = s0 + b;
+  }
+  if (t == 0) *count = all;
+}
+
 // Asynchronous: the list length is left on the device (*d_count) -- no host round trip.
 int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count) {
   if (n_slots == 0) {
     AG2_HIP(c, hipMemsetAsync(d_count, 0, 4, c->stream));
     return 0;
   }
-  AG2_HIP(c, c->d_flags.reserve((n_slots + 1) * 4));
   AG2_HIP(c, out_list.reserve(n_slots * 4));
+  if (n_slots <= 65536 && mode <= 1) {
+    hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, c->stream,
+                       c->d_tab_keep.as<unsigned char>(), (int)n_slots, mode, out_list.as<int>(), d_count);
+    AG2_HIP(c, hipGetLastError());
+    return 0;
+  }
+  AG2_HIP(c, c->d_flags.reserve((n_slots + 1) * 4));
   unsigned* fl = c->d_flags.as<unsigned>();
   const int nb = ((int)n_slots + 1 + 255) / 256;
   hipLaunchKernelGGL(k_slot_flags, dim3(nb), dim3(256), 0, c->stream,
@@ -159,7 +216,7 @@ __global__ void k_gather_records(const ag2_hypothesis* __restrict__ table,
   const int s = list[i];
   out[i] = table[s];
   if (out_off) out_off[i] = tab_off[s];
-  if (out_keep) out_keep[i] = keep[s];
+  if (out_keep) out_keep[i] = (keep[s] == 1 || keep[s] == 2) ? 1 : 0;  // 4 = pruned away
 }
 
 int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypothesis>& recs,

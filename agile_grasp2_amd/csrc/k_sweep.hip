@@ -1168,7 +1168,7 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
         }
         A.table[slot] = h;
         A.tab_off[slot] = off;
-        A.tab_keep[slot] = keep ? 1 : 0;
+        A.tab_keep[slot] = keep ? 1 : 4;  // slot state: 0 empty, 1 survives the prune, 4 pruned away
         atomicAdd(&A.st->n_hyp, 1u);
         atomicAdd(&A.st->sum_p, (unsigned long long)P);
       }
