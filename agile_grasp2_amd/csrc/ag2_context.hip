@@ -228,7 +228,7 @@ void ag2_destroy(ag2_ctx* c) {
                     &c->d_raw, &c->d_raw_nrm, &c->d_pre, &c->d_pflags, &c->d_bitmap, &c->d_wrank,
                     &c->d_first, &c->d_prestats, &c->d_hist, &c->d_samples, &c->d_cluster, &c->d_cluster_tmp, &c->net.w1p, &c->net.b1,
                     &c->net.w2p, &c->net.b2, &c->net.w3p, &c->net.b3, &c->net.w4, &c->net.b4,
-                    &c->net.w1x, &c->net.w2x};
+                    &c->net.w1x, &c->net.w2x, &c->net.w3x};
   for (DevBuf* b : bufs) b->release();
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   for (auto& e : c->ev)

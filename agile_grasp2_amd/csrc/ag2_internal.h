@@ -74,7 +74,7 @@ struct PreStats {
 struct LeNetDev {
   bool loaded = false;
   DevBuf w1p, b1, w2p, b2, w3p, b3, w4, b4;  // packed for the MFMA lane layout (k_lenet.hip)
-  DevBuf w1x, w2x;                           // conv weights split into 3 bf16 terms (k_lenet_x3.hip)
+  DevBuf w1x, w2x, w3x;                      // conv / ip1 weights split into 3 bf16 terms (k_lenet_x3.hip)
   bool use_x3 = true;                        // false: the f32-input MFMA convolutions (AG2_LENET_F32=1)
 };
 
@@ -201,6 +201,8 @@ int make_image_descs(ag2_ctx* c, const int* d_list, size_t n);
 // k_lenet_x3.hip
 int lenet_pack_weights_x3(ag2_ctx* c, const float* conv1_w, const float* conv2_w);
 int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_pooled2);
+int lenet_pack_fc_x3(ag2_ctx* c, const float* w3p_7200x512);
+int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out);
 // k_cluster.hip
 int cluster_async(ag2_ctx* c, const ag2_hypothesis* d_in, size_t n_max, const unsigned* d_n,
                   int min_inliers, unsigned* d_count);

@@ -309,7 +309,9 @@ int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const flo
     AG2_HIP(c, hipMemcpyAsync(u.b->p, u.p, u.n * 4, hipMemcpyHostToDevice, c->stream));
   }
   AG2_HIP(c, hipStreamSynchronize(c->stream));
-  const int rc = lenet_pack_weights_x3(c, c1w, c2w);
+  int rc = lenet_pack_weights_x3(c, c1w, c2w);
+  if (rc) return rc;
+  rc = lenet_pack_fc_x3(c, w3p.data());
   if (rc) return rc;
   d.use_x3 = getenv("AG2_LENET_F32") == nullptr;
   d.loaded = true;
@@ -340,20 +342,26 @@ int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits,
                        c->d_act1.as<float>());
   }
   if (ev_mid) AG2_HIP(c, hipEventRecord(ev_mid, c->stream));
-  const int mtiles = (int)((n + kFcBM - 1) / kFcBM);
-  const int n_pad = mtiles * kFcBM;
-  // split K (75 chunks of 96) so that small batches still put >= 2 workgroups on every CU
-  static const int kSplits[] = {1, 3, 5, 15, 25};
-  int ksplit = 25;
-  for (int ks : kSplits)
-    if ((long long)mtiles * 4 * ks >= 512) {
-      ksplit = ks;
-      break;
-    }
-  AG2_HIP(c, c->d_fcpart.reserve((size_t)ksplit * n_pad * kFcN * 4));
-  hipLaunchKernelGGL(k_lenet_fc1, dim3(mtiles, 4, ksplit), dim3(256), 0, c->stream,
-                     c->d_act1.as<float>(), (int)n, n_pad, d.w3p.as<float>(), 75 / ksplit,
-                     c->d_fcpart.as<float>());
+  int n_pad = 0, ksplit = 0;
+  if (d.use_x3) {  // ip1 with the same three-term split on the bf16 matrix cores
+    const int rc = launch_lenet_fc1_x3(c, n, &n_pad, &ksplit);
+    if (rc) return rc;
+  } else {
+    const int mtiles = (int)((n + kFcBM - 1) / kFcBM);
+    n_pad = mtiles * kFcBM;
+    // split K (75 chunks of 96) so that small batches still put >= 2 workgroups on every CU
+    static const int kSplits[] = {1, 3, 5, 15, 25};
+    ksplit = 25;
+    for (int ks : kSplits)
+      if ((long long)mtiles * 4 * ks >= 512) {
+        ksplit = ks;
+        break;
+      }
+    AG2_HIP(c, c->d_fcpart.reserve((size_t)ksplit * n_pad * kFcN * 4));
+    hipLaunchKernelGGL(k_lenet_fc1, dim3(mtiles, 4, ksplit), dim3(256), 0, c->stream,
+                       c->d_act1.as<float>(), (int)n, n_pad, d.w3p.as<float>(), 75 / ksplit,
+                       c->d_fcpart.as<float>());
+  }
   hipLaunchKernelGGL(k_lenet_fc_finish, dim3(((int)n + 3) / 4), dim3(256), 0, c->stream,
                      c->d_fcpart.as<float>(), (int)n, n_pad, ksplit, d.b3.as<float>(),
                      d.w4.as<float>(), d.b4.as<float>(), d_logits);

@@ -322,6 +322,155 @@ int lenet_pack_weights_x3(ag2_ctx* c, const float* c1w, const float* c2w) {
   return 0;
 }
 
+// ---- ip1 on the bf16 matrix cores, same three-term split ------------------------------------------
+// One 128-image x 128-output tile per workgroup over a K range (split-K; k_lenet_fc_finish adds the
+// partial sums in split order).  The fp32 activations are split into three bf16 terms while they are
+// staged into LDS (row pitch 56 bf16: the 16 rows of an LDS pass fall on disjoint banks), the
+// weights are pre-split and pre-packed in B-fragment order.  Twice the tile height of k_lenet_fc1:
+// the weight stream from L2, which bounds this layer, is read half as often.
+constexpr int kFxBM = 128;
+constexpr int kFxKC = 48;              // k per chunk: 7200 = 150 chunks of three 16-k blocks
+constexpr int kFxPitch = 56;           // bf16 per staged row
+constexpr int kFxN = 512;
+
+struct FxShared {
+  unsigned short a[3][kFxBM][kFxPitch];
+};
+
+__global__ void __launch_bounds__(256, 2)
+k_lenet_fc1_x3(const float* __restrict__ x, int n_img, int n_pad, const uint4* __restrict__ w3x,
+               int chunks_per_split, float* __restrict__ part) {
+  __shared__ FxShared S;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  const int img0 = blockIdx.x * kFxBM;
+  const int nt = blockIdx.y * 4 + wid;  // 32-column tile of this wave
+  const int chunk0 = blockIdx.z * chunks_per_split;
+  v16f acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // staging: thread t owns image row t / 2 and 24 consecutive k of the chunk
+  const int srow = tid >> 1, scol = (tid & 1) * 24;
+  const bool srow_ok = (img0 + srow) < n_img;
+  const float* sx = x + (size_t)(img0 + srow) * 7200 + scol + (size_t)chunk0 * kFxKC;
+  float4 v[6];
+  auto gload = [&](int ci) {
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+      v[i] = srow_ok ? *reinterpret_cast<const float4*>(sx + (size_t)ci * kFxKC + 4 * i)
+                     : make_float4(0, 0, 0, 0);
+  };
+  auto lstore = [&]() {
+    unsigned short t3[24][3];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      split3(v[i].x, t3[4 * i]);
+      split3(v[i].y, t3[4 * i + 1]);
+      split3(v[i].z, t3[4 * i + 2]);
+      split3(v[i].w, t3[4 * i + 3]);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      uint4* d = reinterpret_cast<uint4*>(&S.a[s][srow][scol]);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        uint4 u;
+        u.x = (unsigned)t3[8 * q][s] | ((unsigned)t3[8 * q + 1][s] << 16);
+        u.y = (unsigned)t3[8 * q + 2][s] | ((unsigned)t3[8 * q + 3][s] << 16);
+        u.z = (unsigned)t3[8 * q + 4][s] | ((unsigned)t3[8 * q + 5][s] << 16);
+        u.w = (unsigned)t3[8 * q + 6][s] | ((unsigned)t3[8 * q + 7][s] << 16);
+        d[q] = u;
+      }
+    }
+  };
+  const uint4* wl = w3x + ((size_t)(chunk0 * 3) * 16 + nt) * 3 * 64 + lane;  // k-block stride: 16*3*64
+  uint4 nb0 = wl[0], nb1 = wl[64], nb2 = wl[128];
+  gload(0);
+  for (int ci = 0; ci < chunks_per_split; ci++) {
+    __syncthreads();  // the previous chunk's readers are done
+    lstore();
+    __syncthreads();
+    if (ci + 1 < chunks_per_split) gload(ci + 1);  // in flight during this chunk's MFMAs
+#pragma unroll
+    for (int kb = 0; kb < 3; kb++) {
+      const bf16x8 Bh = as_frag(nb0), Bm = as_frag(nb1), Bl = as_frag(nb2);
+      {  // next k-block's weights (the last prefetch re-reads the final block)
+        const int nxt = min(ci * 3 + kb + 1, chunks_per_split * 3 - 1);
+        const uint4* wn = wl + (size_t)nxt * (16 * 3 * 64);
+        nb0 = wn[0];
+        nb1 = wn[64];
+        nb2 = wn[128];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int row = 32 * t + r, kk = 16 * kb + 8 * h;
+        const bf16x8 Ah = as_frag(*reinterpret_cast<const uint4*>(&S.a[0][row][kk]));
+        const bf16x8 Am = as_frag(*reinterpret_cast<const uint4*>(&S.a[1][row][kk]));
+        const bf16x8 Al = as_frag(*reinterpret_cast<const uint4*>(&S.a[2][row][kk]));
+        v16f a = acc[t];
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, a, 0, 0, 0);
+        acc[t] = a;
+      }
+    }
+  }
+  float* dst = part + ((size_t)blockIdx.z * n_pad + img0) * kFxN + nt * 32 + r;
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int row = 32 * t + (q & 3) + 8 * (q >> 2) + 4 * h;
+      dst[(size_t)row * kFxN] = acc[t][q];
+    }
+}
+
+// w3p: the [7200][512] K'-ordered ip1 matrix of lenet_pack_weights (k_lenet.hip), host memory
+int lenet_pack_fc_x3(ag2_ctx* c, const float* w3p) {
+  std::vector<unsigned short> w3x((size_t)450 * 16 * 3 * 64 * 8);
+  unsigned short s3[3];
+  for (int kbk = 0; kbk < 450; kbk++)
+    for (int nt = 0; nt < 16; nt++)
+      for (int l = 0; l < 64; l++) {
+        const int h = l >> 5, col = nt * 32 + (l & 31);
+        for (int j = 0; j < 8; j++) {
+          split3(w3p[(size_t)(16 * kbk + 8 * h + j) * kFxN + col], s3);
+          for (int t = 0; t < 3; t++) w3x[((((size_t)kbk * 16 + nt) * 3 + t) * 64 + l) * 8 + j] = s3[t];
+        }
+      }
+  LeNetDev& d = c->net;
+  AG2_HIP(c, d.w3x.reserve(w3x.size() * 2));
+  AG2_HIP(c, hipMemcpyAsync(d.w3x.p, w3x.data(), w3x.size() * 2, hipMemcpyHostToDevice, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// partial sums into d_fcpart; *n_pad_out, *ksplit_out describe them for k_lenet_fc_finish
+int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out) {
+  LeNetDev& d = c->net;
+  const int mtiles = (int)((n + kFxBM - 1) / kFxBM);
+  const int n_pad = mtiles * kFxBM;
+  // split K (150 chunks of 48) so that small batches still put about two workgroups on every CU
+  static const int kSplits[] = {1, 2, 3, 5, 6, 10, 15, 25, 30};
+  int ksplit = 30;
+  for (int ks : kSplits)
+    if ((long long)mtiles * 4 * ks >= 448) {
+      ksplit = ks;
+      break;
+    }
+  AG2_HIP(c, c->d_fcpart.reserve((size_t)ksplit * n_pad * kFxN * 4));
+  hipLaunchKernelGGL(k_lenet_fc1_x3, dim3(mtiles, 4, ksplit), dim3(256), 0, c->stream,
+                     c->d_act1.as<float>(), (int)n, n_pad, d.w3x.as<uint4>(), 150 / ksplit,
+                     c->d_fcpart.as<float>());
+  AG2_HIP(c, hipGetLastError());
+  *n_pad_out = n_pad;
+  *ksplit_out = ksplit;
+  return 0;
+}
+
 int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_pooled2) {
   LeNetDev& d = c->net;
   const size_t lds = sizeof(X3Shared);

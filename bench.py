@@ -48,6 +48,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32
 # k_lenet_conv_x3: v_mfma_f32_32x32x16_bf16 issued per image = conv1 98 tiles x 8 k-blocks x 3 terms
 # + conv2 18 tiles x 2 channel halves x 32 k-blocks x 6 terms; 32*32*16*2 flop each
 CONV_X3_ISSUED_FLOP = (98 * 8 * 3 + 18 * 2 * 32 * 6) * 32768.0
+# k_lenet_fc1_x3: per 32-image tile 16 column tiles x 450 k-blocks x 6 terms (ip2 and the padding of
+# the batch to 128 images not counted)
+FC_X3_ISSUED_FLOP = 16 * 450 * 6 * 32768.0 / 32
 
 
 def launch_params(ws, R):
@@ -230,7 +233,11 @@ def main():
                          dict(bound="mfma", work=n_img * CONV_X3_ISSUED_FLOP, ms=ms["lenet_conv_ms"],
                               peak=PEAK_BF16_MFMA_TFLOPS,
                               fp32_equivalent_tflops=n_img * CONV_FLOP / (ms["lenet_conv_ms"] * 1e-3) / 1e12)),
-        "k_lenet_fc": dict(bound="mfma", work=n_img * FC_FLOP, ms=ms["lenet_fc_ms"]),
+        "k_lenet_fc": (dict(bound="mfma", work=n_img * FC_FLOP, ms=ms["lenet_fc_ms"])
+                       if os.environ.get("AG2_LENET_F32") else
+                       dict(bound="mfma", work=n_img * FC_X3_ISSUED_FLOP, ms=ms["lenet_fc_ms"],
+                            peak=PEAK_BF16_MFMA_TFLOPS,
+                            fp32_equivalent_tflops=n_img * FC_FLOP / (ms["lenet_fc_ms"] * 1e-3) / 1e12)),
     }
     for k in kernels.values():
         if k["bound"] == "hbm":
