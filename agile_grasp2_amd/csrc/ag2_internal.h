@@ -43,6 +43,8 @@ struct DevStats {
   unsigned int n_list;               // hypotheses that go on to be scored (after the prune)
   unsigned int n_sel;                // scored hypotheses with score >= min_score_diff
   unsigned int n_clu;                // selected hypotheses that survive the clustering
+  unsigned int n_overflow2;          // samples whose cropped list exceeds the 160-KiB LDS stage too
+  unsigned int pad0;
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
   unsigned int pad1;

@@ -343,8 +343,9 @@ struct SweepArgs {
   long long arena_cap;       // points
   int emit_lists;
   DevStats* st;
-  int* overflow;             // LDS variant: appended; global variant: the work list
-  int n_overflow;            // global variant: list length
+  int* overflow;             // stage 0 appends, stage 1 works through it (length: st->n_overflow)
+  int* overflow2;            // stage 1 appends, stage 2 works through it (length: st->n_overflow2)
+  int n_overflow;            // unused (lengths are read on the device)
   float* gscratch;           // global variant: 6 * gcap floats per block
   int gcap;
   float min_z;
@@ -400,13 +401,24 @@ struct SweepShared {
 // instantiation of the same kernel.
 constexpr int kLdsCap = (int)(((81920 - ((sizeof(SweepShared) + 15) & ~size_t(15))) / 18) & ~size_t(31));
 static_assert(kLdsCap >= 2048 && kLdsCap <= 65536, "unexpected LDS stage size");
+// second stage: one workgroup per CU with the whole 160 KiB (dense clouds)
+constexpr int kLdsCapBig = (int)(((163840 - ((sizeof(SweepShared) + 15) & ~size_t(15))) / 18) & ~size_t(31));
+static_assert(kLdsCapBig > kLdsCap && kLdsCapBig <= 65536, "unexpected LDS stage size");
 
+// Three instantiations run back to back, each taking what the previous one could not hold and
+// reading its queue length on the device (no host round trip):
+//   STAGE 0: every sample; cropped list in 80 KiB of LDS (two workgroups per CU)
+//   STAGE 1: queue of stage 0; 160 KiB of LDS (one workgroup per CU, no register spills)
+//   STAGE 2: queue of stage 1; cropped list in a per-workgroup global scratch
 // RMAX: compile-time bound on num_orientations (8, 16 or 32) for the per-orientation registers
-template <bool LDS_STORE, int RMAX>
-__global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_sweep(SweepArgs A) {
+template <int STAGE, int RMAX>
+__global__ void __launch_bounds__(kSweepThreads, STAGE == 0 ? 2 * kSweepThreads / 256 : kSweepThreads / 256)
+k_sweep(SweepArgs A) {
+  constexpr bool LDS_STORE = STAGE < 2;
+  constexpr int kCapL = (STAGE == 0) ? kLdsCap : kLdsCapBig;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SweepShared& S = *reinterpret_cast<SweepShared*>(smem_raw);
-  const int CAP = LDS_STORE ? kLdsCap : A.gcap;
+  const int CAP = LDS_STORE ? kCapL : A.gcap;
   float* pbase;
   unsigned short* box16 = nullptr;
   int* box32 = nullptr;
@@ -414,7 +426,7 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
   // from L2 only for the few points that end up inside a closing region) = 16 B per point
   if (LDS_STORE) {
     pbase = reinterpret_cast<float*>(smem_raw + ((sizeof(SweepShared) + 15) & ~size_t(15)));
-    box16 = reinterpret_cast<unsigned short*>(pbase + 4 * kLdsCap);
+    box16 = reinterpret_cast<unsigned short*>(pbase + 4 * kCapL);
   } else {
     pbase = A.gscratch + (size_t)blockIdx.x * 5 * (size_t)A.gcap;
     box32 = reinterpret_cast<int*>(pbase + 4 * (size_t)A.gcap);
@@ -430,8 +442,9 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
   const int R = hc.R;
   const double hh = hc.hand_height;
   int red_sel = 0;
-  const int n_work = LDS_STORE ? A.n_samples : (int)A.st->n_overflow;  // queue filled by k_sweep<true>
-  if (!LDS_STORE && n_work == 0) return;
+  const int n_work = (STAGE == 0) ? A.n_samples
+                                  : (int)(STAGE == 1 ? A.st->n_overflow : A.st->n_overflow2);
+  if (STAGE != 0 && n_work == 0) return;
   if (tid < 20) {
     S.fs[tid] = hc.fs[tid];
     S.fsr[tid] = hc.fsr[tid];
@@ -454,7 +467,7 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
   const bool tighten = (A.flags & 1) == 0;
 
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
-    const int t = LDS_STORE ? w : A.overflow[w];
+    const int t = (STAGE == 0) ? w : (STAGE == 1 ? A.overflow[w] : A.overflow2[w]);
     long long tprev = A.prof ? clock64() : 0;
     if (!A.frame_ok[t]) continue;  // uniform
     const float4 q = A.sample_q[t];
@@ -677,9 +690,12 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
     const bool too_big = K > CAP;
     if (too_big) {  // uniform
       if (tid == 0) {
-        if (LDS_STORE) {
+        if (STAGE == 0) {
           const unsigned at = atomicAdd(&A.st->n_overflow, 1u);
           A.overflow[at] = t;
+        } else if (STAGE == 1) {
+          const unsigned at = atomicAdd(&A.st->n_overflow2, 1u);
+          A.overflow2[at] = t;
         } else {
           atomicOr(&A.st->err_flags, 8u);
         }
@@ -1178,9 +1194,10 @@ __global__ void __launch_bounds__(kSweepThreads, 2 * kSweepThreads / 256) k_swee
   }
 }
 
-static size_t sweep_lds_bytes(bool lds_store) {
+static size_t sweep_lds_bytes(int stage) {
   size_t b = (sizeof(SweepShared) + 15) & ~size_t(15);
-  if (lds_store) b += (size_t)kLdsCap * 4 * 4 + (size_t)kLdsCap * 2;
+  if (stage == 0) b += (size_t)kLdsCap * 4 * 4 + (size_t)kLdsCap * 2;
+  if (stage == 1) b += (size_t)kLdsCapBig * 4 * 4 + (size_t)kLdsCapBig * 2;
   return b;
 }
 
@@ -1241,7 +1258,7 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
   AG2_HIP(c, c->d_table.reserve(std::max<size_t>(n_slots, 1) * sizeof(ag2_hypothesis)));
   AG2_HIP(c, c->d_tab_off.reserve(std::max<size_t>(n_slots, 1) * 8));
   AG2_HIP(c, c->d_tab_keep.reserve(std::max<size_t>(n_slots, 1)));
-  AG2_HIP(c, c->d_overflow.reserve(std::max<size_t>(s, 1) * 4));
+  AG2_HIP(c, c->d_overflow.reserve(std::max<size_t>(s, 1) * 8));  // two queues of sample ids
   if (s == 0) return 0;
   if (emit_lists && c->arena_points == 0) {
     c->arena_points = (size_t)16 << 20;  // 16 Mi points = 768 MiB; grown on AG2_ERR_CAPACITY
@@ -1277,12 +1294,16 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
     AG2_HIP(c, hipMemsetAsync(prof_buf.p, 0, 16 * 8, c->stream));
     A.prof = prof_buf.as<unsigned long long>();
   }
-  const size_t lds = sweep_lds_bytes(true);
+  const size_t lds = sweep_lds_bytes(0), lds_big = sweep_lds_bytes(1);
   typedef void (*SweepFn)(SweepArgs);
-  const SweepFn fn_lds = (R <= 8) ? k_sweep<true, 8> : (R <= 16 ? k_sweep<true, 16> : k_sweep<true, 32>);
-  const SweepFn fn_glb = (R <= 8) ? k_sweep<false, 8> : (R <= 16 ? k_sweep<false, 16> : k_sweep<false, 32>);
+  const SweepFn fn_lds = (R <= 8) ? k_sweep<0, 8> : (R <= 16 ? k_sweep<0, 16> : k_sweep<0, 32>);
+  const SweepFn fn_big = (R <= 8) ? k_sweep<1, 8> : (R <= 16 ? k_sweep<1, 16> : k_sweep<1, 32>);
+  const SweepFn fn_glb = (R <= 8) ? k_sweep<2, 8> : (R <= 16 ? k_sweep<2, 16> : k_sweep<2, 32>);
   AG2_HIP(c, hipFuncSetAttribute((const void*)fn_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
+  AG2_HIP(c, hipFuncSetAttribute((const void*)fn_big, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds_big));
+  A.overflow2 = c->d_overflow.as<int>() + s;  // second queue behind the first
   const int grid = (int)std::min<size_t>(s, 256 * 2);
   hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads), lds, c->stream, A);
   AG2_HIP(c, hipGetLastError());
@@ -1297,14 +1318,16 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
     AG2_HIP(c, hipMemsetAsync(prof_buf.p, 0, 16 * 8, c->stream));
   }
   // Overflow samples (cropped neighbourhood larger than the LDS stage) were queued on the device;
-  // the global-scratch instantiation is always launched and reads the queue length itself
-  // (st->n_overflow), so no host round trip sits between the two launches.
+  // the next stages are always launched and read their queue lengths themselves (st->n_overflow,
+  // st->n_overflow2), so no host round trip sits between the launches.
+  hipLaunchKernelGGL(fn_big, dim3(256), dim3(kSweepThreads), lds_big, c->stream, A);
+  AG2_HIP(c, hipGetLastError());
   const int gcap = 1 << 16, g2 = 256;  // 256 workgroups x 5 x 64 Ki words = 336 MB of scratch
   AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 5 * gcap * 4));
   A.n_overflow = -1;  // read from st->n_overflow on the device
   A.gscratch = c->d_gscratch.as<float>();
   A.gcap = gcap;
-  hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads), sweep_lds_bytes(false), c->stream, A);
+  hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads), sweep_lds_bytes(2), c->stream, A);
   AG2_HIP(c, hipGetLastError());
   AG2_HIP(c, hipEventRecord(c->ev[11], c->stream));
   if (want_prof) {

@@ -279,8 +279,8 @@ def main():
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": ("f64 geometry + f32 LeNet (fp32 MFMA)" if os.environ.get("AG2_LENET_F32") else
-                  "f64 geometry + f32 LeNet (convolutions: fp32 operands as 3 exact bf16 terms on bf16 MFMA, "
-                  "fp32 accumulate; inner products: fp32 MFMA)"),
+                  "f64 geometry + f32 LeNet (conv1, conv2, ip1: every fp32 operand as the exact sum of 3 bf16 "
+                  "terms on bf16 MFMA, fp32 accumulate; ip2 in fp32)"),
         "data": "synthetic",
         "config": {
             "workload": (f"{args.config}: {xyz.shape[0]}-pt {'voxelised (3 mm)' if voxelised else 'un-voxelised'} "
