@@ -76,8 +76,12 @@ struct Eig3 {
   double v[3][3];  // columns = eigenvectors
 };
 
+// A converged pair (|apq| <= 2^-60 |aqq - app|: the rotation would change neither the diagonal nor, at
+// f64 resolution, the eigenvectors) is annihilated without rotating -- same rule as the oracle.
 #define AG2_JACOBI_ROT(APP, AQQ, APQ, ARP, ARQ, VP, VQ)                          \
-  if (APQ != 0.0) {                                                              \
+  if (APQ != 0.0 && __builtin_fabs(APQ) <= 0x1p-60 * __builtin_fabs(AQQ - APP)) { \
+    APQ = 0.0;                                                                   \
+  } else if (APQ != 0.0) {                                                       \
     const double theta = (AQQ - APP) / (2.0 * APQ);                              \
     double t = 1.0 / (__builtin_fabs(theta) + __builtin_sqrt(theta * theta + 1.0)); \
     if (theta < 0.0) t = -t;                                                     \

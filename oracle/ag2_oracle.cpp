@@ -60,6 +60,14 @@ void jacobi3(double A[3][3], double V[3][3], double d[3]) {
       const double apq = A[p][q];
       if (apq == 0.0) continue;
       const double app = A[p][p], aqq = A[q][q];
+      // Converged pair: with |apq| <= 2^-60 |aqq - app| the rotation angle is below 2^-60, so the
+      // rotation would change neither the diagonal (by t*apq < 2^-120 of the gap) nor, at f64
+      // resolution, the eigenvectors (c == 1.0 exactly, s < 2^-60): annihilate without rotating.
+      if (std::fabs(apq) <= 0x1p-60 * std::fabs(aqq - app)) {
+        A[p][q] = 0.0;
+        A[q][p] = 0.0;
+        continue;
+      }
       const double theta = (aqq - app) / (2.0 * apq);
       double t = 1.0 / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
       if (theta < 0.0) t = -t;
