@@ -26,9 +26,10 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 # kernels whose traffic bench.py can report, keyed by the short name it uses
+# (a short name sums every kernel its pattern matches: both renderers, both overflow stages ...)
 SHORT = {
-    "k_sweep": re.compile(r"k_sweep<true"),
-    "k_sweep_overflow": re.compile(r"k_sweep<false"),
+    "k_sweep": re.compile(r"k_sweep<(true|0)"),
+    "k_sweep_overflow": re.compile(r"k_sweep<(false|1|2)"),
     "k_normals": re.compile(r"k_normals"),
     "k_frames": re.compile(r"k_frames"),
     "k_render": re.compile(r"k_render"),
@@ -109,7 +110,8 @@ def main():
             w.writerows(rows)
         tpath = os.path.join(ROOT, "pmc_traffic.json")
         traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        traffic[config] = {s: r[4] for s, rx in SHORT.items() for r in rows if rx.search(r[0])}
+        traffic[config] = {s: sum(r[4] for r in rows if rx.search(r[0])) for s, rx in SHORT.items()
+                           if any(rx.search(r[0]) for r in rows)}
         traffic["_source"] = (f"profiles/{os.path.basename(dst)} (rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
                               "WRITE_SIZE, separate passes of python3 bench.py --steps 3 --warmup 1 --no-cpu); "
                               "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch")
