@@ -17,8 +17,11 @@
 //     rows ky / ky+1, a zero-weight sixth row pads 5 -> 6; conv2: channels c / c+1), hence every
 //     A-operand read is one ds_read with an immediate offset off a per-tile base;
 //   * weights are pre-packed on the host in exactly the lane order of the B operand.
-// k_lenet_fc: ip1 + ReLU + ip2 as a 64-image x 512-output tile per workgroup (K = 7200), A staged
-// through LDS, B streamed from L2 / Infinity Cache in lane order, ip2 folded into the epilogue.
+// k_lenet_fc1: ip1 partial sums, 64-image x 128-output tiles with split K (K = 7200), A staged
+// through LDS, B streamed from L2 / Infinity Cache in lane order; k_lenet_fc_finish adds the partial
+// sums in split order, applies bias + ReLU and ip2.
+// These f32-input kernels are the AG2_LENET_F32=1 path; the default convolutions and ip1 run on the
+// bf16 matrix cores with three-term operand splits (k_lenet_x3.hip) and share k_lenet_fc_finish.
 #include "ag2_internal.h"
 
 namespace ag2 {

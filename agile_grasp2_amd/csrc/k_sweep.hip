@@ -538,8 +538,9 @@ k_sweep(SweepArgs A) {
     }
     __syncthreads();
     // ---- piece table: rows cut into pieces of <= PL consecutive points, in canonical order -----
-    // One thread walks one piece, so all 256 threads have an independent stream of loads in flight
-    // (the rows are short after the culling above; a wave per row would idle most lanes).
+    // A small group of lanes takes one piece in the crop passes, so every wave has many independent
+    // loads in flight (the rows are short after the culling above; a wave per row would idle most
+    // lanes).
     int nrows_c = 0, kcand = 0;
     {
       int cnt = 0, tot = 0;

@@ -83,7 +83,7 @@ typedef struct ag2_hypothesis {
 typedef struct ag2_counters {
   int64_t n_points, n_valid_points, n_samples, n_frames, n_hypotheses, n_pruned, n_scored, n_selected;
   int64_t sum_k1, sum_k2, sum_kcrop, sum_p;  /* measured neighbourhood sizes (roofline bytes) */
-  int64_t n_overflow_samples;                /* samples that took the global-memory sweep path */
+  int64_t n_overflow_samples;                /* samples whose cropped list did not fit the first sweep stage */
   int64_t reserved;
 } ag2_counters;
 
@@ -94,14 +94,14 @@ typedef struct ag2_times {
   float grid_ms;        /* K0 search grid (ag2_set_cloud*) */
   float normals_ms;     /* K1 k_normals */
   float frames_ms;      /* K2 k_frames */
-  float sweep_ms;       /* K3 k_sweep, LDS-staged instantiation */
+  float sweep_ms;       /* K3 k_sweep, first stage (cropped list in 80 KiB of LDS) */
   float compact_ms;     /* prune-flag compaction + image descriptors */
   float render_ms;      /* K4 k_render */
   float lenet_conv_ms;  /* K5 k_lenet_conv */
   float lenet_fc_ms;    /* K5 k_lenet_fc */
   float select_ms;      /* K6 score scatter, threshold compaction, record gather */
   float total_ms;       /* first to last event of the call */
-  float sweep_overflow_ms; /* K3 k_sweep, global-scratch instantiation (oversized neighbourhoods) */
+  float sweep_overflow_ms; /* K3 k_sweep, later stages for oversized neighbourhoods (160 KiB of LDS, then global scratch) */
   float preprocess_ms;  /* workspace filter + voxel grid (ag2_preprocess_cloud*), without the grid build */
 } ag2_times;
 
@@ -156,7 +156,11 @@ int ag2_render_images_from_points(ag2_ctx* c, size_t n, const int64_t* offsets_n
 int ag2_lenet_load(ag2_ctx* c, const float* conv1_w, const float* conv1_b, const float* conv2_w,
                    const float* conv2_b, const float* ip1_w, const float* ip1_b,
                    const float* ip2_w, const float* ip2_b);
-/* Classifier::ClassifyBatch / PredictBatch, caffe_classifier.cpp:70-127: n x 2 raw ip2 logits. */
+/* Classifier::ClassifyBatch / PredictBatch, caffe_classifier.cpp:70-127: n x 2 raw ip2 logits.
+ * fp32 like Caffe.  By default conv1, conv2 and ip1 run on the bf16 matrix cores with every fp32
+ * operand written as the exact sum of three bf16 terms and fp32 accumulation (deviation from a
+ * sequential fp32 evaluation: that of a re-ordered fp32 sum); with AG2_LENET_F32=1 in the
+ * environment when ag2_lenet_load is called they run on the f32-input matrix instructions. */
 int ag2_lenet_forward(ag2_ctx* c, const uint8_t* images_hwc, size_t n, float* ip2_out);
 /* GraspDetector::detectGraspPoses, grasp_detector.cpp:84-282 (antipodal_mode PREDICTION, no
  * clustering): hypotheses -> [prune] -> images -> LeNet -> score >= min_score_diff -> top
