@@ -259,6 +259,7 @@ int ag2_set_cloud(ag2_ctx* c, const float* xyz, size_t n, size_t stride_bytes,
   if (n > (size_t)1 << 30) return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 points");
   c->n = n;
   c->has_cloud = c->has_normals = false;
+  c->bounds_known = false;
   std::vector<float> pack(n * 4);
   const char* base = (const char*)xyz;
   for (size_t i = 0; i < n; i++) {
@@ -305,6 +306,7 @@ int ag2_set_cloud_device(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_
   if (n > (size_t)1 << 30) return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 points");
   c->n = n;
   c->has_cloud = c->has_normals = false;
+  c->bounds_known = false;
   AG2_HIP(c, c->d_xyz_in.reserve(std::max<size_t>(n, 1) * 16));
   const int rc = pack_device_xyz(c, d_xyz, n, stride_bytes, c->d_xyz_in.as<float4>());
   if (rc) return rc;

@@ -253,20 +253,36 @@ int build_grid(ag2_ctx* c) {
   c->grid = GridDesc{};
   if (n == 0) return 0;
   const float4* xyz = c->d_xyz_in.as<float4>();
-  const int nb = std::min((n + 255) / 256, 128);  // 7 contended atomics per workgroup: keep them few
-  hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, c->stream, xyz, n, st);
-  DevStats hs;
-  AG2_HIP(c, hipMemcpyAsync(pin_small(c), st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
-  AG2_HIP(c, hipStreamSynchronize(c->stream));
-  __builtin_memcpy(&hs, pin_small(c), sizeof(hs));
-  c->n_valid = hs.bounds[6];
+  float bmin[3], bmax[3];
+  if (c->bounds_known) {
+    // the front end already knows the extent of what it produced (all points finite): no bounds
+    // pass, no host round trip
+    c->bounds_known = false;
+    for (int a = 0; a < 3; a++) {
+      bmin[a] = c->known_min[a];
+      bmax[a] = c->known_max[a];
+    }
+    c->n_valid = (size_t)n;
+  } else {
+    const int nb = std::min((n + 255) / 256, 128);  // 7 contended atomics per workgroup: keep them few
+    hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, c->stream, xyz, n, st);
+    DevStats hs;
+    AG2_HIP(c, hipMemcpyAsync(pin_small(c), st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+    __builtin_memcpy(&hs, pin_small(c), sizeof(hs));
+    c->n_valid = hs.bounds[6];
+    for (int a = 0; a < 3; a++) {
+      bmin[a] = ord2f((int)hs.bounds[a]);
+      bmax[a] = ord2f((int)hs.bounds[3 + a]);
+    }
+  }
   if (c->n_valid == 0) return 0;
   GridDesc g{};
   g.inv = 1.0f / (float)c->p.grid_cell;
   long long ncells = 1;
   for (int a = 0; a < 3; a++) {
-    g.o[a] = ord2f((int)hs.bounds[a]);
-    const float mx = ord2f((int)hs.bounds[3 + a]);
+    g.o[a] = bmin[a];
+    const float mx = bmax[a];
     g.dims[a] = (int)floorf((mx - g.o[a]) * g.inv) + 1;
     ncells *= g.dims[a];
   }

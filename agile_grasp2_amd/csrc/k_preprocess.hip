@@ -343,10 +343,20 @@ static int preprocess_resident(ag2_ctx* c, size_t n, bool have_cam, bool have_nr
                      have_nrm ? c->d_raw_nrm.as<float4>() : (const float4*)nullptr, pf, ni, kept,
                      have_nrm ? c->d_tmp.as<float4>() : (float4*)nullptr);
   PreStats hs;
-  AG2_HIP(c, hipMemcpyAsync(&hs, ps, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipMemcpyAsync(pin_small(c), ps, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
+  __builtin_memcpy(&hs, pin_small(c), sizeof(hs));
   const size_t m = hs.n_keep;
-  if (!voxelize || m == 0) return finish(m);
+  if (!voxelize || m == 0) {
+    if (m) {  // extent of the survivors: the grid build needs no bounds pass of its own
+      for (int a = 0; a < 3; a++) {
+        c->known_min[a] = ord2f(hs.mn[a]);
+        c->known_max[a] = ord2f(hs.mx[a]);
+      }
+      c->bounds_known = true;
+    }
+    return finish(m);
+  }
 
   VoxDesc v{};
   v.cell = (float)voxel_size;
@@ -391,8 +401,16 @@ static int preprocess_resident(ag2_ctx* c, size_t n, bool have_cam, bool have_nr
   }
   AG2_HIP(c, hipGetLastError());
   unsigned n_vox = 0;
-  AG2_HIP(c, hipMemcpyAsync(&n_vox, wrank + words, 4, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipMemcpyAsync(pin_small(c), wrank + words, 4, hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
+  __builtin_memcpy(&n_vox, pin_small(c), 4);
+  // the voxel lattice spans [mn, (dims - 1) * cell + mn] per axis (both end voxels are occupied, by
+  // the extreme points); same float expression as k_vox_emit
+  for (int a = 0; a < 3; a++) {
+    c->known_min[a] = v.mn[a];
+    c->known_max[a] = (float)(v.dims[a] - 1) * v.cell + v.mn[a];
+  }
+  c->bounds_known = n_vox > 0;
   return finish(n_vox);
 }
 
