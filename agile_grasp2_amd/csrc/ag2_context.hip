@@ -366,6 +366,21 @@ int ag2_get_grid_perm(ag2_ctx* c, int32_t* perm, size_t cap, size_t* n_valid) {
   return 0;
 }
 
+int ag2_set_grid_origin(ag2_ctx* c, const float* origin3) {
+  if (!c) return AG2_ERR_ARG;
+  c->origin_set = origin3 != nullptr;
+  if (origin3) {
+    for (int a = 0; a < 3; a++) {
+      if (!std::isfinite(origin3[a])) {
+        c->origin_set = false;
+        return set_err(c, AG2_ERR_ARG, "grid origin must be finite");
+      }
+      c->origin[a] = origin3[a];
+    }
+  }
+  return 0;
+}
+
 int ag2_get_counters(ag2_ctx* c, ag2_counters* out) {
   if (!c || !out) return AG2_ERR_ARG;
   (void)hipSetDevice(c->device);

@@ -122,6 +122,8 @@ struct ag2_ctx {
   ag2::DevBuf d_hist;      // 65536-bin digit histogram of the sub-sampling radix select
   ag2::DevBuf d_samples;   // int32 sample indices left resident by ag2_subsample_uniformly
   size_t n_resident_samples = 0;
+  bool origin_set = false;    // ag2_set_grid_origin: grid origin (and cloud minimum) of the whole cloud
+  float origin[3] = {0, 0, 0};
   bool bounds_known = false;  // set by the front end for the next grid build: extent of d_xyz_in
   float known_min[3] = {0, 0, 0}, known_max[3] = {0, 0, 0};
 

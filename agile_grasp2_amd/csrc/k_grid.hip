@@ -281,12 +281,15 @@ int build_grid(ag2_ctx* c) {
   g.inv = 1.0f / (float)c->p.grid_cell;
   long long ncells = 1;
   for (int a = 0; a < 3; a++) {
-    g.o[a] = bmin[a];
+    // a spatial tile bins its points from the origin of the WHOLE cloud (ag2_set_grid_origin)
+    if (c->origin_set && bmin[a] < c->origin[a])
+      return set_err(c, AG2_ERR_ARG, "a point lies below the grid origin given to ag2_set_grid_origin");
+    g.o[a] = c->origin_set ? c->origin[a] : bmin[a];
     const float mx = bmax[a];
     g.dims[a] = (int)floorf((mx - g.o[a]) * g.inv) + 1;
     ncells *= g.dims[a];
   }
-  c->min_z = g.o[2];
+  c->min_z = g.o[2];  // pcl::getMinMax3D of the (whole) cloud, grasp_detector.cpp:152-153
   if (ncells > (1ll << 30))
     return set_err(c, AG2_ERR_CAPACITY, "search grid has more than 2^30 cells; raise grid_cell");
   g.ncells = (int)ncells;

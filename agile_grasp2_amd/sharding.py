@@ -53,3 +53,59 @@ def all_gather_tables(local_tab_u8, world: int):
     out = torch.empty(local_tab_u8.numel() * world, dtype=torch.uint8, device=local_tab_u8.device)
     dist.all_gather_into_tensor(out, local_tab_u8)
     return out
+
+
+# ---- spatial tiles: for clouds too large to replicate on every GPU ------------------------------
+#
+# A sample's hypotheses depend on the cloud only through the points within
+# max(nn_radius_hands, nn_radius_taubin) of it and through those points' normals, which in turn
+# depend on the points within normals_radius of each of them.  So a rank that owns the samples of
+# one x-interval needs the points of that interval widened by the sum of the two radii and nothing
+# else.  Three things make the result IDENTICAL to the unsplit run instead of merely close:
+#   * the sample list is put in x order ONCE, independently of the number of ranks, and the RNG
+#     stays keyed by the position in that list (slot_base + i);
+#   * the tile keeps its points in their original relative order, so every neighbourhood is visited
+#     in the same canonical (cell, index) order;
+#   * the rank bins against the WHOLE cloud's minimum (ag2_set_grid_origin), so cells -- and the
+#     cloud minimum z the prune test uses -- are those of the unsplit run.
+
+
+def cloud_origin(xyz: np.ndarray) -> np.ndarray:
+    """Per-axis minimum over the finite points, as float32: the unsplit run's grid origin."""
+    a = np.asarray(xyz, dtype=np.float32)
+    ok = np.isfinite(a).all(axis=1)
+    return a[ok].min(axis=0).astype(np.float32)
+
+
+def order_samples_by_x(xyz: np.ndarray, sample_idx: np.ndarray) -> np.ndarray:
+    """The sample list in ascending x (stable): the rank-count-independent order tiles shard."""
+    sample_idx = np.asarray(sample_idx)
+    return sample_idx[np.argsort(np.asarray(xyz)[sample_idx, 0], kind="stable")]
+
+
+def tile_halo(nn_radius_hands: float, nn_radius_taubin: float, normals_radius: float) -> float:
+    """Width of the halo a tile needs either side of its samples' x-interval.  The last term covers
+    the rounding of the f32 coordinate differences the radius tests see."""
+    return max(nn_radius_hands, nn_radius_taubin) + normals_radius + 1e-5
+
+
+def tile_points(xyz: np.ndarray, ordered_sample_idx: np.ndarray, rank: int, world: int,
+                halo: float):
+    """Tile of `rank`: (keep, local_sample_idx, slot_base).
+
+    keep              ascending indices of the points the rank must hold (apply the same subset to
+                      the camera-source and normals arrays);
+    local_sample_idx  the rank's samples as indices into xyz[keep];
+    slot_base         position of the rank's first sample in ordered_sample_idx (RNG key and table
+                      slot, as with replicated clouds)."""
+    xyz = np.asarray(xyz)
+    b, e = shard_range(len(ordered_sample_idx), rank, world)
+    mine = np.asarray(ordered_sample_idx[b:e], dtype=np.int64)
+    if len(mine) == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int32), b
+    x = xyz[:, 0].astype(np.float64)
+    lo, hi = x[mine].min() - halo, x[mine].max() + halo
+    keep = np.flatnonzero((x >= lo) & (x <= hi))      # NaN x compares false: dropped, never a neighbour
+    local = np.searchsorted(keep, mine).astype(np.int32)
+    assert (keep[local] == mine).all()
+    return keep, local, b

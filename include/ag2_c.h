@@ -173,6 +173,14 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
  * (i * R + orientation), n_points == 0 where empty, score filled where scored.  Copied
  * device-to-device into d_dst (e.g. a torch tensor) for the RCCL all-gather. */
 int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes);
+/* Spatial tiles (multi-GPU, for clouds too large to replicate): origin of the search grid -- and the
+ * cloud minimum the prune test uses (pcl::getMinMax3D, grasp_detector.cpp:152-153) -- for the clouds
+ * set afterwards; NULL = automatic (per-axis minimum of the cloud).  A rank that holds only a tile
+ * (its samples' x-range plus a halo of nn_radius_hands + normals_radius, points in their original
+ * relative order) passes the minimum of the WHOLE cloud: it then bins its points, orders every
+ * neighbourhood and prunes exactly as the unsplit run, so its hypotheses are identical.  Every point
+ * of a cloud set afterwards must be >= the origin on every axis. */
+int ag2_set_grid_origin(ag2_ctx* c, const float* origin3);
 
 /* ---- the step in front of the path: GraspDetector::preprocessPointCloud, grasp_detector.cpp:285-335 ----
  * Steps 1-2 on the GPU: CloudCamera::filterWorkspace (cloud_camera.cpp:89-121; bounds =

@@ -140,8 +140,10 @@ struct Grid {
     return ((int64_t)cz * dims[1] + cy) * dims[0] + cx;
   }
 
+  // origin: nullptr = per-axis minimum of the finite points; else the caller's (a spatial tile passes
+  // the minimum of the whole cloud so that it bins its points exactly as the whole cloud would)
   void build(const std::vector<float>& x, const std::vector<float>& y, const std::vector<float>& z,
-             double cell) {
+             double cell, const float* origin = nullptr) {
     const size_t n = x.size();
     float mn[3] = {std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(),
                    std::numeric_limits<float>::infinity()};
@@ -164,7 +166,7 @@ struct Grid {
       for (size_t i = 0; i < n; i++) perm[i] = (int32_t)i;
       return;
     }
-    for (int a = 0; a < 3; a++) o[a] = mn[a];
+    for (int a = 0; a < 3; a++) o[a] = origin ? origin[a] : mn[a];
     for (int a = 0; a < 3; a++) dims[a] = cell_of(mx[a], a) + 1;
     const int64_t ncells = (int64_t)dims[0] * dims[1] * dims[2];
     std::vector<int64_t> keys(n, ncells);  // invalid points sort to the end
@@ -242,6 +244,8 @@ struct ag2o_ctx {
   std::vector<double> cos_t, sin_t;    // per orientation
   std::vector<double> depths;          // deepenHand depth sequence
   int min_inliers = 0;                 // HandleSearch::setMinInliers; grasp_detector.cpp:59-65
+  bool has_origin = false;             // ag2o_set_grid_origin
+  float origin[3] = {0, 0, 0};
 };
 
 namespace {
@@ -890,11 +894,18 @@ int ag2o_set_cloud(ag2o_ctx* c, const float* xyz, size_t n, size_t stride_bytes,
   }
   c->cam.assign(n * (size_t)n_cams, 1);  // cloud_camera.cpp:59 file ctor: ones
   if (cam_source) std::copy(cam_source, cam_source + n * (size_t)n_cams, c->cam.begin());
-  c->grid.build(c->x, c->y, c->z, c->p.grid_cell);
-  // pcl::getMinMax3D over finite points, grasp_detector.cpp:152-153
+  if (c->has_origin)
+    for (size_t i = 0; i < n; i++)
+      if (finite3f(c->x[i], c->y[i], c->z[i]) &&
+          (c->x[i] < c->origin[0] || c->y[i] < c->origin[1] || c->z[i] < c->origin[2]))
+        return fail(c, "set_cloud: a point lies below the grid origin given to ag2o_set_grid_origin");
+  c->grid.build(c->x, c->y, c->z, c->p.grid_cell, c->has_origin ? c->origin : nullptr);
+  // pcl::getMinMax3D over finite points, grasp_detector.cpp:152-153 (a tile: the whole cloud's
+  // minimum, which is what the caller passed as the origin)
   c->min_z = std::numeric_limits<float>::infinity();
   for (size_t i = 0; i < n; i++)
     if (finite3f(c->x[i], c->y[i], c->z[i])) c->min_z = std::min(c->min_z, c->z[i]);
+  if (c->has_origin) c->min_z = c->origin[2];
   c->nx.assign(n, 0.f); c->ny.assign(n, 0.f); c->nz.assign(n, 0.f);
   c->has_normals = false;
   if (normals) {
@@ -1161,6 +1172,14 @@ int ag2o_find_clusters(const ag2o_hypothesis* hands, size_t n, int min_inliers, 
   }
   *n_out = k;
   return (k > cap) ? -2 : 0;
+}
+
+int ag2o_set_grid_origin(ag2o_ctx* c, const float* origin3) {
+  if (!c) return -1;
+  c->has_origin = origin3 != nullptr;
+  if (origin3)
+    for (int a = 0; a < 3; a++) c->origin[a] = origin3[a];
+  return 0;
 }
 
 int ag2o_set_min_inliers(ag2o_ctx* c, int min_inliers) {

@@ -125,6 +125,11 @@ int ag2o_find_clusters(const ag2o_hypothesis* hands, size_t n, int min_inliers, 
 /* HandleSearch::setMinInliers: > 0 makes ag2o_detect cluster before the top-k (grasp_detector.cpp:228-236) */
 int ag2o_set_min_inliers(ag2o_ctx* c, int min_inliers);
 
+/* Spatial tiles (multi-GPU): origin of the search grid for the clouds set afterwards
+ * (NULL = automatic: per-axis minimum).  A tile passes the minimum of the WHOLE cloud, which makes
+ * its binning, its canonical neighbour order and the prune's cloud minimum those of the unsplit run. */
+int ag2o_set_grid_origin(ag2o_ctx* c, const float* origin3);
+
 /* Preprocessing in front of the path (GraspDetector::preprocessPointCloud, grasp_detector.cpp:285-335):
  * CloudCamera::filterWorkspace (cloud_camera.cpp:89-121, bounds = params.workspace) and
  * CloudCamera::voxelizeCloud (:124-168); the result becomes the context's cloud.  flags bit 0:

@@ -276,6 +276,10 @@ class Oracle:
                                     C.byref(na)))
         return sel[: ns.value].copy(), allh[: na.value].copy()
 
+    def set_grid_origin(self, origin):
+        o = None if origin is None else np.ascontiguousarray(origin, dtype=np.float32)
+        self._ck(self.L.ag2o_set_grid_origin(self.h, _ptr(o)))
+
     def set_min_inliers(self, k):
         self._ck(self.L.ag2o_set_min_inliers(self.h, C.c_int(k)))
 
