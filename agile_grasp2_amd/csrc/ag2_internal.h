@@ -44,7 +44,7 @@ struct DevStats {
   unsigned int n_sel;                // scored hypotheses with score >= min_score_diff
   unsigned int n_clu;                // selected hypotheses that survive the clustering
   unsigned int n_overflow2;          // samples whose cropped list exceeds the 160-KiB LDS stage too
-  unsigned int pad0;
+  unsigned int work_next[3];         // k_sweep work queues, one per stage (items beyond the first grid)
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
   unsigned int pad1;

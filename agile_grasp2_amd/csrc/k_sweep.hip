@@ -394,6 +394,7 @@ struct SweepShared {
   long long arena_off;
   int flag;
   unsigned dead;                 // pass A: orientations known to have a point behind the hand
+  int next_w[2];                 // work item of the next loop iteration (double-buffered)
 };
 
 // Cropped points resident in LDS (16 B + a 2-B in-box index each): whatever two workgroups per CU
@@ -466,7 +467,23 @@ k_sweep(SweepArgs A) {
   const float r2_hands = hc.r2_hands;
   const bool tighten = (A.flags & 1) == 0;
 
-  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+  // Work distribution: the cost of a sample varies with its neighbourhood, and a workgroup sees only
+  // about ten of them, so a static stride leaves a long tail.  The first gridDim.x items are taken
+  // by position, every further one from a device counter; thread 0 asks for the next item at the
+  // START of the current one, so the atomic's latency is never waited for.  Every workgroup leaves
+  // the loop with the first item >= n_work it draws.  Results go to fixed slots: the order in which
+  // samples are processed changes nothing.
+  unsigned nxt = 0;
+  int it = 0;
+  auto next_work = [&]() -> int {
+    if (tid == 0) S.next_w[it & 1] = (int)nxt;
+    __syncthreads();  // also: every reader of S of this iteration is done
+    const int w = __builtin_amdgcn_readfirstlane(S.next_w[it & 1]);
+    it++;  // the slot is rewritten two barriers from now: no reader can still be pending
+    return w;
+  };
+  for (int w = blockIdx.x; w < n_work; w = next_work()) {
+    if (tid == 0) nxt = gridDim.x + atomicAdd(&A.st->work_next[STAGE], 1u);
     const int t = (STAGE == 0) ? w : (STAGE == 1 ? A.overflow[w] : A.overflow2[w]);
     long long tprev = A.prof ? clock64() : 0;
     if (!A.frame_ok[t]) continue;  // uniform
@@ -481,7 +498,7 @@ k_sweep(SweepArgs A) {
     const int ny = qr.empty ? 0 : (qr.hi[1] - qr.lo[1] + 1);
     const int nz = qr.empty ? 0 : (qr.hi[2] - qr.lo[2] + 1);
     const int nrows = ny * nz;  // <= kMaxRows by check_params
-    __syncthreads();            // previous sample's readers of S are done
+    // (the previous sample's readers of S are done: barrier in next_work)
     for (int r = tid; r < nrows; r += kSweepThreads) {
       const int cz = qr.lo[2] + r / ny, cy = qr.lo[1] + r % ny;
       int cxa = qr.lo[0], cxb = qr.hi[0];
