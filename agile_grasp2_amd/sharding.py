@@ -77,10 +77,18 @@ def cloud_origin(xyz: np.ndarray) -> np.ndarray:
     return a[ok].min(axis=0).astype(np.float32)
 
 
-def order_samples_by_x(xyz: np.ndarray, sample_idx: np.ndarray) -> np.ndarray:
-    """The sample list in ascending x (stable): the rank-count-independent order tiles shard."""
+def longest_axis(xyz: np.ndarray) -> int:
+    """Axis along which tiles are thinnest relative to their halo: the cloud's longest extent."""
+    a = np.asarray(xyz, dtype=np.float32)
+    ok = np.isfinite(a).all(axis=1)
+    return int(np.argmax(a[ok].max(axis=0) - a[ok].min(axis=0)))
+
+
+def order_samples_by_x(xyz: np.ndarray, sample_idx: np.ndarray, axis: int = 0) -> np.ndarray:
+    """The sample list in ascending x -- or another `axis` -- (stable): the rank-count-independent
+    order tiles shard."""
     sample_idx = np.asarray(sample_idx)
-    return sample_idx[np.argsort(np.asarray(xyz)[sample_idx, 0], kind="stable")]
+    return sample_idx[np.argsort(np.asarray(xyz)[sample_idx, axis], kind="stable")]
 
 
 def tile_halo(nn_radius_hands: float, nn_radius_taubin: float, normals_radius: float) -> float:
@@ -90,8 +98,9 @@ def tile_halo(nn_radius_hands: float, nn_radius_taubin: float, normals_radius: f
 
 
 def tile_points(xyz: np.ndarray, ordered_sample_idx: np.ndarray, rank: int, world: int,
-                halo: float):
-    """Tile of `rank`: (keep, local_sample_idx, slot_base).
+                halo: float, axis: int = 0):
+    """Tile of `rank` along `axis` (the one the samples were ordered by): (keep, local_sample_idx,
+    slot_base).
 
     keep              ascending indices of the points the rank must hold (apply the same subset to
                       the camera-source and normals arrays);
@@ -103,7 +112,7 @@ def tile_points(xyz: np.ndarray, ordered_sample_idx: np.ndarray, rank: int, worl
     mine = np.asarray(ordered_sample_idx[b:e], dtype=np.int64)
     if len(mine) == 0:
         return np.zeros(0, np.int64), np.zeros(0, np.int32), b
-    x = xyz[:, 0].astype(np.float64)
+    x = xyz[:, axis].astype(np.float64)
     lo, hi = x[mine].min() - halo, x[mine].max() + halo
     keep = np.flatnonzero((x >= lo) & (x <= hi))      # NaN x compares false: dropped, never a neighbour
     local = np.searchsorted(keep, mine).astype(np.int32)

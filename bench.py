@@ -10,9 +10,12 @@ full pass over one cloud.  value = hypotheses scored by all ranks / max-over-ran
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg1|cfg3] [--no-cpu]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the cloud is replicated, every rank
-sweeps its own num_samples samples (weak scaling) and the fixed-slot candidate tables are
-exchanged with one RCCL all-gather.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the cloud is cut into spatial tiles.
+The N x num_samples samples are ordered along the cloud's longest axis once, rank r owns a contiguous
+range of them and holds only the points of that interval plus a halo of nn_radius_hands + normals_radius, binned
+against the whole cloud's minimum (ag2_set_grid_origin) -- its hypotheses are exactly those of an
+unsplit run (tests/test_tiles.py).  Every rank sweeps num_samples samples (weak scaling) and the
+fixed-slot candidate tables are exchanged with one RCCL all-gather.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (live HIP-event
 durations on the launch stream; algorithmic bytes/flops per SURVEY.md section 8d with the measured
@@ -148,14 +151,29 @@ def main():
 
     n_points, S, R, voxelised, kind = CONFIGS[args.config]
     xyz, ws = scene.make_scene(args.seed, n_points, kind=kind, voxel=scene.VOXEL if voxelised else None)
-    idx = scene.draw_samples(args.seed + 1000 * rank, xyz.shape[0], S)
+    from agile_grasp2_amd import sharding
+    prm = launch_params(ws, R)
+    n_cloud = xyz.shape[0]
+    origin, slot_base, tile_note = None, 0, None
+    if dist_on:
+        # spatial tiles: same scene and same N x S samples on every rank, cut by x
+        axis = sharding.longest_axis(xyz)
+        ordered = sharding.order_samples_by_x(xyz, scene.draw_samples(args.seed, n_cloud, S * world), axis)
+        halo = sharding.tile_halo(prm["nn_radius_hands"], prm["nn_radius_taubin"], 0.01)
+        keep, idx, slot_base = sharding.tile_points(xyz, ordered, rank, world, halo, axis)
+        origin = sharding.cloud_origin(xyz)
+        xyz = np.ascontiguousarray(xyz[keep])
+        tile_note = f"{xyz.shape[0]} of {n_cloud} points on rank 0"
+    else:
+        idx = scene.draw_samples(args.seed, n_cloud, S)
     weights = make_lenet_weights(7)
-    d = capi.Detector(device=local_rank, **launch_params(ws, R))
+    d = capi.Detector(device=local_rank, **prm)
+    assert abs(d.params.normals_radius - 0.01) < 1e-12     # the halo above assumes the default
     d.set_stream(torch.cuda.current_stream().cuda_stream)
     d.lenet_load(weights)
-    xyz_dev = torch.from_numpy(xyz).cuda()          # HBM-resident input
+    d.set_grid_origin(origin)
+    xyz_dev = torch.from_numpy(xyz).cuda()          # HBM-resident input (this rank's tile when N > 1)
     torch.cuda.synchronize()
-    from agile_grasp2_amd import sharding
     slot_bytes = S * R * sharding.SLOT_BYTES
     local_tab = torch.empty(slot_bytes, dtype=torch.uint8, device="cuda") if dist_on else None
 
@@ -164,7 +182,7 @@ def main():
     def step():
         d.set_cloud_device(xyz_dev.data_ptr(), xyz.shape[0], 12)
         d.compute_normals()
-        sel, n_scored = d.detect(sample_idx=idx, slot_base=rank * S, seed=args.seed, do_prune=True,
+        sel, n_scored = d.detect(sample_idx=idx, slot_base=slot_base, seed=args.seed, do_prune=True,
                                  want_all=False)
         if dist_on:
             # the path's one exchange step: fixed-slot candidate tables, RCCL all-gather over xGMI
@@ -208,9 +226,10 @@ def main():
     dd = capi.Detector(device=local_rank, **dict(launch_params(ws, R), debug_flags=1))
     dd.set_stream(torch.cuda.current_stream().cuda_stream)
     dd.lenet_load(weights)
+    dd.set_grid_origin(origin)
     dd.set_cloud_device(xyz_dev.data_ptr(), xyz.shape[0], 12)
     dd.compute_normals()
-    dd.detect(sample_idx=idx, slot_base=rank * S, seed=args.seed, do_prune=True, want_all=False)
+    dd.detect(sample_idx=idx, slot_base=slot_base, seed=args.seed, do_prune=True, want_all=False)
     sum_k2 = dd.counters().sum_k2
     dd.close()
 
@@ -283,18 +302,20 @@ def main():
                   "terms on bf16 MFMA, fp32 accumulate; ip2 in fp32)"),
         "data": "synthetic",
         "config": {
-            "workload": (f"{args.config}: {xyz.shape[0]}-pt {'voxelised (3 mm)' if voxelised else 'un-voxelised'} "
+            "workload": (f"{args.config}: {n_cloud}-pt {'voxelised (3 mm)' if voxelised else 'un-voxelised'} "
                          f"synthetic tabletop cloud, num_samples={S}/GPU, {R} orientations, launch-file hand "
                          f"geometry, seeded LeNet weights"),
-            "n_points": int(xyz.shape[0]), "num_samples_per_gpu": S, "num_orientations": R,
+            "n_points": int(n_cloud), "num_samples_per_gpu": S, "num_orientations": R,
             "hypotheses_per_step_per_gpu": int(c.n_hypotheses), "scored_per_step_per_gpu": int(n_img),
             "slots_swept_per_s": S * R * world / (elapsed / K),
             "mean_K1": c.sum_k1 / max(1, c.n_valid_points), "mean_K2": sum_k2 / max(1, c.n_frames),
             "mean_Kcrop": c.sum_kcrop / max(1, c.n_frames), "mean_P": c.sum_p / max(1, c.n_hypotheses),
             "overflow_samples": int(c.n_overflow_samples),
-            "parallelism": ("single GPU" if world == 1 else
-                            f"cloud replicated, sample-range sharding x{world}, one RCCL all-gather of the "
-                            f"{S * R}-slot x 176 B candidate table per rank"),
+            "parallelism": ("single GPU" if not dist_on else
+                            f"{world} spatial tiles along the cloud's longest axis (interval of the rank's {S} "
+                            f"samples + 0.11 m halo, "
+                            f"{tile_note}), one RCCL all-gather of the {S * R}-slot x 176 B candidate "
+                            f"table per rank"),
         },
         "stage_ms": {k: round(v, 4) for k, v in ms.items()},
         "roofline": roofline,

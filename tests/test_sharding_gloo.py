@@ -1,4 +1,5 @@
-"""N > 1 path on CPU: world_size-2 gloo processes shard the sample list by range, each fills its
+"""N > 1 path on CPU: world_size-2 gloo processes shard the sample list by range (cloud replicated,
+or cut into spatial tiles as bench.py does), each fills its
 fixed-slot candidate table, one all-gather exchanges them, and the merged result must equal the
 single-process result record for record -- whatever the number of ranks.  The per-rank compute is
 done by the oracle here (no GPU in this container); the sharding, slot addressing, global-slot RNG
@@ -21,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, tiles=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -36,10 +37,22 @@ def _worker(rank, world, port, q):
     idx = scene.draw_samples(3, xyz.shape[0], 61)   # odd count: uneven shards
     R = 8
     o = api.Oracle(**scene_params(ws, num_threads=2))
-    o.set_cloud(xyz)
-    o.compute_normals()
     b, e = sharding.shard_range(len(idx), rank, world)
-    recs = o.generate_hypotheses(sample_idx=idx[b:e], slot_base=b, seed=11)
+    if tiles:
+        # spatial tiles (what bench.py does for N > 1): the rank holds only its x-interval + halo
+        ordered = sharding.order_samples_by_x(xyz, idx)
+        q_ = o.params
+        halo = sharding.tile_halo(q_.nn_radius_hands, q_.nn_radius_taubin, q_.normals_radius)
+        keep, local, base = sharding.tile_points(xyz, ordered, rank, world, halo)
+        assert base == b and len(local) == e - b and len(keep) <= xyz.shape[0]
+        o.set_grid_origin(sharding.cloud_origin(xyz))
+        o.set_cloud(xyz[keep])
+        o.compute_normals()
+        recs = o.generate_hypotheses(sample_idx=local, slot_base=b, seed=11)
+    else:
+        o.set_cloud(xyz)
+        o.compute_normals()
+        recs = o.generate_hypotheses(sample_idx=idx[b:e], slot_base=b, seed=11)
     pad = sharding.max_shard(len(idx), world)
     tab = sharding.table_from_records(recs, b, e - b, R, pad)
     local = torch.from_numpy(tab.view(np.uint8).copy())
@@ -51,17 +64,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_all_gather_equals_single_process(world):
+@pytest.mark.parametrize("world,tiles", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_all_gather_equals_single_process(world, tiles):
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
-    from agile_grasp2_amd import scene
+    from agile_grasp2_amd import scene, sharding
     from conftest import scene_params
     from oracle import api
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, tiles)) for r in range(world)]
     for p in procs:
         p.start()
     blob = q.get(timeout=240)
@@ -74,6 +87,8 @@ def test_sharded_all_gather_equals_single_process(world):
     o = api.Oracle(**scene_params(ws, num_threads=2))
     o.set_cloud(xyz)
     o.compute_normals()
+    if tiles:  # the tiled job works through the samples in x order
+        idx = sharding.order_samples_by_x(xyz, idx)
     want = o.generate_hypotheses(sample_idx=idx, slot_base=0, seed=11)
     assert len(want) > 10
     assert merged.tobytes() == want.tobytes()

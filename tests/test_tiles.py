@@ -16,10 +16,13 @@ from agile_grasp2_amd import scene, sharding  # noqa: E402
 from conftest import scene_params  # noqa: E402
 
 
+AXIS = 0  # tiling axis of the case being run
+
+
 def _case(seed, n_target, n_samples):
     xyz, ws = scene.make_scene(seed=seed, n_target=n_target)
     idx = scene.draw_samples(seed, xyz.shape[0], n_samples)
-    return xyz, ws, sharding.order_samples_by_x(xyz, idx)
+    return xyz, ws, sharding.order_samples_by_x(xyz, idx, AXIS)
 
 
 def _halo(det):
@@ -32,7 +35,7 @@ def _run_tiled(make, xyz, ordered, world, R, seed, halo):
     pad = sharding.max_shard(len(ordered), world)
     tabs, keeps, fractions = [], [], []
     for rank in range(world):
-        keep, local, base = sharding.tile_points(xyz, ordered, rank, world, halo)
+        keep, local, base = sharding.tile_points(xyz, ordered, rank, world, halo, AXIS)
         det = make()
         if len(local) == 0:
             recs = np.zeros(0, dtype=HYP)
@@ -70,12 +73,16 @@ def _check(make, world, seed=5, n_target=9000, n_samples=53, R=8):
     return fr
 
 
-@pytest.mark.parametrize("world", [2, 3, 5])
-def test_oracle_tiles_equal_unsplit(world):
-    global HYP
+@pytest.mark.parametrize("world,axis", [(2, 0), (3, 0), (5, 0), (3, 1)])
+def test_oracle_tiles_equal_unsplit(world, axis):
+    global HYP, AXIS
     from oracle import api
     HYP = api.HYP_DTYPE
-    fr = _check(lambda p: api.Oracle(**p), world)
+    AXIS = axis
+    try:
+        fr = _check(lambda p: api.Oracle(**p), world)
+    finally:
+        AXIS = 0
     assert min(fr) < 1.0          # at least one tile really dropped points
 
 
@@ -97,6 +104,7 @@ def test_tile_helpers():
         x = xyz[keep, 0]
         assert x.min() >= xyz[keep[local], 0].min() - 0.1 - 1e-6
     assert seen == list(ordered)
+    assert sharding.longest_axis(xyz * np.float32([1, 3, 2])) == 1
     # more ranks than samples: empty tiles
     keep, local, base = sharding.tile_points(xyz, ordered[:2], 3, 4, 0.1)
     assert len(keep) == 0 and len(local) == 0
@@ -114,12 +122,16 @@ def test_origin_above_a_point_is_an_error():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_gpu_tiles_equal_unsplit(world):
-    global HYP
+@pytest.mark.parametrize("world,axis", [(2, 0), (4, 0), (4, 1)])
+def test_gpu_tiles_equal_unsplit(world, axis):
+    global HYP, AXIS
     from agile_grasp2_amd import capi
     HYP = capi.HYP_DTYPE
-    fr = _check(lambda p: capi.Detector(**p), world, seed=9, n_target=60000, n_samples=301)
+    AXIS = axis
+    try:
+        fr = _check(lambda p: capi.Detector(**p), world, seed=9, n_target=60000, n_samples=301)
+    finally:
+        AXIS = 0
     assert min(fr) < 1.0
 
 
