@@ -220,7 +220,7 @@ void ag2_destroy(ag2_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->d_xyz_in, &c->d_key, &c->d_cell, &c->d_fill, &c->d_perm, &c->d_sorted,
+  DevBuf* bufs[] = {&c->d_xyz_in, &c->d_key, &c->d_bounds, &c->d_cell, &c->d_perm, &c->d_sorted,
                     &c->d_nrm, &c->d_scan, &c->d_stats, &c->d_hc, &c->d_sample_q, &c->d_frames,
                     &c->d_frame_ok, &c->d_table, &c->d_tab_off, &c->d_tab_keep, &c->d_arena,
                     &c->d_overflow, &c->d_gscratch, &c->d_list, &c->d_list2, &c->d_images,
@@ -308,7 +308,7 @@ int ag2_set_cloud_device(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_
   c->has_cloud = c->has_normals = false;
   c->bounds_known = false;
   AG2_HIP(c, c->d_xyz_in.reserve(std::max<size_t>(n, 1) * 16));
-  const int rc = pack_device_xyz(c, d_xyz, n, stride_bytes, c->d_xyz_in.as<float4>());
+  const int rc = pack_device_xyz(c, d_xyz, n, stride_bytes, c->d_xyz_in.as<float4>(), /*with_bounds=*/true);
   if (rc) return rc;
   return after_cloud(c);
 }

@@ -99,13 +99,14 @@ struct ag2_ctx {
   bool grid_pending = false;     // grid kernels launched, duration not collected yet
   float min_z = 0.f;
   ag2::DevBuf d_xyz_in;    // packed float4 (x,y,z, cam mask bits) in ORIGINAL order
-  ag2::DevBuf d_key;       // int32 cell key per original point (-1 invalid)
+  ag2::DevBuf d_key;       // int2 per original point: cell key (-1 invalid), arrival rank in the cell
+  ag2::DevBuf d_bounds;    // per-workgroup extent partials of k_bounds (8 ints each)
+  int bounds_blocks = 0;   // > 0: the fused pack left that many partials for build_grid
   ag2::DevBuf d_cell;      // uint32 cell_start[ncells+1]
-  ag2::DevBuf d_fill;      // uint32 per-cell cursor / scan scratch
   ag2::DevBuf d_perm;      // int32 sorted position -> original index
   ag2::DevBuf d_sorted;    // float4 (x,y,z, cam mask bits) in sorted order
   ag2::DevBuf d_nrm;       // float4 (nx,ny,nz,0) in sorted order
-  ag2::DevBuf d_scan;      // block sums for the scan
+  ag2::DevBuf d_scan;      // control words of the chained scan
   ag2::DevBuf d_stats;     // DevStats
   ag2::DevBuf d_hc;        // HandConst
   ag2::HandConst hc{};
@@ -189,8 +190,10 @@ inline char* pin_bulk(ag2_ctx* c) { return (char*)c->h_pin + kPinSmall; }
 // k_grid.hip
 int build_grid(ag2_ctx* c);
 int gather_normals(ag2_ctx* c);  // d_tmp (float4, original order) -> d_nrm (sorted order)
-int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, float4* dst);
-int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n);
+int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, float4* dst,
+                    bool with_bounds = false);
+size_t scan_ctl_words(int n);
+int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n, unsigned* zeroed_ctl = nullptr);
 // k_normals.hip
 int launch_normals(ag2_ctx* c);
 // k_sweep.hip

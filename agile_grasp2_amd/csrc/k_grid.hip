@@ -26,12 +26,29 @@ __global__ void k_pack_xyz(const char* __restrict__ src, size_t stride, int n,
   dst[i] = make_float4(p[0], p[1], p[2], __int_as_float(1));
 }
 
-__global__ void __launch_bounds__(256) k_bounds(const float4* __restrict__ xyz, int n, DevStats* st) {
+// Extent of the cloud (finite points only), optionally fused with the pack above: every workgroup
+// writes ONE partial record (min xyz, max xyz as order-preserving ints, count) that the host reduces
+// after the read-back it needs anyway -- no atomics, nothing to initialise.  Block 0 also clears the
+// device statistics of the previous cloud.
+constexpr int kBoundsBlocks = 128;  // 128 records x 32 B = the small page-locked read-back area
+static_assert(kBoundsBlocks * 32 <= (int)kPinSmall, "extent partials must fit the small read-back area");
+template <bool PACK>
+__global__ void __launch_bounds__(256) k_bounds(const char* __restrict__ src, size_t stride,
+                                                float4* __restrict__ xyz, int n, int* __restrict__ part,
+                                                DevStats* st) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *st = DevStats{};
   int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
   int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   int cnt = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float4 p = xyz[i];
+    float4 p;
+    if (PACK) {
+      const float* q = (const float*)(src + (size_t)i * stride);
+      p = make_float4(q[0], q[1], q[2], __int_as_float(1));
+      xyz[i] = p;
+    } else {
+      p = xyz[i];
+    }
     if (finite3(p.x, p.y, p.z)) {
       cnt++;
       const int a[3] = {f2ord(p.x), f2ord(p.y), f2ord(p.z)};
@@ -51,50 +68,61 @@ __global__ void __launch_bounds__(256) k_bounds(const float4* __restrict__ xyz, 
     }
   }
   cnt = wave_sum_i(cnt);
-  // one set of atomics per workgroup (7 contended addresses chip-wide)
-  __shared__ int part[4][7];
+  __shared__ int wpart[4][7];
   if (lane_id() == 0) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      part[wave_id()][k] = mn[k];
-      part[wave_id()][3 + k] = mx[k];
+      wpart[wave_id()][k] = mn[k];
+      wpart[wave_id()][3 + k] = mx[k];
     }
-    part[wave_id()][6] = cnt;
+    wpart[wave_id()][6] = cnt;
   }
   __syncthreads();
   if (threadIdx.x < 7) {
     const int k = threadIdx.x;
-    int v = part[0][k];
+    int v = wpart[0][k];
     for (int w = 1; w < 4; w++) {
-      const int o = part[w][k];
+      const int o = wpart[w][k];
       v = (k < 3) ? min(v, o) : (k < 6 ? max(v, o) : v + o);
     }
-    if (k < 3) atomicMin((int*)&st->bounds[k], v);
-    else if (k < 6) atomicMax((int*)&st->bounds[k], v);
-    else atomicAdd(&st->bounds[6], (unsigned)v);
+    part[blockIdx.x * 8 + k] = v;
   }
 }
 
+// key[i] = (cell key or -1, arrival rank inside the cell): the rank the counting atomic hands out
+// places the point in the scatter below without a second round of atomics.
 __global__ void k_cell_count(const float4* __restrict__ xyz, int n, GridDesc g,
-                             int* __restrict__ key, unsigned* __restrict__ cell) {
+                             int2* __restrict__ key, unsigned* __restrict__ cell) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 p = xyz[i];
-  int k = -1;
+  int k = -1, r = 0;
   if (finite3(p.x, p.y, p.z)) {
     const int cx = cell_of(p.x, g.o[0], g.inv), cy = cell_of(p.y, g.o[1], g.inv),
               cz = cell_of(p.z, g.o[2], g.inv);
     k = (cz * g.dims[1] + cy) * g.dims[0] + cx;
-    atomicAdd(&cell[k], 1u);
+    r = (int)atomicAdd(&cell[k], 1u);
   }
-  key[i] = k;
+  key[i] = make_int2(k, r);
 }
 
-// ---- exclusive scan of uint32 (2048 elements per block) ---------------------------------------
-__global__ void __launch_bounds__(256) k_scan_block(unsigned* __restrict__ data, int n,
-                                                    unsigned* __restrict__ sums) {
+// ---- exclusive scan of uint32, one pass (2048 elements per tile) ---------------------------------
+// Chained scan with look-back: a workgroup draws its tile from a ticket counter (so every
+// predecessor it waits for is already running, whatever the dispatch order), scans the tile,
+// publishes the tile total, and wave 0 looks back over the predecessors' records -- 64 at a time --
+// until it meets one that already holds an inclusive prefix.  A record is one 64-bit word
+// (state << 32 | value; state 1 = tile total, 2 = inclusive prefix), read and written with relaxed
+// device-scope atomics: state and value travel together, so no ordering against other memory is
+// needed.  ctl[0] = ticket, ctl[2 + 2 * t ...] = record of tile t; all zero before the launch.
+__global__ void __launch_bounds__(256) k_scan_chained(unsigned* __restrict__ data, int n,
+                                                      unsigned* __restrict__ ctl) {
   __shared__ unsigned wsum[4];
-  const int base = blockIdx.x * 2048 + threadIdx.x * 8;
+  __shared__ unsigned s_tile, s_prefix;
+  unsigned long long* rec = reinterpret_cast<unsigned long long*>(ctl + 2);
+  if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[0], 1u);
+  __syncthreads();
+  const int tile = (int)s_tile;
+  const int base = tile * 2048 + threadIdx.x * 8;
   unsigned v[8];
   unsigned tot = 0;
 #pragma unroll
@@ -102,7 +130,6 @@ __global__ void __launch_bounds__(256) k_scan_block(unsigned* __restrict__ data,
     v[k] = (base + k < n) ? data[base + k] : 0u;
     tot += v[k];
   }
-  // inclusive wave scan of tot
   unsigned inc = tot;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -113,53 +140,75 @@ __global__ void __launch_bounds__(256) k_scan_block(unsigned* __restrict__ data,
   __syncthreads();
   unsigned woff = 0;
   for (int w = 0; w < wave_id(); w++) woff += wsum[w];
-  unsigned run = woff + inc - tot;
+  if (wave_id() == 0) {
+    const unsigned total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (lane_id() == 0)
+      __hip_atomic_store(&rec[tile], ((unsigned long long)(tile == 0 ? 2u : 1u) << 32) | total,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned prefix = 0;
+    int jb = tile - 1;
+    while (jb >= 0) {
+      const int j = jb - lane_id();
+      // tiles before the first count as an inclusive prefix of zero
+      const unsigned long long r = (j >= 0) ? __hip_atomic_load(&rec[j], __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT)
+                                            : (2ull << 32);
+      const unsigned state = (unsigned)(r >> 32);
+      const unsigned long long m2 = __ballot(state == 2u), m0 = __ballot(state == 0u);
+      const int first2 = m2 ? (__ffsll((long long)m2) - 1) : 64;
+      const unsigned long long need = (first2 >= 63) ? ~0ull : ((2ull << first2) - 1ull);
+      if (m0 & need) {  // a predecessor in the window has not published yet: poll again
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      unsigned val = (lane_id() <= first2) ? (unsigned)r : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) val += (unsigned)__shfl_xor((int)val, o, 64);
+      prefix += val;
+      if (first2 < 64) break;
+      jb -= 64;
+    }
+    if (lane_id() == 0) {
+      if (tile > 0)
+        __hip_atomic_store(&rec[tile], (2ull << 32) | (unsigned long long)(prefix + total),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_prefix = prefix;
+    }
+  }
+  __syncthreads();
+  unsigned run = s_prefix + woff + inc - tot;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     if (base + k < n) data[base + k] = run;
     run += v[k];
   }
-  if (sums && threadIdx.x == 255) sums[blockIdx.x] = woff + inc;
 }
 
-__global__ void k_scan_add(unsigned* __restrict__ data, int n, const unsigned* __restrict__ sums) {
-  const int i = blockIdx.x * 2048 + threadIdx.x;
-  const unsigned off = sums[blockIdx.x];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int j = i + k * 256;
-    if (j < n) data[j] += off;
-  }
-}
+size_t scan_ctl_words(int n) { return 2 + 2 * ((size_t)n / 2048 + 1) + 2; }
 
-static int scan_exclusive(ag2_ctx* c, unsigned* d, int n, unsigned* scratch, size_t scratch_elems) {
+// zeroed_ctl: scan_ctl_words(n) zeroed words the caller cleared together with its own buffers
+// (saves the fill); nullptr = the scan clears its own.
+int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n, unsigned* zeroed_ctl) {
+  if (n <= 0) return 0;
   const int nb = (n + 2047) / 2048;
-  if (nb <= 1) {
-    hipLaunchKernelGGL(k_scan_block, dim3(1), dim3(256), 0, c->stream, d, n, (unsigned*)nullptr);
-    return 0;
+  if (!zeroed_ctl) {
+    const size_t words = scan_ctl_words(n);
+    AG2_HIP(c, c->d_scan.reserve(words * sizeof(unsigned)));
+    AG2_HIP(c, hipMemsetAsync(c->d_scan.p, 0, words * sizeof(unsigned), c->stream));
+    zeroed_ctl = c->d_scan.as<unsigned>();
   }
-  if ((size_t)nb > scratch_elems) return set_err(c, AG2_ERR_CAPACITY, "scan scratch too small");
-  hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, c->stream, d, n, scratch);
-  const int rc = scan_exclusive(c, scratch, nb, scratch + nb, scratch_elems - nb);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, c->stream, d, n, scratch);
+  hipLaunchKernelGGL(k_scan_chained, dim3(nb), dim3(256), 0, c->stream, d, n, zeroed_ctl);
+  AG2_HIP(c, hipGetLastError());
   return 0;
 }
 
-int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n) {
-  const size_t need = ((size_t)n / 2048 + 8) * 2;
-  AG2_HIP(c, c->d_scan.reserve(need * sizeof(unsigned)));
-  return scan_exclusive(c, d, n, c->d_scan.as<unsigned>(), need);
-}
-
-__global__ void k_scatter(const int* __restrict__ key, int n, const unsigned* __restrict__ cell,
-                          unsigned* __restrict__ fill, int* __restrict__ perm) {
+__global__ void k_scatter(const int2* __restrict__ key, int n, const unsigned* __restrict__ cell,
+                          int* __restrict__ perm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int k = key[i];
-  if (k < 0) return;
-  const unsigned pos = cell[k] + atomicAdd(&fill[k], 1u);
-  perm[pos] = i;
+  const int2 k = key[i];
+  if (k.x < 0) return;
+  perm[cell[k.x] + (unsigned)k.y] = i;
 }
 
 // Within a cell the scatter order is whatever the atomics produced; restore ascending original
@@ -168,8 +217,12 @@ __global__ void k_scatter(const int* __restrict__ key, int n, const unsigned* __
 // The 256 cells of a workgroup own one contiguous span of perm: it is staged in LDS (coalesced load
 // and store), so the dependent compares and moves of the insertion sorts never touch global memory.
 constexpr int kSortStage = 6144;
+// The sorted float4 cloud is written from here as well (sorted[pos] = xyz[perm[pos]]): the final
+// position of every element is known at this point, so no separate gather pass re-reads perm.
 __global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ cell, int ncells,
-                                                   int* __restrict__ perm) {
+                                                   int* __restrict__ perm,
+                                                   const float4* __restrict__ xyz,
+                                                   float4* __restrict__ sorted) {
   __shared__ int stage[kSortStage];
   const int c0 = blockIdx.x * 256, c = c0 + threadIdx.x;
   const int lo = (int)cell[c0], hi = (int)cell[min(c0 + 256, ncells)];
@@ -190,6 +243,7 @@ __global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ 
       int rank = 0;
       for (int k = 0; k < cl; k++) rank += (stage[cb + k] < v) ? 1 : 0;
       perm[lo + cb + rank] = v;  // indices within a cell are distinct: ranks are a permutation
+      sorted[lo + cb + rank] = xyz[v];
     }
   } else if ((hi - lo) <= kSortStage) {  // staged insertion sort
     for (int i = lo + threadIdx.x; i < hi; i += 256) stage[i - lo] = perm[i];
@@ -207,7 +261,11 @@ __global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ 
       stage[j + 1] = v;
     }
     __syncthreads();
-    for (int i = lo + threadIdx.x; i < hi; i += 256) perm[i] = stage[i - lo];
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      const int v = stage[i - lo];
+      perm[i] = v;
+      sorted[i] = xyz[v];
+    }
   } else {  // dense cells: in place in global memory
     for (int i = b + 1; i < e; i++) {
       const int v = perm[i];
@@ -220,6 +278,7 @@ __global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ 
       }
       perm[j + 1] = v;
     }
+    for (int i = b; i < e; i++) sorted[i] = xyz[perm[i]];
   }
 }
 
@@ -237,10 +296,22 @@ int gather_normals(ag2_ctx* c) {
   return 0;
 }
 
-int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, float4* dst) {
+// with_bounds: the pack also produces the extent partials build_grid needs (c->bounds_blocks > 0
+// tells build_grid they are there), one pass over the source instead of two.
+int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, float4* dst,
+                    bool with_bounds) {
+  c->bounds_blocks = 0;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_pack_xyz, dim3(((int)n + 255) / 256), dim3(256), 0, c->stream,
-                     (const char*)d_xyz, stride_bytes, (int)n, dst);
+  if (with_bounds) {
+    const int nb = std::min(((int)n + 255) / 256, kBoundsBlocks);
+    AG2_HIP(c, c->d_bounds.reserve((size_t)kBoundsBlocks * 8 * 4));
+    hipLaunchKernelGGL(k_bounds<true>, dim3(nb), dim3(256), 0, c->stream, (const char*)d_xyz,
+                       stride_bytes, dst, (int)n, c->d_bounds.as<int>(), c->d_stats.as<DevStats>());
+    c->bounds_blocks = nb;
+  } else {
+    hipLaunchKernelGGL(k_pack_xyz, dim3(((int)n + 255) / 256), dim3(256), 0, c->stream,
+                       (const char*)d_xyz, stride_bytes, (int)n, dst);
+  }
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
@@ -248,15 +319,20 @@ int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes
 int build_grid(ag2_ctx* c) {
   const int n = (int)c->n;
   DevStats* st = c->d_stats.as<DevStats>();
-  hipLaunchKernelGGL(k_init_stats, dim3(1), dim3(64), 0, c->stream, st);
   c->n_valid = 0;
   c->grid = GridDesc{};
-  if (n == 0) return 0;
+  const int packed_blocks = c->bounds_blocks;
+  c->bounds_blocks = 0;
+  if (n == 0) {
+    hipLaunchKernelGGL(k_init_stats, dim3(1), dim3(64), 0, c->stream, st);
+    return 0;
+  }
   const float4* xyz = c->d_xyz_in.as<float4>();
   float bmin[3], bmax[3];
   if (c->bounds_known) {
     // the front end already knows the extent of what it produced (all points finite): no bounds
     // pass, no host round trip
+    hipLaunchKernelGGL(k_init_stats, dim3(1), dim3(64), 0, c->stream, st);
     c->bounds_known = false;
     for (int a = 0; a < 3; a++) {
       bmin[a] = c->known_min[a];
@@ -264,16 +340,31 @@ int build_grid(ag2_ctx* c) {
     }
     c->n_valid = (size_t)n;
   } else {
-    const int nb = std::min((n + 255) / 256, 128);  // 7 contended atomics per workgroup: keep them few
-    hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, c->stream, xyz, n, st);
-    DevStats hs;
-    AG2_HIP(c, hipMemcpyAsync(pin_small(c), st, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+    int nb = packed_blocks;
+    if (nb == 0) {  // the cloud did not come through the fused pack: extent pass on its own
+      nb = std::min((n + 255) / 256, kBoundsBlocks);
+      AG2_HIP(c, c->d_bounds.reserve((size_t)kBoundsBlocks * 8 * 4));
+      hipLaunchKernelGGL(k_bounds<false>, dim3(nb), dim3(256), 0, c->stream, (const char*)nullptr,
+                         (size_t)0, c->d_xyz_in.as<float4>(), n, c->d_bounds.as<int>(), st);
+    }
+    AG2_HIP(c, hipMemcpyAsync(pin_small(c), c->d_bounds.p, (size_t)nb * 32, hipMemcpyDeviceToHost,
+                              c->stream));
     AG2_HIP(c, hipStreamSynchronize(c->stream));
-    __builtin_memcpy(&hs, pin_small(c), sizeof(hs));
-    c->n_valid = hs.bounds[6];
+    const int* part = (const int*)pin_small(c);
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+    int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    long long cnt = 0;
+    for (int b = 0; b < nb; b++) {
+      for (int a = 0; a < 3; a++) {
+        mn[a] = std::min(mn[a], part[b * 8 + a]);
+        mx[a] = std::max(mx[a], part[b * 8 + 3 + a]);
+      }
+      cnt += part[b * 8 + 6];
+    }
+    c->n_valid = (size_t)cnt;
     for (int a = 0; a < 3; a++) {
-      bmin[a] = ord2f((int)hs.bounds[a]);
-      bmax[a] = ord2f((int)hs.bounds[3 + a]);
+      bmin[a] = ord2f(mn[a]);
+      bmax[a] = ord2f(mx[a]);
     }
   }
   if (c->n_valid == 0) return 0;
@@ -295,28 +386,26 @@ int build_grid(ag2_ctx* c) {
   g.ncells = (int)ncells;
   g.n_valid = (int)c->n_valid;
   c->grid = g;
-  AG2_HIP(c, c->d_key.reserve((size_t)n * 4));
-  // cell_start and the per-cell cursors share one buffer so that ONE fill (a multiple of 16 bytes:
-  // no tail kernel) clears both
+  AG2_HIP(c, c->d_key.reserve((size_t)n * 8));
+  // the cell counters and the scan's control words share one buffer so that ONE fill (a multiple of
+  // 16 bytes: no tail kernel) clears both
   const size_t cell_words = (((size_t)ncells + 1) + 3) & ~size_t(3);
-  AG2_HIP(c, c->d_cell.reserve(2 * cell_words * 4));
+  const size_t ctl_words = (scan_ctl_words((int)ncells + 1) + 3) & ~size_t(3);
+  AG2_HIP(c, c->d_cell.reserve((cell_words + ctl_words) * 4));
   AG2_HIP(c, c->d_perm.reserve((size_t)n * 4));
   AG2_HIP(c, c->d_sorted.reserve((size_t)n * 16));
   AG2_HIP(c, c->d_nrm.reserve((size_t)n * 16));
   unsigned* cell = c->d_cell.as<unsigned>();
-  unsigned* fill = cell + cell_words;
-  AG2_HIP(c, hipMemsetAsync(cell, 0, 2 * cell_words * 4, c->stream));
+  AG2_HIP(c, hipMemsetAsync(cell, 0, (cell_words + ctl_words) * 4, c->stream));
   const int g256 = (n + 255) / 256;
   hipLaunchKernelGGL(k_cell_count, dim3(g256), dim3(256), 0, c->stream, xyz, n, g,
-                     c->d_key.as<int>(), cell);
-  const int rc = scan_exclusive_u32(c, cell, (int)ncells + 1);
+                     c->d_key.as<int2>(), cell);
+  const int rc = scan_exclusive_u32(c, cell, (int)ncells + 1, cell + cell_words);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, c->stream, c->d_key.as<int>(), n, cell,
-                     fill, c->d_perm.as<int>());
+  hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, c->stream, c->d_key.as<int2>(), n, cell,
+                     c->d_perm.as<int>());
   hipLaunchKernelGGL(k_cell_sort, dim3(((int)ncells + 255) / 256), dim3(256), 0, c->stream, cell,
-                     (int)ncells, c->d_perm.as<int>());
-  hipLaunchKernelGGL(k_gather4, dim3(((int)c->n_valid + 255) / 256), dim3(256), 0, c->stream, xyz,
-                     c->d_perm.as<int>(), (int)c->n_valid, c->d_sorted.as<float4>());
+                     (int)ncells, c->d_perm.as<int>(), xyz, c->d_sorted.as<float4>());
   AG2_HIP(c, hipGetLastError());
   return 0;
 }

@@ -242,14 +242,24 @@ k_lenet_fc_finish(const float* __restrict__ part, int n_img, int n_pad, int kspl
   const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (img >= n_img) return;
   float s0 = 0.f, s1 = 0.f;
+  // the eight outputs of a lane are summed side by side: eight independent loads per split in
+  // flight instead of one chain of 8 * ksplit dependent ones (each sum still runs in split order)
+  float h[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* pr = part + (size_t)img * kFcN + lane;
+  for (int ks = 0; ks < ksplit; ks++) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = pr[j * 64];
+#pragma unroll
+    for (int j = 0; j < 8; j++) h[j] += v[j];
+    pr += (size_t)n_pad * kFcN;
+  }
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const int n = j * 64 + lane;
-    float h = 0.f;
-    for (int ks = 0; ks < ksplit; ks++) h += part[((size_t)ks * n_pad + img) * kFcN + n];
-    h = fmaxf(h + b3[n], 0.f);
-    s0 = __builtin_fmaf(h, w4[n], s0);
-    s1 = __builtin_fmaf(h, w4[kFcN + n], s1);
+    const float r = fmaxf(h[j] + b3[n], 0.f);
+    s0 = __builtin_fmaf(r, w4[n], s0);
+    s1 = __builtin_fmaf(r, w4[kFcN + n], s1);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
