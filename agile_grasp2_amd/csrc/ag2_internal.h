@@ -44,6 +44,7 @@ struct DevStats {
   unsigned int n_sel;                // scored hypotheses with score >= min_score_diff
   unsigned int n_clu;                // selected hypotheses that survive the clustering
   unsigned int n_overflow2;          // samples whose cropped list exceeds the 160-KiB LDS stage too
+  unsigned int max_p;                // largest in-box list of the run (picks the image renderers)
   unsigned int work_next[3];         // k_sweep work queues, one per stage (items beyond the first grid)
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
@@ -162,6 +163,7 @@ struct ag2_ctx {
   std::vector<int64_t> h_offsets;       // their arena offsets
   std::vector<uint8_t> h_keep;          // their prune flags
   size_t n_img = 0;
+  int max_p = 0;           // largest in-box point list of the last hypothesis run
 
   ag2::LeNetDev net;
   ag2_counters cnt{};
@@ -218,7 +220,7 @@ int cluster_async(ag2_ctx* c, const ag2_hypothesis* d_in, size_t n_max, const un
 int launch_scatter_scores(ag2_ctx* c, const int* d_list, size_t n_img);
 // k_image.hip
 int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, const int* d_cnt,
-                  size_t n_img, uint8_t* d_out);
+                  size_t n_img, uint8_t* d_out, int max_p);
 // k_lenet.hip
 int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const float* c2w,
                        const float* c2b, const float* f1w, const float* f1b, const float* f2w,

@@ -81,6 +81,7 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     c->cnt.sum_p = (int64_t)hs.sum_p;
     c->cnt.n_overflow_samples = hs.n_overflow;
     if (compact_mode >= 0) c->n_img = hs.n_list;
+    c->max_p = (int)hs.max_p;
     (void)hipEventElapsedTime(&c->times.frames_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->times.sweep_ms, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&c->times.sweep_overflow_ms, c->ev[2], c->ev[11]);
@@ -187,7 +188,7 @@ int ag2_render_images(ag2_ctx* c, size_t first, size_t count, uint8_t* out) {
   AG2_HIP(c, c->d_images.reserve(count * 10800));
   rc = launch_render(c, c->d_arena.as<double>(), c->d_desc.as<long long>(),
                      (const int*)(c->d_desc.as<long long>() + count), count,
-                     c->d_images.as<uint8_t>());
+                     c->d_images.as<uint8_t>(), c->max_p);
   if (rc) return rc;
   AG2_HIP(c, hipEventRecord(c->ev[4], c->stream));
   AG2_HIP(c, hipMemcpyAsync(out, c->d_images.p, count * 10800, hipMemcpyDeviceToHost, c->stream));
@@ -222,7 +223,9 @@ int ag2_render_images_from_points(ag2_ctx* c, size_t n, const int64_t* offsets, 
   AG2_HIP(c, hipMemcpyAsync(c->d_tmp.p, inter.data(), inter.size() * 8, hipMemcpyHostToDevice, c->stream));
   AG2_HIP(c, hipMemcpyAsync(d_off, off.data(), n * 8, hipMemcpyHostToDevice, c->stream));
   AG2_HIP(c, hipMemcpyAsync(d_cnt, cnt.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-  const int rc = launch_render(c, c->d_tmp.as<double>(), d_off, d_cnt, n, c->d_images.as<uint8_t>());
+  int max_p = 0;
+  for (size_t i = 0; i < n; i++) max_p = std::max(max_p, cnt[i]);
+  const int rc = launch_render(c, c->d_tmp.as<double>(), d_off, d_cnt, n, c->d_images.as<uint8_t>(), max_p);
   if (rc) return rc;
   AG2_HIP(c, hipMemcpyAsync(out, c->d_images.p, n * 10800, hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
@@ -285,7 +288,7 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   AG2_HIP(c, hipEventRecord(c->ev[3], c->stream));
   rc = launch_render(c, c->d_arena.as<double>(), c->d_desc.as<long long>(),
                      (const int*)(c->d_desc.as<long long>() + n_img), n_img,
-                     c->d_images.as<uint8_t>());
+                     c->d_images.as<uint8_t>(), c->max_p);
   if (rc) return rc;
   AG2_HIP(c, hipEventRecord(c->ev[4], c->stream));
   rc = launch_lenet(c, c->d_images.as<uint8_t>(), n_img, c->d_logits.as<float>(), c->ev[5]);  // 3b.

@@ -211,74 +211,76 @@ __global__ void k_scatter(const int2* __restrict__ key, int n, const unsigned* _
   perm[cell[k.x] + (unsigned)k.y] = i;
 }
 
-// Within a cell the scatter order is whatever the atomics produced; restore ascending original
-// index so the layout is deterministic ((key, index) order).  Cells hold ~10-30 points on a 3 mm
-// voxel cloud: one thread per cell, insertion sort.
-// The 256 cells of a workgroup own one contiguous span of perm: it is staged in LDS (coalesced load
-// and store), so the dependent compares and moves of the insertion sorts never touch global memory.
-constexpr int kSortStage = 6144;
+// Within a cell the arrival order is whatever the atomics produced; restore ascending original
+// index so the layout is deterministic ((key, index) order).
+// A workgroup owns 256 consecutive cells = one contiguous span of perm.  The span is worked through
+// in batches of whole cells that fit the LDS stage (usually one batch: cells of a 3 mm voxel cloud
+// hold ~10-30 points; un-voxelised clouds with hundreds of points per cell take several), each batch
+// rank-sorted with one thread per ELEMENT: every element counts the smaller indices in its own cell
+// (independent compares, no dependent insertion chains) and is written to (cell start + rank).
+// Only a single cell larger than the stage is sorted in place in global memory by one thread.
 // The sorted float4 cloud is written from here as well (sorted[pos] = xyz[perm[pos]]): the final
 // position of every element is known at this point, so no separate gather pass re-reads perm.
+constexpr int kSortStage = 6144;     // ints of LDS: values [0, n) + packed cell (start | length << 16) [n, 2n)
+constexpr int kSortBatch = kSortStage / 2;
+static_assert(kSortBatch <= 65535, "cell start and length are packed into 16 bits each");
 __global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ cell, int ncells,
                                                    int* __restrict__ perm,
                                                    const float4* __restrict__ xyz,
                                                    float4* __restrict__ sorted) {
   __shared__ int stage[kSortStage];
-  const int c0 = blockIdx.x * 256, c = c0 + threadIdx.x;
-  const int lo = (int)cell[c0], hi = (int)cell[min(c0 + 256, ncells)];
-  const int b = (c < ncells) ? (int)cell[c] : 0, e = (c < ncells) ? (int)cell[c + 1] : 0;
-  if ((hi - lo) <= kSortStage / 2) {  // uniform: LDS path (ds_ instructions, no generic pointers)
-    // Rank sort, one thread per ELEMENT: every element counts the smaller indices in its own cell
-    // (independent compares, no dependent insertion chains) and is written to (cell start + rank).
-    // stage[0, n) = values; stage[n, 2n) = packed (cell start - lo) | (cell length << 16).
-    const int n = hi - lo;
-    for (int i = lo + threadIdx.x; i < hi; i += 256) stage[i - lo] = perm[i];
-    for (int i = b; i < e; i++)  // lengths fit 16 bits: n <= kSortStage / 2
-      stage[n + (i - lo)] = (b - lo) | ((e - b) << 16);
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) {
-      const int v = stage[i];
-      const int be = stage[n + i];
-      const int cb = be & 0xFFFF, cl = be >> 16;
-      int rank = 0;
-      for (int k = 0; k < cl; k++) rank += (stage[cb + k] < v) ? 1 : 0;
-      perm[lo + cb + rank] = v;  // indices within a cell are distinct: ranks are a permutation
-      sorted[lo + cb + rank] = xyz[v];
+  __shared__ int cs[257];  // sorted position at which each of the workgroup's cells starts
+  const int c0 = blockIdx.x * 256, tid = threadIdx.x;
+  for (int t = tid; t <= 256; t += 256) cs[t] = (int)cell[min(c0 + t, ncells)];
+  __syncthreads();
+  int cb = 0;  // first cell of the batch (everything below is uniform across the workgroup)
+  while (cb < 256 && cs[256] > cs[cb]) {
+    const int lo = cs[cb];
+    // largest ce in [cb, 256] with cs[ce] - lo <= kSortBatch (cs is non-decreasing)
+    int a = cb, b = 256;
+    while (a < b) {
+      const int m = (a + b + 1) >> 1;
+      if (cs[m] - lo <= kSortBatch) a = m; else b = m - 1;
     }
-  } else if ((hi - lo) <= kSortStage) {  // staged insertion sort
-    for (int i = lo + threadIdx.x; i < hi; i += 256) stage[i - lo] = perm[i];
-    __syncthreads();
-    const int sb = b - lo, se = e - lo;
-    for (int i = sb + 1; i < se; i++) {
-      const int v = stage[i];
-      int j = i - 1;
-      while (j >= sb) {
-        const int u = stage[j];
-        if (!(u > v)) break;
-        stage[j + 1] = u;
-        j--;
+    int ce = a;
+    if (ce == cb) {  // a single cell larger than the stage: in place, one thread
+      ce = cb + 1;
+      const int e = cs[ce];
+      if (tid == 0) {
+        for (int i = lo + 1; i < e; i++) {
+          const int v = perm[i];
+          int j = i - 1;
+          while (j >= lo) {
+            const int u = perm[j];
+            if (!(u > v)) break;
+            perm[j + 1] = u;
+            j--;
+          }
+          perm[j + 1] = v;
+        }
       }
-      stage[j + 1] = v;
-    }
-    __syncthreads();
-    for (int i = lo + threadIdx.x; i < hi; i += 256) {
-      const int v = stage[i - lo];
-      perm[i] = v;
-      sorted[i] = xyz[v];
-    }
-  } else {  // dense cells: in place in global memory
-    for (int i = b + 1; i < e; i++) {
-      const int v = perm[i];
-      int j = i - 1;
-      while (j >= b) {
-        const int u = perm[j];
-        if (!(u > v)) break;
-        perm[j + 1] = u;
-        j--;
+      __syncthreads();
+      for (int i = lo + tid; i < e; i += 256) sorted[i] = xyz[perm[i]];
+    } else {
+      const int n = cs[ce] - lo;
+      for (int i = tid; i < n; i += 256) stage[i] = perm[lo + i];
+      if (tid >= cb && tid < ce) {  // the owner of a cell labels its elements
+        const int st = cs[tid] - lo, len = cs[tid + 1] - cs[tid];
+        for (int k = 0; k < len; k++) stage[n + st + k] = st | (len << 16);
       }
-      perm[j + 1] = v;
+      __syncthreads();
+      for (int i = tid; i < n; i += 256) {
+        const int v = stage[i];
+        const int be = stage[n + i];
+        const int st = be & 0xFFFF, len = (int)((unsigned)be >> 16);
+        int rank = 0;
+        for (int k = 0; k < len; k++) rank += (stage[st + k] < v) ? 1 : 0;
+        perm[lo + st + rank] = v;  // indices within a cell are distinct: ranks are a permutation
+        sorted[lo + st + rank] = xyz[v];
+      }
+      __syncthreads();  // the stage is reused by the next batch
     }
-    for (int i = b; i < e; i++) sorted[i] = xyz[perm[i]];
+    cb = ce;
   }
 }
 

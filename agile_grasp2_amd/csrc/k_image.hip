@@ -10,6 +10,7 @@
 // Round r then adds the normals of all rank-r points to their leader's accumulator -- distinct
 // cells within a round, list order across rounds -- and only the leaders quantise a pixel.  43 KB of
 // LDS: three workgroups per CU.
+// k_render_sorted (1024 < P <= 4096): cell-major sort of the points in LDS, then one run per cell.
 // k_render (any P): every cell is owned by one thread (cell % 256) which adds the normals of its
 // points in list order; two passes of 30 image rows, 76 KB of LDS.
 // Quantisation to u8 happens BEFORE the 3x3 dilate: v -> sat(rint(255 v)) is monotone, so
@@ -290,8 +291,90 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
   }
 }
 
+// k_render_sorted (kSparseMax < P <= kSortedMax, dense clouds): the points' (cell, list position)
+// keys are sorted in LDS (bitonic, the position in the low bits keeps list order inside a cell), so
+// every cell's points sit together; the thread that finds the head of a run adds the run's normals
+// in list order -- the same f64 sums as the reference's scan over all points for each cell, at
+// O(P log^2 P) instead of O(3600 P).
+constexpr int kSortedMax = 4096;
+struct SortedShared {
+  unsigned key[kSortedMax];        // cell << 12 | position; 0xFFFFFFFF = dropped point / padding
+  unsigned pix[kCells];
+  unsigned char obuf[kCells * 3];
+  double red[kImgThreads / kWave];
+};
+static_assert(kCells <= 4096 && kSortedMax <= 4096, "12 bits each for cell and position");
+static_assert(sizeof(SortedShared) * 3 <= 160 * 1024, "k_render_sorted: three workgroups per CU");
+
+__global__ void __launch_bounds__(kImgThreads) k_render_sorted(const double* __restrict__ arena,
+                                                               const long long* __restrict__ desc_off,
+                                                               const int* __restrict__ desc_cnt,
+                                                               int n_img, int p_min,
+                                                               unsigned char* __restrict__ out) {
+  __shared__ SortedShared S;
+  const int tid = threadIdx.x;
+  for (int im = blockIdx.x; im < n_img; im += gridDim.x) {
+    const long long off = desc_off[im];
+    const int P = (off >= 0) ? desc_cnt[im] : 0;
+    if (P < p_min || P > kSortedMax) continue;  // the other renderers' images (uniform)
+    const double* pts = arena + (size_t)off * 6;
+    __syncthreads();  // previous image's readers of S are done
+    const double miny = block_min_y(pts, P, S.red, tid);
+    int N = 2048;
+    while (N < P) N <<= 1;
+    for (int b = tid; b < N; b += kImgThreads) {
+      unsigned k = 0xFFFFFFFFu;
+      if (b < P) {
+        const short c = cell_id(pts[(size_t)b * 6], pts[(size_t)b * 6 + 1], miny);
+        if (c >= 0) k = ((unsigned)c << 12) | (unsigned)b;
+      }
+      S.key[b] = k;
+    }
+    for (int i = tid; i < kCells; i += kImgThreads) S.pix[i] = 0u;  // image.setTo(0)
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < N / 2; t += kImgThreads) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int l = i | j;
+          const unsigned a = S.key[i], b = S.key[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            S.key[i] = b;
+            S.key[l] = a;
+          }
+        }
+        __syncthreads();
+      }
+    // heads of runs: sum the run in list order (:166-179), quantise, write at (59 - row, col)
+    for (int i = tid; i < P; i += kImgThreads) {
+      const unsigned k = S.key[i];
+      if (k == 0xFFFFFFFFu) continue;
+      const unsigned cell = k >> 12;
+      if (i > 0 && (S.key[i - 1] >> 12) == cell) continue;
+      double ax = 0.0, ay = 0.0, az = 0.0;
+      unsigned kk = k;
+      int j = i;
+      do {
+        const double* y = pts + (size_t)(kk & 4095u) * 6 + 3;
+        ax = ax + y[0];
+        ay = ay + y[1];
+        az = az + y[2];
+        j++;
+        kk = (j < P) ? S.key[j] : 0xFFFFFFFFu;
+      } while ((kk >> 12) == cell);
+      const int row = kImg - 1 - (int)cell / kImg, col = (int)cell % kImg;
+      S.pix[row * kImg + col] = quantise(ax, ay, az);
+    }
+    __syncthreads();
+    dilate_store(S.pix, S.obuf, out + (size_t)im * (kCells * 3), tid);
+  }
+}
+
+// max_p: an upper bound of the images' point counts (the sweep's statistics have it): renderers
+// none of whose images can occur are not launched.
 int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, const int* d_cnt,
-                  size_t n_img, uint8_t* d_out) {
+                  size_t n_img, uint8_t* d_out, int max_p) {
   if (n_img == 0) return 0;
   const size_t lds = sizeof(ImgShared);
   static bool attr_set = false;
@@ -303,9 +386,13 @@ int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, con
   // images with at most kSparseMax points (nearly all) ...
   hipLaunchKernelGGL(k_render_sparse, dim3((int)std::min<size_t>(n_img, 256 * 12)), dim3(kImgThreads), 0,
                      c->stream, d_arena, d_off, d_cnt, (int)n_img, d_out);
-  // ... the rest; each kernel skips the other's images by the point count alone
-  hipLaunchKernelGGL(k_render, dim3((int)std::min<size_t>(n_img, 256 * 2)), dim3(kImgThreads), lds, c->stream,
-                     d_arena, d_off, d_cnt, (int)n_img, kSparseMax + 1, d_out);
+  // ... the rest; each kernel skips the others' images by the point count alone
+  if (max_p > kSparseMax)
+    hipLaunchKernelGGL(k_render_sorted, dim3((int)std::min<size_t>(n_img, 256 * 3)), dim3(kImgThreads), 0,
+                     c->stream, d_arena, d_off, d_cnt, (int)n_img, kSparseMax + 1, d_out);
+  if (max_p > kSortedMax)
+    hipLaunchKernelGGL(k_render, dim3((int)std::min<size_t>(n_img, 256 * 2)), dim3(kImgThreads), lds, c->stream,
+                     d_arena, d_off, d_cnt, (int)n_img, kSortedMax + 1, d_out);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }

@@ -1205,6 +1205,7 @@ k_sweep(SweepArgs A) {
         A.tab_keep[slot] = keep ? 1 : 4;  // slot state: 0 empty, 1 survives the prune, 4 pruned away
         atomicAdd(&A.st->n_hyp, 1u);
         atomicAdd(&A.st->sum_p, (unsigned long long)P);
+        atomicMax(&A.st->max_p, (unsigned)P);
       }
       AG2_PROF(6);
     }

@@ -177,11 +177,16 @@ def test_images_from_points_edge_cases():
     lists.append((u2, rng.normal(size=(3, 300))))
     # the sparse renderer's limit (1024 points, many per cell: dozens of accumulation rounds; zero
     # normal sums) and the first size the dense renderer takes
-    for npts in (1024, 1025, 7, 64, 257):
+    # ... the sorted renderer's range (1025..4096: padded to 2048 / 4096 keys) and the first size
+    # beyond it
+    for npts in (1024, 1025, 7, 64, 257, 2047, 2048, 2049, 3000, 4096, 4097):
         u3 = rng.uniform(0.2, 0.8, size=(3, npts))
         u3[:2, : npts // 2] = np.round(u3[:2, : npts // 2] * 6) / 6.0
         n3 = rng.normal(size=(3, npts))
         n3[:, 1::7] = -n3[:, 0:-1:7][:, : n3[:, 1::7].shape[1]]   # pairs that cancel where they share a cell
+        if npts == 3000:  # dropped points (cells outside the image) and aliasing x-cells in between
+            u3[0, 5::11] = 1.3
+            u3[1, 3::13] = 2.5
         lists.append((u3, n3))
     got = d.render_images_from_points([a for a, _ in lists], [b for _, b in lists])
     for k, (a, b) in enumerate(lists):
