@@ -10,7 +10,7 @@
 // Round r then adds the normals of all rank-r points to their leader's accumulator -- distinct
 // cells within a round, list order across rounds -- and only the leaders quantise a pixel.  43 KB of
 // LDS: three workgroups per CU.
-// k_render_sorted (1024 < P <= 4096): cell-major sort of the points in LDS, then one run per cell.
+// k_render_sorted (1024 < P <= 16384): cell-major sort of the points in LDS, then one run per cell.
 // k_render (any P): every cell is owned by one thread (cell % 256) which adds the normals of its
 // points in list order; two passes of 30 image rows, 76 KB of LDS.
 // Quantisation to u8 happens BEFORE the 3x3 dilate: v -> sat(rint(255 v)) is monotone, so
@@ -71,10 +71,11 @@ __device__ __forceinline__ unsigned quantise(double ax, double ay, double az) {
 
 // :202-203 3x3 rect dilate (border taps ignored), :206 BGR2RGB swap; staged so that the global
 // store is coalesced dwords
+template <int NT = kImgThreads>
 __device__ __forceinline__ void dilate_store(const unsigned* __restrict__ pix,
                                              unsigned char* __restrict__ obuf,
                                              unsigned char* __restrict__ out_img, int tid) {
-  for (int p = tid; p < kCells; p += kImgThreads) {
+  for (int p = tid; p < kCells; p += NT) {
     const int r = p / kImg, cc = p % kImg;
     unsigned m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
@@ -96,12 +97,13 @@ __device__ __forceinline__ void dilate_store(const unsigned* __restrict__ pix,
   __syncthreads();
   unsigned* dst = reinterpret_cast<unsigned*>(out_img);
   const unsigned* src = reinterpret_cast<const unsigned*>(obuf);
-  for (int i = tid; i < kCells * 3 / 4; i += kImgThreads) dst[i] = src[i];
+  for (int i = tid; i < kCells * 3 / 4; i += NT) dst[i] = src[i];
 }
 
+template <int NT = kImgThreads>
 __device__ __forceinline__ double block_min_y(const double* __restrict__ pts, int P, double* red, int tid) {
   double miny = __builtin_inf();  // learning.cpp:148-149  y <- y - min y
-  for (int b = tid; b < P; b += kImgThreads) {
+  for (int b = tid; b < P; b += NT) {
     const double y = pts[(size_t)b * 6 + 1];
     miny = (y < miny) ? y : miny;
   }
@@ -110,7 +112,7 @@ __device__ __forceinline__ double block_min_y(const double* __restrict__ pts, in
   __syncthreads();
   miny = red[0];
 #pragma unroll
-  for (int k = 1; k < kImgThreads / kWave; k++) miny = (red[k] < miny) ? red[k] : miny;
+  for (int k = 1; k < NT / kWave; k++) miny = (red[k] < miny) ? red[k] : miny;
   return miny;
 }
 
@@ -296,78 +298,211 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
 // every cell's points sit together; the thread that finds the head of a run adds the run's normals
 // in list order -- the same f64 sums as the reference's scan over all points for each cell, at
 // O(P log^2 P) instead of O(3600 P).
-constexpr int kSortedMax = 4096;
+// Two instantiations: up to 4096 points (48 KB of LDS, three workgroups per CU) and up to 16384
+// (96 KB, one per CU); NBITS = bits of the list position inside a key.
+constexpr int kSortedMax = 4096, kSortedMaxBig = 16384;
+constexpr int kWalk = 768;         // sorted positions whose normals are staged in LDS at a time
+template <int NMAX, int NT>
 struct SortedShared {
-  unsigned key[kSortedMax];        // cell << 12 | position; 0xFFFFFFFF = dropped point / padding
+  unsigned key[NMAX];              // cell << NBITS | position; 0xFFFFFFFF = dropped point / padding
   unsigned pix[kCells];
-  unsigned char obuf[kCells * 3];
-  double red[kImgThreads / kWave];
+  double nbuf[kWalk * 3];          // normals in sorted order; the staged output image aliases it afterwards
+  double red[NT / kWave];
+  double carry[3];                 // sum of a run that continues into the next chunk
 };
-static_assert(kCells <= 4096 && kSortedMax <= 4096, "12 bits each for cell and position");
-static_assert(sizeof(SortedShared) * 3 <= 160 * 1024, "k_render_sorted: three workgroups per CU");
+static_assert(kWalk * 3 * 8 >= kCells * 3, "output staging must fit the normal stage");
+static_assert(kCells <= 4096, "12 bits for the cell");
+static_assert(sizeof(SortedShared<kSortedMax, kImgThreads>) * 3 <= 160 * 1024, "k_render_sorted: three workgroups per CU");
+static_assert(sizeof(SortedShared<kSortedMaxBig, 1024>) <= 160 * 1024, "k_render_sorted, big: one workgroup per CU");
 
-__global__ void __launch_bounds__(kImgThreads) k_render_sorted(const double* __restrict__ arena,
+// Bitonic sort (ascending) of PER * NT keys held PER per thread: element index = tid * PER + r.
+// Compare-exchanges between registers of one thread need no memory at all (v_min / v_max), those
+// between threads of a wave go through a lane shuffle, only partners in different waves exchange
+// through LDS.  A phase that runs descending for this thread sorts the complemented keys ascending
+// instead, so every compare-exchange is a plain (min, max).
+template <int PER, int NT>
+__device__ __forceinline__ void bitonic_sort_regs(unsigned (&x)[PER], unsigned* __restrict__ lds, int tid) {
+  constexpr int N = PER * NT;
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+    unsigned flip = 0u;
+    if (k >= PER) {
+      flip = (((unsigned)tid * PER) & (unsigned)k) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+      for (int r = 0; r < PER; r++) x[r] ^= flip;
+    }
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < PER) {
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+          if ((r & j) == 0) {
+            const unsigned a = x[r], b = x[r | j];
+            const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+            const bool up = (k >= PER) || ((r & k) == 0);  // known at compile time
+            x[r] = up ? lo : hi;
+            x[r | j] = up ? hi : lo;
+          }
+        }
+      } else {
+        const int m = j / PER;  // the partner thread holds the same r
+        const bool lower = (tid & m) == 0;
+        if (m < kWave) {
+#pragma unroll
+          for (int r = 0; r < PER; r++) {
+            const unsigned p = (unsigned)__shfl_xor((int)x[r], m, kWave);
+            const unsigned lo = x[r] < p ? x[r] : p, hi = x[r] < p ? p : x[r];
+            x[r] = lower ? lo : hi;
+          }
+        } else {
+          __syncthreads();  // earlier readers of the exchange area are done
+#pragma unroll
+          for (int r = 0; r < PER; r++) lds[r * NT + tid] = x[r];
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < PER; r++) {
+            const unsigned p = lds[r * NT + (tid ^ m)];
+            const unsigned lo = x[r] < p ? x[r] : p, hi = x[r] < p ? p : x[r];
+            x[r] = lower ? lo : hi;
+          }
+        }
+      }
+    }
+    if (k >= PER) {
+#pragma unroll
+      for (int r = 0; r < PER; r++) x[r] ^= flip;
+    }
+  }
+  __syncthreads();  // the exchange area is free again: the caller stores the result there
+#pragma unroll
+  for (int r = 0; r < PER; r++) lds[tid * PER + r] = x[r];
+}
+
+template <int NMAX, int NBITS, int NT>
+__global__ void __launch_bounds__(NT) k_render_sorted(const double* __restrict__ arena,
                                                                const long long* __restrict__ desc_off,
                                                                const int* __restrict__ desc_cnt,
                                                                int n_img, int p_min,
                                                                unsigned char* __restrict__ out) {
-  __shared__ SortedShared S;
+  static_assert((1 << NBITS) >= NMAX && NBITS + 12 < 32, "key layout");
+  constexpr unsigned kPosMask = (1u << NBITS) - 1u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_sorted[];
+  SortedShared<NMAX, NT>& S = *reinterpret_cast<SortedShared<NMAX, NT>*>(smem_sorted);
   const int tid = threadIdx.x;
   for (int im = blockIdx.x; im < n_img; im += gridDim.x) {
     const long long off = desc_off[im];
     const int P = (off >= 0) ? desc_cnt[im] : 0;
-    if (P < p_min || P > kSortedMax) continue;  // the other renderers' images (uniform)
+    if (P < p_min || P > NMAX) continue;  // the other renderers' images (uniform)
     const double* pts = arena + (size_t)off * 6;
     __syncthreads();  // previous image's readers of S are done
-    const double miny = block_min_y(pts, P, S.red, tid);
-    int N = 2048;
-    while (N < P) N <<= 1;
-    for (int b = tid; b < N; b += kImgThreads) {
-      unsigned k = 0xFFFFFFFFu;
+    // x and y of this thread's points are read ONCE, all loads in flight together (the kernel is
+    // bound by memory latency, not bandwidth), and kept in registers for the cell ids
+    constexpr int kPer = NMAX / NT;
+    double px[kPer], py[kPer];
+    double miny = __builtin_inf();  // learning.cpp:148-149  y <- y - min y
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int b = tid + k * NT;
+      px[k] = 0.0;
+      py[k] = __builtin_inf();
       if (b < P) {
-        const short c = cell_id(pts[(size_t)b * 6], pts[(size_t)b * 6 + 1], miny);
-        if (c >= 0) k = ((unsigned)c << 12) | (unsigned)b;
+        px[k] = pts[(size_t)b * 6];
+        py[k] = pts[(size_t)b * 6 + 1];
       }
-      S.key[b] = k;
     }
-    for (int i = tid; i < kCells; i += kImgThreads) S.pix[i] = 0u;  // image.setTo(0)
+#pragma unroll
+    for (int k = 0; k < kPer; k++) miny = (py[k] < miny) ? py[k] : miny;
+    miny = wave_min_d(miny);
+    if (lane_id() == 0) S.red[wave_id()] = miny;
     __syncthreads();
-    for (int k = 2; k <= N; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < N / 2; t += kImgThreads) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const int l = i | j;
-          const unsigned a = S.key[i], b = S.key[l];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            S.key[i] = b;
-            S.key[l] = a;
+    miny = S.red[0];
+#pragma unroll
+    for (int k = 1; k < NT / kWave; k++) miny = (S.red[k] < miny) ? S.red[k] : miny;
+    unsigned key[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int b = tid + k * NT;
+      key[k] = 0xFFFFFFFFu;
+      if (b < P) {
+        const short c = cell_id(px[k], py[k], miny);
+        if (c >= 0) key[k] = ((unsigned)c << NBITS) | (unsigned)b;
+      }
+    }
+    for (int i = tid; i < kCells; i += NT) S.pix[i] = 0u;  // image.setTo(0)
+    if (P <= NMAX / 2) {  // uniform: half the keys would be padding -- sort half as many
+      unsigned half[kPer / 2];
+#pragma unroll
+      for (int k = 0; k < kPer / 2; k++) half[k] = key[k];
+      bitonic_sort_regs<kPer / 2, NT>(half, S.key, tid);
+    } else {
+      bitonic_sort_regs<kPer, NT>(key, S.key, tid);
+    }
+    // Runs of equal cells, kWalk sorted positions at a time.  The normals of a chunk are gathered
+    // into LDS by all threads first (independent loads), so the thread that owns a run -- the one at
+    // its head -- adds them in list order (:166-179) without waiting for memory; a run that crosses
+    // the chunk boundary hands its partial sum on through S.carry.
+    for (int c0 = 0; c0 < P; c0 += kWalk) {
+      const int cn = min(kWalk, P - c0);
+      __syncthreads();  // previous chunk's readers of nbuf are done, its carry is written
+      {
+        constexpr int kG = (kWalk + NT - 1) / NT;  // gathers per thread: issued together, then stored
+        double g[kG][3];
+#pragma unroll
+        for (int u = 0; u < kG; u++) {
+          const int t = tid + u * NT;
+          const unsigned k = (t < cn) ? S.key[c0 + t] : 0xFFFFFFFFu;
+          g[u][0] = g[u][1] = g[u][2] = 0.0;
+          if (k != 0xFFFFFFFFu) {
+            const double* y = pts + (size_t)(k & kPosMask) * 6 + 3;
+            g[u][0] = y[0];
+            g[u][1] = y[1];
+            g[u][2] = y[2];
           }
         }
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kG; u++) {
+          const int t = tid + u * NT;
+          if (t < cn) {
+            S.nbuf[3 * t] = g[u][0];
+            S.nbuf[3 * t + 1] = g[u][1];
+            S.nbuf[3 * t + 2] = g[u][2];
+          }
+        }
       }
-    // heads of runs: sum the run in list order (:166-179), quantise, write at (59 - row, col)
-    for (int i = tid; i < P; i += kImgThreads) {
-      const unsigned k = S.key[i];
-      if (k == 0xFFFFFFFFu) continue;
-      const unsigned cell = k >> 12;
-      if (i > 0 && (S.key[i - 1] >> 12) == cell) continue;
-      double ax = 0.0, ay = 0.0, az = 0.0;
-      unsigned kk = k;
-      int j = i;
-      do {
-        const double* y = pts + (size_t)(kk & 4095u) * 6 + 3;
-        ax = ax + y[0];
-        ay = ay + y[1];
-        az = az + y[2];
-        j++;
-        kk = (j < P) ? S.key[j] : 0xFFFFFFFFu;
-      } while ((kk >> 12) == cell);
-      const int row = kImg - 1 - (int)cell / kImg, col = (int)cell % kImg;
-      S.pix[row * kImg + col] = quantise(ax, ay, az);
+      __syncthreads();
+      for (int t = tid; t < cn; t += NT) {
+        const unsigned k = S.key[c0 + t];
+        if (k == 0xFFFFFFFFu) continue;
+        const unsigned cell = k >> NBITS;
+        const bool cont = (c0 + t > 0) && (S.key[c0 + t - 1] >> NBITS) == cell;
+        if (cont && t != 0) continue;  // inside a run: its head does the work
+        double ax = 0.0, ay = 0.0, az = 0.0;
+        if (cont) {  // first position of the chunk, run started in the previous one
+          ax = S.carry[0];
+          ay = S.carry[1];
+          az = S.carry[2];
+        }
+        int j = t;
+        unsigned kk;
+        do {
+          ax = ax + S.nbuf[3 * j];
+          ay = ay + S.nbuf[3 * j + 1];
+          az = az + S.nbuf[3 * j + 2];
+          j++;
+          kk = (c0 + j < P) ? S.key[c0 + j] : 0xFFFFFFFFu;
+        } while (j < cn && (kk >> NBITS) == cell);
+        if (j == cn && (kk >> NBITS) == cell) {  // continues in the next chunk (at most one such run)
+          S.carry[0] = ax;
+          S.carry[1] = ay;
+          S.carry[2] = az;
+        } else {  // quantise, write at (59 - row, col)
+          const int row = kImg - 1 - (int)cell / kImg, col = (int)cell % kImg;
+          S.pix[row * kImg + col] = quantise(ax, ay, az);
+        }
+      }
     }
     __syncthreads();
-    dilate_store(S.pix, S.obuf, out + (size_t)im * (kCells * 3), tid);
+    dilate_store<NT>(S.pix, reinterpret_cast<unsigned char*>(S.nbuf), out + (size_t)im * (kCells * 3), tid);
   }
 }
 
@@ -381,6 +516,9 @@ int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, con
   if (!attr_set) {
     AG2_HIP(c, hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
+    AG2_HIP(c, hipFuncSetAttribute((const void*)k_render_sorted<kSortedMaxBig, 14, 1024>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(SortedShared<kSortedMaxBig, 1024>)));
     attr_set = true;
   }
   // images with at most kSparseMax points (nearly all) ...
@@ -388,11 +526,16 @@ int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, con
                      c->stream, d_arena, d_off, d_cnt, (int)n_img, d_out);
   // ... the rest; each kernel skips the others' images by the point count alone
   if (max_p > kSparseMax)
-    hipLaunchKernelGGL(k_render_sorted, dim3((int)std::min<size_t>(n_img, 256 * 3)), dim3(kImgThreads), 0,
-                     c->stream, d_arena, d_off, d_cnt, (int)n_img, kSparseMax + 1, d_out);
+    hipLaunchKernelGGL((k_render_sorted<kSortedMax, 12, kImgThreads>), dim3((int)std::min<size_t>(n_img, 256 * 3)),
+                       dim3(kImgThreads), sizeof(SortedShared<kSortedMax, kImgThreads>), c->stream, d_arena, d_off, d_cnt,
+                       (int)n_img, kSparseMax + 1, d_out);
   if (max_p > kSortedMax)
+    hipLaunchKernelGGL((k_render_sorted<kSortedMaxBig, 14, 1024>), dim3((int)std::min<size_t>(n_img, 256)),
+                       dim3(1024), sizeof(SortedShared<kSortedMaxBig, 1024>), c->stream, d_arena, d_off,
+                       d_cnt, (int)n_img, kSortedMax + 1, d_out);
+  if (max_p > kSortedMaxBig)
     hipLaunchKernelGGL(k_render, dim3((int)std::min<size_t>(n_img, 256 * 2)), dim3(kImgThreads), lds, c->stream,
-                     d_arena, d_off, d_cnt, (int)n_img, kSortedMax + 1, d_out);
+                       d_arena, d_off, d_cnt, (int)n_img, kSortedMaxBig + 1, d_out);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }

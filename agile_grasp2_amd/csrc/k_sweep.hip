@@ -708,10 +708,10 @@ k_sweep(SweepArgs A) {
     const bool too_big = K > CAP;
     if (too_big) {  // uniform
       if (tid == 0) {
-        if (STAGE == 0) {
+        if (STAGE == 0 && K <= kLdsCapBig) {
           const unsigned at = atomicAdd(&A.st->n_overflow, 1u);
           A.overflow[at] = t;
-        } else if (STAGE == 1) {
+        } else if (STAGE <= 1) {  // (stage 0 knows the list length: straight to the stage that holds it)
           const unsigned at = atomicAdd(&A.st->n_overflow2, 1u);
           A.overflow2[at] = t;
         } else {
