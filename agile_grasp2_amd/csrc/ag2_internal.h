@@ -45,6 +45,7 @@ struct DevStats {
   unsigned int n_clu;                // selected hypotheses that survive the clustering
   unsigned int n_overflow2;          // samples whose cropped list exceeds the 160-KiB LDS stage too
   unsigned int max_p;                // largest in-box list of the run (picks the image renderers)
+  unsigned int n_handed_on;          // samples stage 0 of the sweep passed to a later stage
   unsigned int work_next[3];         // k_sweep work queues, one per stage (items beyond the first grid)
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid

@@ -413,7 +413,7 @@ static_assert(kLdsCapBig > kLdsCap && kLdsCapBig <= 65536, "unexpected LDS stage
 //   STAGE 2: queue of stage 1; cropped list in a per-workgroup global scratch
 // RMAX: compile-time bound on num_orientations (8, 16 or 32) for the per-orientation registers
 template <int STAGE, int RMAX>
-__global__ void __launch_bounds__(kSweepThreads, STAGE == 0 ? 2 * kSweepThreads / 256 : kSweepThreads / 256)
+__global__ void __launch_bounds__(kSweepThreads, STAGE != 1 ? 2 * kSweepThreads / 256 : kSweepThreads / 256)
 k_sweep(SweepArgs A) {
   constexpr bool LDS_STORE = STAGE < 2;
   constexpr int kCapL = (STAGE == 0) ? kLdsCap : kLdsCapBig;
@@ -581,6 +581,17 @@ k_sweep(SweepArgs A) {
         kcand += S.red.i[0][k][0];
       }
     }
+    if (STAGE == 0 && kcand > 3 * kLdsCapBig) {
+      // Very dense neighbourhood: the cropped list is about 0.6 of the candidates, so it will not
+      // fit either LDS stage -- hand the sample to the global-scratch stage before the crop pass
+      // instead of after it.  Only a routing decision: every stage computes the same result.
+      if (tid == 0) {
+        const unsigned at = atomicAdd(&A.st->n_overflow2, 1u);
+        A.overflow2[at] = t;
+        atomicAdd(&A.st->n_handed_on, 1u);
+      }
+      continue;
+    }
     int PL = kGrp;  // piece length; grows only if the table would overflow (dense clouds)
     while (kcand / PL + nrows_c > kMaxPieces) PL <<= 1;
     int n_pieces = 0;
@@ -708,6 +719,7 @@ k_sweep(SweepArgs A) {
     const bool too_big = K > CAP;
     if (too_big) {  // uniform
       if (tid == 0) {
+        if (STAGE == 0) atomicAdd(&A.st->n_handed_on, 1u);
         if (STAGE == 0 && K <= kLdsCapBig) {
           const unsigned at = atomicAdd(&A.st->n_overflow, 1u);
           A.overflow[at] = t;
@@ -1341,7 +1353,7 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
   // st->n_overflow2), so no host round trip sits between the launches.
   hipLaunchKernelGGL(fn_big, dim3(256), dim3(kSweepThreads), lds_big, c->stream, A);
   AG2_HIP(c, hipGetLastError());
-  const int gcap = 1 << 16, g2 = 256;  // 256 workgroups x 5 x 64 Ki words = 336 MB of scratch
+  const int gcap = 1 << 16, g2 = 512;  // two workgroups per CU x 5 x 64 Ki words = 671 MB of scratch
   AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 5 * gcap * 4));
   A.n_overflow = -1;  // read from st->n_overflow on the device
   A.gscratch = c->d_gscratch.as<float>();
