@@ -90,3 +90,36 @@ def test_larger_cloud_bit_exact():
     g, w = d.get_normals().astype(np.float32), o.get_normals().astype(np.float32)
     assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
     d.close()
+
+
+def test_cells_of_every_density():
+    """Cell sort paths: many cells per LDS batch, several batches per workgroup (hundreds of points
+    per cell), and one cell larger than the whole LDS stage (> 3072 points: sorted in place); device
+    clouds (fused pack + extent pass) give the same grid as uploaded ones."""
+    import ctypes as C
+    from agile_grasp2_amd import capi
+    from oracle import api
+    rng = np.random.default_rng(17)
+    base, ws = scene.make_scene(seed=2, n_target=4000)
+    lo = base.min(axis=0)
+    clump = (lo + np.float32(0.203) + rng.uniform(0, 0.004, size=(3500, 3))).astype(np.float32)   # one cell
+    dense = (lo + np.float32(0.05) + rng.uniform(0, 0.06, size=(60000, 3))).astype(np.float32)     # ~280 per cell
+    xyz = np.concatenate([base, clump, dense]).astype(np.float32)
+    xyz = xyz[rng.permutation(xyz.shape[0])]
+    o = api.Oracle(**scene_params(ws, num_threads=8))
+    o.set_cloud(xyz)
+    want = o.get_grid_perm()
+    d = capi.Detector(**scene_params(ws))
+    d.set_cloud(xyz)
+    assert np.array_equal(d.get_grid_perm(), want)
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), xyz.nbytes) == 0
+    assert hip.hipMemcpy(dptr, xyz.ctypes.data_as(C.c_void_p), xyz.nbytes, 1) == 0
+    d.set_cloud_device(dptr.value, xyz.shape[0], 12)
+    assert np.array_equal(d.get_grid_perm(), want)
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipFree(dptr)
+    d.close()
