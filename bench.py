@@ -276,7 +276,14 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
-            per_kernel = json.load(open(pmc_path)).get(args.config, {})
+            pmc = json.load(open(pmc_path))
+            # MFMA-busy fraction of the matrix-core kernels (SQ_VALU_MFMA_BUSY_CYCLES over the busy
+            # CUs' SIMD cycles) from the committed counter pass of the same command
+            if args.config == "cfg2" and not os.environ.get("AG2_LENET_F32"):
+                for name, frac in pmc.get("mfma_busy", {}).items():
+                    if name in kernels:
+                        kernels[name]["mfma_busy"] = frac
+            per_kernel = pmc.get(args.config, {})
             traffic = per_kernel.get(dom)
             if dom == "k_sweep" and traffic is not None:  # both instantiations, like the duration
                 traffic += per_kernel.get("k_sweep_overflow", 0)
@@ -289,7 +296,8 @@ def main():
                 "all_kernels": {n: dict({"ms": round(k["ms"], 4), "achieved": round(k["achieved"], 3),
                                          "unit": k["unit"], "peak": k["peak"], "frac": round(k["frac"], 4)},
                                         **({"fp32_equivalent_tflops": round(k["fp32_equivalent_tflops"], 2)}
-                                           if "fp32_equivalent_tflops" in k else {}))
+                                           if "fp32_equivalent_tflops" in k else {}),
+                                        **({"mfma_busy": k["mfma_busy"]} if "mfma_busy" in k else {}))
                                 for n, k in kernels.items()}}
     out = {
         "metric": "grasp hypotheses scored/sec on 300k-pt cloud; end-to-end detect latency",

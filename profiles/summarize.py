@@ -3,6 +3,7 @@
 
   python profiles/summarize.py stats  <dir>                              profiles/rNN_x_kernel_stats.csv
   python profiles/summarize.py pmc    <fetch-dir> <write-dir> <config>   profiles/rNN_x_pmc_summary.csv
+  python profiles/summarize.py sq     <dir>                              profiles/rNN_x_sq_summary.csv
 
 <dir> holds either rocprofv3's CSV output (--output-format csv) or its default rocpd SQLite
 database (*_results.db); both are read without the GPU.
@@ -117,6 +118,41 @@ def main():
                               "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch")
         json.dump(traffic, open(tpath, "w"), indent=1)
         print("wrote", dst, "and", tpath)
+        return
+    if mode == "sq":
+        # per-kernel means of the SQ counters of one --pmc pass; MFMA-busy fraction as the guide
+        # defines the units: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs of the busy
+        # CUs, SQ_BUSY_CU_CYCLES counts cycles summed over busy CUs (4 SIMDs each)
+        src, dst = sys.argv[2], sys.argv[3]
+        names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU",
+                 "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"]
+        cols = {n: counter_means(src, n) for n in names}
+        kernels = sorted(k for k in cols["SQ_BUSY_CU_CYCLES"] if k.startswith(("ag2::", "void ag2::")))
+        with open(dst, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls"] + [n + "_mean" for n in names] +
+                       ["mfma_busy_frac=MFMA_BUSY/(4*BUSY_CU)", "wave_wait_frac=WAIT_INST_ANY/WAVE_CYCLES",
+                        "wave_valu_frac=ACTIVE_INST_VALU/WAVE_CYCLES"])
+            for k in kernels:
+                v = {n: cols[n].get(k, (0, 0.0))[1] for n in names}
+                busy = v["SQ_BUSY_CU_CYCLES"] or 1.0
+                wc = v["SQ_WAVE_CYCLES"] or 1.0
+                w.writerow([k, cols["SQ_BUSY_CU_CYCLES"][k][0]] + [round(v[n], 1) for n in names] +
+                           [round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * busy), 4),
+                            round(v["SQ_WAIT_INST_ANY"] / wc, 4), round(v["SQ_ACTIVE_INST_VALU"] / wc, 4)])
+        # MFMA-busy fractions of the matrix-core kernels, read by bench.py next to the traffic
+        mpath = os.path.join(ROOT, "pmc_traffic.json")
+        tr = json.load(open(mpath)) if os.path.exists(mpath) else {}
+        busy = {}
+        for short in ("k_lenet_conv", "k_lenet_fc"):
+            for k in kernels:
+                if SHORT[short].search(k):
+                    b = cols["SQ_BUSY_CU_CYCLES"][k][1] or 1.0
+                    busy[short] = round(cols["SQ_VALU_MFMA_BUSY_CYCLES"].get(k, (0, 0.0))[1] / (4.0 * b), 4)
+        tr["mfma_busy"] = busy
+        tr["_mfma_source"] = f"profiles/{os.path.basename(dst)}: SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)"
+        json.dump(tr, open(mpath, "w"), indent=1)
+        print("wrote", dst, "and", mpath)
         return
     sys.exit(__doc__)
 
