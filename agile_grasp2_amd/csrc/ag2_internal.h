@@ -43,9 +43,7 @@ struct DevStats {
   unsigned int n_list;               // hypotheses that go on to be scored (after the prune)
   unsigned int n_sel;                // scored hypotheses with score >= min_score_diff
   unsigned int n_clu;                // selected hypotheses that survive the clustering
-  unsigned int n_overflow2;          // samples whose cropped list exceeds the 160-KiB LDS stage too
   unsigned int max_p;                // largest in-box list of the run (picks the image renderers)
-  unsigned int n_handed_on;          // samples stage 0 of the sweep passed to a later stage
   unsigned int work_next[3];         // k_sweep work queues, one per stage (items beyond the first grid)
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
@@ -103,6 +101,7 @@ struct ag2_ctx {
   ag2::DevBuf d_xyz_in;    // packed float4 (x,y,z, cam mask bits) in ORIGINAL order
   ag2::DevBuf d_key;       // int2 per original point: cell key (-1 invalid), arrival rank in the cell
   ag2::DevBuf d_bounds;    // per-workgroup extent partials of k_bounds (8 ints each)
+  ag2::DevBuf d_gpos;      // sweep stage 0: per-workgroup position lists that exceed its LDS
   int bounds_blocks = 0;   // > 0: the fused pack left that many partials for build_grid
   ag2::DevBuf d_cell;      // uint32 cell_start[ncells+1]
   ag2::DevBuf d_perm;      // int32 sorted position -> original index

@@ -79,7 +79,7 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     c->cnt.sum_k2 = (int64_t)hs.sum_k2;
     c->cnt.sum_kcrop = (int64_t)hs.sum_kcrop;
     c->cnt.sum_p = (int64_t)hs.sum_p;
-    c->cnt.n_overflow_samples = hs.n_handed_on;  // not finished by the sweep's first stage
+    c->cnt.n_overflow_samples = hs.n_overflow;  // handed to the sweep's global-scratch stage
     if (compact_mode >= 0) c->n_img = hs.n_list;
     c->max_p = (int)hs.max_p;
     (void)hipEventElapsedTime(&c->times.frames_ms, c->ev[0], c->ev[1]);

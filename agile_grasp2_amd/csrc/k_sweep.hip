@@ -17,14 +17,13 @@
 
 namespace ag2 {
 
-// 512 threads per workgroup (8 waves, two workgroups per CU => 4 waves per SIMD) measured 3-4 %
-// faster than 256 on cfg2 despite ~75 spilled VGPRs at the 128-register cap: the sweep is
-// latency-bound (SQ_WAIT_ANY ~ 52 % of wave cycles), so the extra waves pay.
-#ifndef AG2_SWEEP_THREADS
-#define AG2_SWEEP_THREADS 512
-#endif
-constexpr int kSweepThreads = AG2_SWEEP_THREADS;  // 256 or 512 (tuning knob)
-constexpr int kSweepWaves = kSweepThreads / kWave;
+// Threads per workgroup of the sweep's stages.  The sweep is bound by the latencies of its ~40
+// dependent phases per sample (SQ: waves wait > 50 % of their cycles), not by issue: halving the
+// threads of a workgroup costs 3-4 %, doubling the samples in flight per CU gains 12 %.  Stage 0
+// therefore runs FOUR 256-thread workgroups per CU; the stages for long lists keep 512 threads.
+constexpr int kSweepThreads0 = 256;   // stage 0
+constexpr int kSweepThreads1 = 512;   // stage 1 (long lists, global scratch)
+constexpr int sweep_threads(int stage) { return stage == 0 ? kSweepThreads0 : kSweepThreads1; }
 
 // ---------------------------------------------------------------------------------------------
 // sample queries: (x, y, z, valid) per sample
@@ -344,10 +343,10 @@ struct SweepArgs {
   int emit_lists;
   DevStats* st;
   int* overflow;             // stage 0 appends, stage 1 works through it (length: st->n_overflow)
-  int* overflow2;            // stage 1 appends, stage 2 works through it (length: st->n_overflow2)
-  int n_overflow;            // unused (lengths are read on the device)
   float* gscratch;           // global variant: 6 * gcap floats per block
   int gcap;
+  int* gpos;                 // stage 0: kGposCap positions per workgroup, then kGposCap u16 in-box
+                             // indices per workgroup (lists a little longer than the LDS stage)
   float min_z;
   int flags;                 // bit0: no row tightening (exact K2 accounting, diagnostic)
   unsigned long long* prof;  // optional per-phase cycle sums (AG2_SWEEP_PROF=1), else nullptr
@@ -363,10 +362,11 @@ struct SweepArgs {
     }                                                                  \
   } while (0)
 
+template <int NW>
 struct Red {
-  double d[2][kSweepWaves][12];
-  unsigned u[2][kSweepWaves][4];
-  int i[2][kSweepWaves][2];
+  double d[2][NW][12];
+  unsigned u[2][NW][4];
+  int i[2][NW][2];
 };
 
 constexpr int kMaxPieces = 1024;
@@ -376,10 +376,10 @@ constexpr int kMaxPieces = 1024;
 constexpr int kGrp = AG2_SWEEP_GROUP;  // lanes that share one piece in the crop passes (tuning knob)
 constexpr int kGpw = kWave / kGrp;     // pieces per wave-wide load
 static_assert(kGrp >= 4 && kGrp <= 64 && (kGrp & (kGrp - 1)) == 0, "lane group must be a power of two");
-constexpr int kRowsPerThread = (kMaxRows + kSweepThreads - 1) / kSweepThreads;
-constexpr int kPiecesPerThread = (kMaxPieces + kSweepThreads - 1) / kSweepThreads;
 
+template <int NT>
 struct SweepShared {
+  static constexpr int NW = NT / kWave;
   int row_start[kMaxRows];       // per stencil row (cy, cz): first sorted position, length
   int row_len[kMaxRows];
   int piece_start[kMaxPieces];   // rows cut into pieces of <= PL points
@@ -388,46 +388,62 @@ struct SweepShared {
   double depths[kMaxDepths];
   double cosd[kMaxOrient], sind[kMaxOrient];    // hand angles, f64 (exact path)
   float cosf_t[kMaxOrient], sinf_t[kMaxOrient]; // and rounded to f32 (classification)
-  unsigned res_a[kSweepWaves][kMaxOrient][2];   // pass A per wave: slot mask, flags
-  Red red;
-  int wave_cnt[kSweepWaves + 1];
+  unsigned res_a[NW][kMaxOrient][2];            // pass A per wave: slot mask, flags
+  Red<NW> red;
+  int wave_cnt[NW + 1];
   long long arena_off;
   int flag;
   unsigned dead;                 // pass A: orientations known to have a point behind the hand
   int next_w[2];                 // work item of the next loop iteration (double-buffered)
 };
 
-// Cropped points resident in LDS (16 B + a 2-B in-box index each): whatever two workgroups per CU
-// leave after the control block (2 x 80 KiB = 160 KiB).  Larger samples take the global-scratch
-// instantiation of the same kernel.
-constexpr int kLdsCap = (int)(((81920 - ((sizeof(SweepShared) + 15) & ~size_t(15))) / 18) & ~size_t(31));
-static_assert(kLdsCap >= 2048 && kLdsCap <= 65536, "unexpected LDS stage size");
-// second stage: one workgroup per CU with the whole 160 KiB (dense clouds)
-constexpr int kLdsCapBig = (int)(((163840 - ((sizeof(SweepShared) + 15) & ~size_t(15))) / 18) & ~size_t(31));
-static_assert(kLdsCapBig > kLdsCap && kLdsCapBig <= 65536, "unexpected LDS stage size");
+// Stage 0 keeps only the sorted POSITION of every cropped point in LDS (4 B + the 2-B in-box index)
+// and re-reads the point from the sorted cloud in L2 where a pass needs it (p - q in float: the very
+// value the crop computed).  The list costs a third of what staged coordinates would, so four
+// workgroups fit a CU with room for ~4 000 points each.
+constexpr int kStage0WgPerCu = 4;
+constexpr int kStage0PointBytes = 6;
+constexpr size_t sweep_ctl_bytes(int stage) {
+  return stage == 0 ? ((sizeof(SweepShared<kSweepThreads0>) + 15) & ~size_t(15))
+                    : ((sizeof(SweepShared<kSweepThreads1>) + 15) & ~size_t(15));
+}
+constexpr int kLdsCapRaw = (int)(((163840 / kStage0WgPerCu - sweep_ctl_bytes(0)) / kStage0PointBytes) & ~size_t(31));
+constexpr int kLdsCap = kLdsCapRaw > 32752 ? 32752 : kLdsCapRaw;
+static_assert(kLdsCap >= 2048, "unexpected LDS stage size");
+// A list that is longer than stage 0's LDS but not by much keeps its positions in a per-workgroup
+// global slice instead (L2-resident, same code): the few such samples of a tabletop cloud would
+// otherwise cost a whole extra launch whose duration is one sample's latency.
+constexpr int kGposCap = 2 * kLdsCap;
+static_assert(kGposCap <= 65536, "in-box indices are 16 bits");
 
-// Three instantiations run back to back, each taking what the previous one could not hold and
-// reading its queue length on the device (no host round trip):
-//   STAGE 0: every sample; cropped list in 80 KiB of LDS (two workgroups per CU)
-//   STAGE 1: queue of stage 0; 160 KiB of LDS (one workgroup per CU, no register spills)
-//   STAGE 2: queue of stage 1; cropped list in a per-workgroup global scratch
+// Two instantiations run back to back; the second reads its queue length on the device (no host
+// round trip):
+//   STAGE 0: every sample; positions of the cropped list in 40 KiB of LDS (four 256-thread
+//            workgroups per CU), or in the workgroup's global slice up to kGposCap points
+//   STAGE 1: the samples stage 0 handed on (dense clouds); centred coordinates + positions of the
+//            cropped list in a per-workgroup global scratch (two 512-thread workgroups per CU)
 // RMAX: compile-time bound on num_orientations (8, 16 or 32) for the per-orientation registers
 template <int STAGE, int RMAX>
-__global__ void __launch_bounds__(kSweepThreads, STAGE != 1 ? 2 * kSweepThreads / 256 : kSweepThreads / 256)
+__global__ void __launch_bounds__(sweep_threads(STAGE),
+                                  (STAGE == 0 ? kStage0WgPerCu : 2) * sweep_threads(STAGE) / 256)
 k_sweep(SweepArgs A) {
-  constexpr bool LDS_STORE = STAGE < 2;
-  constexpr int kCapL = (STAGE == 0) ? kLdsCap : kLdsCapBig;
+  constexpr int NT = sweep_threads(STAGE), NW = NT / kWave;
+  constexpr int kRowsPerThread = (kMaxRows + NT - 1) / NT;
+  constexpr int kPiecesPerThread = (kMaxPieces + NT - 1) / NT;
+  constexpr bool LDS_STORE = STAGE == 0;
+  constexpr bool LITE = STAGE == 0;  // positions only: points are re-read from the sorted cloud
+  constexpr int kCapL = kLdsCap;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  SweepShared& S = *reinterpret_cast<SweepShared*>(smem_raw);
-  const int CAP = LDS_STORE ? kCapL : A.gcap;
+  SweepShared<NT>& S = *reinterpret_cast<SweepShared<NT>*>(smem_raw);
+  const int CAP = LITE ? kGposCap : (LDS_STORE ? kCapL : A.gcap);
   float* pbase;
   unsigned short* box16 = nullptr;
   int* box32 = nullptr;
   // staged cropped list: centred xyz (float) + sorted position of the point (its normal is fetched
   // from L2 only for the few points that end up inside a closing region) = 16 B per point
   if (LDS_STORE) {
-    pbase = reinterpret_cast<float*>(smem_raw + ((sizeof(SweepShared) + 15) & ~size_t(15)));
-    box16 = reinterpret_cast<unsigned short*>(pbase + 4 * kCapL);
+    pbase = reinterpret_cast<float*>(smem_raw + sweep_ctl_bytes(STAGE));
+    box16 = reinterpret_cast<unsigned short*>(pbase + (LITE ? 1 : 4) * kCapL);
   } else {
     pbase = A.gscratch + (size_t)blockIdx.x * 5 * (size_t)A.gcap;
     box32 = reinterpret_cast<int*>(pbase + 4 * (size_t)A.gcap);
@@ -435,7 +451,13 @@ k_sweep(SweepArgs A) {
   float* PX = pbase;
   float* PY = pbase + CAP;
   float* PZ = pbase + 2 * (size_t)CAP;
-  int* POS = reinterpret_cast<int*>(pbase + 3 * (size_t)CAP);
+  int* POS = reinterpret_cast<int*>(pbase + (LITE ? 0 : 3) * (size_t)(LITE ? kCapL : CAP));
+  int* gpos = nullptr;
+  unsigned short* gbox = nullptr;
+  if (LITE) {
+    gpos = A.gpos + (size_t)blockIdx.x * kGposCap;
+    gbox = reinterpret_cast<unsigned short*>(A.gpos + (size_t)gridDim.x * kGposCap) + (size_t)blockIdx.x * kGposCap;
+  }
 
   const HandConst& hc = *A.hc;
   const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
@@ -443,8 +465,7 @@ k_sweep(SweepArgs A) {
   const int R = hc.R;
   const double hh = hc.hand_height;
   int red_sel = 0;
-  const int n_work = (STAGE == 0) ? A.n_samples
-                                  : (int)(STAGE == 1 ? A.st->n_overflow : A.st->n_overflow2);
+  const int n_work = (STAGE == 0) ? A.n_samples : (int)A.st->n_overflow;
   if (STAGE != 0 && n_work == 0) return;
   if (tid < 20) {
     S.fs[tid] = hc.fs[tid];
@@ -484,10 +505,24 @@ k_sweep(SweepArgs A) {
   };
   for (int w = blockIdx.x; w < n_work; w = next_work()) {
     if (tid == 0) nxt = gridDim.x + atomicAdd(&A.st->work_next[STAGE], 1u);
-    const int t = (STAGE == 0) ? w : (STAGE == 1 ? A.overflow[w] : A.overflow2[w]);
+    const int t = (STAGE == 0) ? w : A.overflow[w];
     long long tprev = A.prof ? clock64() : 0;
     if (!A.frame_ok[t]) continue;  // uniform
     const float4 q = A.sample_q[t];
+    bool gmode = false;  // stage 0: this sample's list lives in the global slice (set once K is known)
+    auto pos_at = [&](int j) -> int { return (LITE && gmode) ? gpos[j] : POS[j]; };
+    auto ldp = [&](int j, float& x, float& y, float& z) {  // cropped point j, centred on the sample
+      if (LITE) {
+        const float4 p = A.pts[pos_at(j)];
+        x = p.x - q.x;
+        y = p.y - q.y;
+        z = p.z - q.z;
+      } else {
+        x = PX[j];
+        y = PY[j];
+        z = PZ[j];
+      }
+    };
     const double* fr = A.frames + (size_t)t * 12;
     const double smp[3] = {fr[0], fr[1], fr[2]};
     // frame = [normal binormal curvature_axis] as columns, hand_search.cpp:325-326
@@ -499,7 +534,7 @@ k_sweep(SweepArgs A) {
     const int nz = qr.empty ? 0 : (qr.hi[2] - qr.lo[2] + 1);
     const int nrows = ny * nz;  // <= kMaxRows by check_params
     // (the previous sample's readers of S are done: barrier in next_work)
-    for (int r = tid; r < nrows; r += kSweepThreads) {
+    for (int r = tid; r < nrows; r += NT) {
       const int cz = qr.lo[2] + r / ny, cy = qr.lo[1] + r % ny;
       int cxa = qr.lo[0], cxb = qr.hi[0];
       if (tighten) {
@@ -576,19 +611,18 @@ k_sweep(SweepArgs A) {
       }
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < kSweepWaves; k++) {
+      for (int k = 0; k < NW; k++) {
         nrows_c += S.wave_cnt[k];
         kcand += S.red.i[0][k][0];
       }
     }
-    if (STAGE == 0 && kcand > 3 * kLdsCapBig) {
-      // Very dense neighbourhood: the cropped list is about 0.6 of the candidates, so it will not
-      // fit either LDS stage -- hand the sample to the global-scratch stage before the crop pass
-      // instead of after it.  Only a routing decision: every stage computes the same result.
+    if (STAGE == 0 && kcand > 2 * kGposCap) {
+      // Dense neighbourhood: the cropped list is about 0.6 of the candidates, so it will not fit
+      // this stage -- hand the sample to the global-scratch stage before the crop pass instead of
+      // after it.  Only a routing decision: both stages compute the same result.
       if (tid == 0) {
-        const unsigned at = atomicAdd(&A.st->n_overflow2, 1u);
-        A.overflow2[at] = t;
-        atomicAdd(&A.st->n_handed_on, 1u);
+        const unsigned at = atomicAdd(&A.st->n_overflow, 1u);
+        A.overflow[at] = t;
       }
       continue;
     }
@@ -615,7 +649,7 @@ k_sweep(SweepArgs A) {
       __syncthreads();
       int poff = 0;
 #pragma unroll
-      for (int k = 0; k < kSweepWaves; k++) {
+      for (int k = 0; k < NW; k++) {
         if (k < wid) poff += S.wave_cnt[k];
         n_pieces += S.wave_cnt[k];
       }
@@ -649,12 +683,12 @@ k_sweep(SweepArgs A) {
     const unsigned long long grp_mask = ((kGrp == 64) ? ~0ull : ((1ull << kGrp) - 1ull)) << (grp * kGrp);
     const int n_sets = (n_pieces + kGpw - 1) / kGpw;  // one set = the pieces of one wave-wide load
     int my_k2 = 0;
-    for (int pp0 = wid; pp0 < n_sets; pp0 += 4 * kSweepWaves) {
+    for (int pp0 = wid; pp0 < n_sets; pp0 += 4 * NW) {
       int pb[4], pl[4];
       float4 pv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int pc = kGpw * (pp0 + u * kSweepWaves) + grp;
+        const int pc = kGpw * (pp0 + u * NW) + grp;
         const bool ok = pc < n_pieces;
         pb[u] = ok ? S.piece_start[pc] : 0;
         pl[u] = ok ? (int)(S.piece_lc[pc] & 0xFFFFu) : 0;
@@ -663,7 +697,7 @@ k_sweep(SweepArgs A) {
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int pc = kGpw * (pp0 + u * kSweepWaves) + grp;
+        const int pc = kGpw * (pp0 + u * NW) + grp;
         float4 d;
         int cls = (lg < pl[u]) ? classify(pv[u], d) : 0;
         int keep = __popcll(__ballot(cls == 3) & grp_mask);
@@ -701,7 +735,7 @@ k_sweep(SweepArgs A) {
       __syncthreads();
       int woff = 0;
 #pragma unroll
-      for (int k = 0; k < kSweepWaves; k++) {
+      for (int k = 0; k < NW; k++) {
         if (k < wid) woff += S.wave_cnt[k];
         K += S.wave_cnt[k];
         k2 += S.red.i[0][k][0];
@@ -717,15 +751,12 @@ k_sweep(SweepArgs A) {
       }
     }
     const bool too_big = K > CAP;
+    gmode = LITE && K > kCapL;
     if (too_big) {  // uniform
       if (tid == 0) {
-        if (STAGE == 0) atomicAdd(&A.st->n_handed_on, 1u);
-        if (STAGE == 0 && K <= kLdsCapBig) {
+        if (STAGE == 0) {
           const unsigned at = atomicAdd(&A.st->n_overflow, 1u);
           A.overflow[at] = t;
-        } else if (STAGE <= 1) {  // (stage 0 knows the list length: straight to the stage that holds it)
-          const unsigned at = atomicAdd(&A.st->n_overflow2, 1u);
-          A.overflow2[at] = t;
         } else {
           atomicOr(&A.st->err_flags, 8u);
         }
@@ -742,12 +773,12 @@ k_sweep(SweepArgs A) {
     __syncthreads();
     // pass 2: write the survivors of each piece at its offset (order within a piece preserved)
     const unsigned long long lt_grp = lt_mask & grp_mask;  // lower lanes of my lane group
-    for (int pp0 = wid; pp0 < n_sets; pp0 += 4 * kSweepWaves) {
+    for (int pp0 = wid; pp0 < n_sets; pp0 += 4 * NW) {
       int pb[4], pl[4], po[4];
       float4 pv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int pc = kGpw * (pp0 + u * kSweepWaves) + grp;
+        const int pc = kGpw * (pp0 + u * NW) + grp;
         const bool ok = pc < n_pieces;
         const unsigned lc = ok ? S.piece_lc[pc] : 0u;
         pb[u] = ok ? S.piece_start[pc] : 0;
@@ -766,8 +797,10 @@ k_sweep(SweepArgs A) {
           const unsigned long long mask = __ballot(cls == 3);
           if (cls == 3) {
             const int dst = dst0 + __popcll(mask & lt_grp);
-            PX[dst] = d.x; PY[dst] = d.y; PZ[dst] = d.z;
-            POS[dst] = pb[u] + j;
+            if (!LITE) {
+              PX[dst] = d.x; PY[dst] = d.y; PZ[dst] = d.z;
+            }
+            if (LITE && gmode) gpos[dst] = pb[u] + j; else POS[dst] = pb[u] + j;
           }
           dst0 += __popcll(mask & grp_mask);
           o += kGrp;
@@ -857,12 +890,13 @@ k_sweep(SweepArgs A) {
       // work; the set is shared across the workgroup through S.dead (an optimisation only: a late
       // reader just does redundant work).
       unsigned alive = (R >= 32) ? 0xFFFFFFFFu : ((1u << R) - 1u);
-      for (int j0 = 0; j0 < K; j0 += kSweepThreads) {
+      for (int j0 = 0; j0 < K; j0 += NT) {
         alive = (unsigned)__builtin_amdgcn_readfirstlane((int)(alive & ~S.dead));
         if (alive == 0u) break;
         const int j = j0 + tid;
         const bool valid = j < K;
-        const float px = valid ? PX[j] : 0.f, py = valid ? PY[j] : 0.f, pz = valid ? PZ[j] : 0.f;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (valid) ldp(j, px, py, pz);
         const float u = (n0 * px + n1 * py) + n2 * pz;
         const float v = (b0 * px + b1 * py) + b2 * pz;
         unsigned need_exact = 0;  // orientations whose estimate is too close to a threshold
@@ -936,7 +970,7 @@ k_sweep(SweepArgs A) {
       unsigned cb = 0, cf = 0;
       if (lane < R) {
 #pragma unroll
-        for (int k = 0; k < kSweepWaves; k++) {
+        for (int k = 0; k < NW; k++) {
           cb |= S.res_a[k][lane][0];
           cf |= S.res_a[k][lane][1];
         }
@@ -979,8 +1013,10 @@ k_sweep(SweepArgs A) {
       // (the same pass yields surface = min y over ALL rotated points, finger_hand.cpp:158)
       int kfail = n_depths;
       double miny = __builtin_inf();
-      for (int j = tid; j < K; j += kSweepThreads) {
-        const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
+      for (int j = tid; j < K; j += NT) {
+        float fx_, fy_, fz_;
+        ldp(j, fx_, fy_, fz_);
+        const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
         const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
         const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
         miny = (y < miny) ? y : miny;
@@ -1004,7 +1040,7 @@ k_sweep(SweepArgs A) {
       kfail = n_depths;
       double surface = __builtin_inf();
 #pragma unroll
-      for (int k = 0; k < kSweepWaves; k++) {
+      for (int k = 0; k < NW; k++) {
         kfail = min(kfail, S.red.i[red_sel][k][0]);
         const double v = S.red.d[red_sel][k][0];
         surface = (v < surface) ? v : surface;
@@ -1020,7 +1056,7 @@ k_sweep(SweepArgs A) {
       const double right = fr0;
       const double center = 0.5 * (left + right);
       // pass C: in-box points, ordered compaction (each wave a contiguous quarter of the list)
-      const int segk = (((K + kSweepWaves - 1) / kSweepWaves) + 63) & ~63;
+      const int segk = (((K + NW - 1) / NW) + 63) & ~63;
       const int jb = min(wid * segk, K), je = min(jb + segk, K);
       int cnt = 0;
       double mnx = __builtin_inf(), mxx = -__builtin_inf();
@@ -1028,7 +1064,9 @@ k_sweep(SweepArgs A) {
         const int j = j0 + lane;
         bool in = false;
         if (j < je) {
-          const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
+          float fx_, fy_, fz_;
+          ldp(j, fx_, fy_, fz_);
+          const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
           const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
           const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
           in = (y < top && x > left && x < right);
@@ -1052,7 +1090,7 @@ k_sweep(SweepArgs A) {
       mnx = __builtin_inf();
       mxx = -__builtin_inf();
 #pragma unroll
-      for (int k = 0; k < kSweepWaves; k++) {
+      for (int k = 0; k < NW; k++) {
         const int ck = S.red.i[red_sel][k][0];
         if (k < wid) pbase_w += ck;
         P += ck;
@@ -1067,7 +1105,9 @@ k_sweep(SweepArgs A) {
           const int j = j0 + lane;
           bool in = false;
           if (j < je) {
-            const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
+            float fx_, fy_, fz_;
+            ldp(j, fx_, fy_, fz_);
+            const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
             const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
             const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
             in = (y < top && x > left && x < right);
@@ -1075,7 +1115,9 @@ k_sweep(SweepArgs A) {
           const unsigned long long mask = __ballot(in);
           if (in) {
             const int dst = run + __popcll(mask & lt_mask);
-            if (LDS_STORE) box16[dst] = (unsigned short)j; else box32[dst] = j;
+            if (LITE && gmode) gbox[dst] = (unsigned short)j;
+            else if (LDS_STORE) box16[dst] = (unsigned short)j;
+            else box32[dst] = j;
           }
           run += __popcll(mask);
         }
@@ -1106,10 +1148,12 @@ k_sweep(SweepArgs A) {
       double e[8] = {-__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf(),
                      -__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf()};
       // e: lmaxy lminy lmaxz lminz rmaxy rminy rmaxz rminz
-      for (int b = tid; b < P; b += kSweepThreads) {
-        const int j = LDS_STORE ? (int)box16[b] : box32[b];
-        const double p0 = (double)PX[j], p1 = (double)PY[j], p2 = (double)PZ[j];
-        const float4 nn = A.nrm[POS[j]];  // hand_search.cpp:211, :394: the point's normal
+      for (int b = tid; b < P; b += NT) {
+        const int j = (LITE && gmode) ? (int)gbox[b] : (LDS_STORE ? (int)box16[b] : box32[b]);
+        float fx_, fy_, fz_;
+        ldp(j, fx_, fy_, fz_);
+        const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
+        const float4 nn = A.nrm[pos_at(j)];  // hand_search.cpp:211, :394: the point's normal
         const double q0 = (double)nn.x, q1 = (double)nn.y, q2 = (double)nn.z;
         double X[3], Y[3], U[3];
 #pragma unroll
@@ -1157,7 +1201,7 @@ k_sweep(SweepArgs A) {
           e[k] = -__builtin_inf();
           e[k + 1] = __builtin_inf();
         }
-        for (int wv = 0; wv < kSweepWaves; wv++) {
+        for (int wv = 0; wv < NW; wv++) {
           nl += S.red.i[red_sel][wv][0];
           nr += S.red.i[red_sel][wv][1];
           for (int k = 0; k < 8; k += 2) {
@@ -1226,9 +1270,8 @@ k_sweep(SweepArgs A) {
 }
 
 static size_t sweep_lds_bytes(int stage) {
-  size_t b = (sizeof(SweepShared) + 15) & ~size_t(15);
-  if (stage == 0) b += (size_t)kLdsCap * 4 * 4 + (size_t)kLdsCap * 2;
-  if (stage == 1) b += (size_t)kLdsCapBig * 4 * 4 + (size_t)kLdsCapBig * 2;
+  size_t b = sweep_ctl_bytes(stage);
+  if (stage == 0) b += (size_t)kLdsCap * (size_t)kStage0PointBytes;
   return b;
 }
 
@@ -1289,7 +1332,7 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
   AG2_HIP(c, c->d_table.reserve(std::max<size_t>(n_slots, 1) * sizeof(ag2_hypothesis)));
   AG2_HIP(c, c->d_tab_off.reserve(std::max<size_t>(n_slots, 1) * 8));
   AG2_HIP(c, c->d_tab_keep.reserve(std::max<size_t>(n_slots, 1)));
-  AG2_HIP(c, c->d_overflow.reserve(std::max<size_t>(s, 1) * 8));  // two queues of sample ids
+  AG2_HIP(c, c->d_overflow.reserve(std::max<size_t>(s, 1) * 4));  // queue of sample ids for stage 1
   if (s == 0) return 0;
   if (emit_lists && c->arena_points == 0) {
     c->arena_points = (size_t)16 << 20;  // 16 Mi points = 768 MiB; grown on AG2_ERR_CAPACITY
@@ -1325,47 +1368,40 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
     AG2_HIP(c, hipMemsetAsync(prof_buf.p, 0, 16 * 8, c->stream));
     A.prof = prof_buf.as<unsigned long long>();
   }
-  const size_t lds = sweep_lds_bytes(0), lds_big = sweep_lds_bytes(1);
+  const size_t lds = sweep_lds_bytes(0);
   typedef void (*SweepFn)(SweepArgs);
   const SweepFn fn_lds = (R <= 8) ? k_sweep<0, 8> : (R <= 16 ? k_sweep<0, 16> : k_sweep<0, 32>);
-  const SweepFn fn_big = (R <= 8) ? k_sweep<1, 8> : (R <= 16 ? k_sweep<1, 16> : k_sweep<1, 32>);
-  const SweepFn fn_glb = (R <= 8) ? k_sweep<2, 8> : (R <= 16 ? k_sweep<2, 16> : k_sweep<2, 32>);
-  AG2_HIP(c, hipFuncSetAttribute((const void*)fn_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-  AG2_HIP(c, hipFuncSetAttribute((const void*)fn_big, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds_big));
-  A.overflow2 = c->d_overflow.as<int>() + s;  // second queue behind the first
-  const int grid = (int)std::min<size_t>(s, 256 * 2);
-  hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads), lds, c->stream, A);
+  const SweepFn fn_glb = (R <= 8) ? k_sweep<1, 8> : (R <= 16 ? k_sweep<1, 16> : k_sweep<1, 32>);
+  const int grid = (int)std::min<size_t>(s, 256 * kStage0WgPerCu);
+  AG2_HIP(c, c->d_gpos.reserve((size_t)256 * kStage0WgPerCu * kGposCap * 6));
+  A.gpos = c->d_gpos.as<int>();
+  hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads0), lds, c->stream, A);
   AG2_HIP(c, hipGetLastError());
   AG2_HIP(c, hipEventRecord(c->ev[2], c->stream));
   if (want_prof) {
     unsigned long long h[8];
     AG2_HIP(c, hipStreamSynchronize(c->stream));
     AG2_HIP(c, hipMemcpy(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[ag2 sweep prof, LDS variant, cycles summed over workgroups] rows %llu crop1 %llu "
+    fprintf(stderr, "[ag2 sweep prof, stage 0, cycles summed over workgroups] rows %llu crop1 %llu "
             "crop2 %llu passA %llu deepen %llu passC %llu passD %llu other %llu\n",
             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     AG2_HIP(c, hipMemsetAsync(prof_buf.p, 0, 16 * 8, c->stream));
   }
-  // Overflow samples (cropped neighbourhood larger than the LDS stage) were queued on the device;
-  // the next stages are always launched and read their queue lengths themselves (st->n_overflow,
-  // st->n_overflow2), so no host round trip sits between the launches.
-  hipLaunchKernelGGL(fn_big, dim3(256), dim3(kSweepThreads), lds_big, c->stream, A);
-  AG2_HIP(c, hipGetLastError());
+  // Samples whose cropped list exceeds stage 0 were queued on the device; the second stage is always
+  // launched and reads the queue length itself (st->n_overflow), so no host round trip sits between
+  // the launches.
   const int gcap = 1 << 16, g2 = 512;  // two workgroups per CU x 5 x 64 Ki words = 671 MB of scratch
   AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 5 * gcap * 4));
-  A.n_overflow = -1;  // read from st->n_overflow on the device
   A.gscratch = c->d_gscratch.as<float>();
   A.gcap = gcap;
-  hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads), sweep_lds_bytes(2), c->stream, A);
+  hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads1), sweep_lds_bytes(1), c->stream, A);
   AG2_HIP(c, hipGetLastError());
   AG2_HIP(c, hipEventRecord(c->ev[11], c->stream));
   if (want_prof) {
     unsigned long long h[8];
     AG2_HIP(c, hipStreamSynchronize(c->stream));
     AG2_HIP(c, hipMemcpy(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[ag2 sweep prof, global variant] rows %llu crop1 %llu crop2 %llu passA %llu "
+    fprintf(stderr, "[ag2 sweep prof, stage 1 (global scratch)] rows %llu crop1 %llu crop2 %llu passA %llu "
             "deepen %llu passC %llu passD %llu other %llu\n",
             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
   }
