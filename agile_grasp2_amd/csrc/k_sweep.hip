@@ -384,6 +384,7 @@ struct SweepShared {
   int row_len[kMaxRows];
   int piece_start[kMaxPieces];   // rows cut into pieces of <= PL points
   unsigned piece_lc[kMaxPieces]; // low 16 bits: length; high 16: survivor count, then offset
+  unsigned piece_mask[kMaxPieces]; // stage 0: which points of the piece survive the crop (pieces <= 32)
   double fs[20], fsr[20];        // finger-slot table (exact path of pass A, deepen)
   double depths[kMaxDepths];
   double cosd[kMaxOrient], sind[kMaxOrient];    // hand angles, f64 (exact path)
@@ -628,6 +629,13 @@ k_sweep(SweepArgs A) {
     }
     int PL = kGrp;  // piece length; grows only if the table would overflow (dense clouds)
     while (kcand / PL + nrows_c > kMaxPieces) PL <<= 1;
+    if (LITE && PL > 32) {  // (cannot happen below the hand-on threshold above; the masks are 32 bits)
+      if (tid == 0) {
+        const unsigned at = atomicAdd(&A.st->n_overflow, 1u);
+        A.overflow[at] = t;
+      }
+      continue;
+    }
     int n_pieces = 0;
     {
       int len[kRowsPerThread], st[kRowsPerThread], np = 0;
@@ -700,15 +708,22 @@ k_sweep(SweepArgs A) {
         const int pc = kGpw * (pp0 + u * NW) + grp;
         float4 d;
         int cls = (lg < pl[u]) ? classify(pv[u], d) : 0;
-        int keep = __popcll(__ballot(cls == 3) & grp_mask);
+        unsigned long long bal = __ballot(cls == 3) & grp_mask;
+        int keep = __popcll(bal);
+        unsigned pm = (unsigned)(bal >> (grp * kGrp));  // survivors of the piece, bit = position in it
         my_k2 += (cls != 0) ? 1 : 0;
         for (int o = kGrp; o < pl[u]; o += kGrp) {  // pieces longer than a group (dense clouds)
           const int j = o + lg;
           cls = (j < pl[u]) ? classify(A.pts[pb[u] + j], d) : 0;
-          keep += __popcll(__ballot(cls == 3) & grp_mask);
+          bal = __ballot(cls == 3) & grp_mask;
+          keep += __popcll(bal);
+          if (LITE) pm |= (unsigned)(bal >> (grp * kGrp)) << (o & 31);
           my_k2 += (cls != 0) ? 1 : 0;
         }
-        if (lg == 0 && pc < n_pieces) S.piece_lc[pc] = (unsigned)pl[u] | ((unsigned)keep << 16);
+        if (lg == 0 && pc < n_pieces) {
+          S.piece_lc[pc] = (unsigned)pl[u] | ((unsigned)keep << 16);
+          if (LITE) S.piece_mask[pc] = pm;
+        }
       }
     }
     my_k2 = wave_sum_i(my_k2);
@@ -771,9 +786,24 @@ k_sweep(SweepArgs A) {
     }
     if (K == 0) continue;  // hand_search.cpp:201 (no neighbours) / no cropped points => no fingers
     __syncthreads();
-    // pass 2: write the survivors of each piece at its offset (order within a piece preserved)
+    // pass 2: write the survivors of each piece at its offset (order within a piece preserved).
+    // Stage 0 stores positions only, and pass 1 left every piece's survivors as a bit mask: the list
+    // is written from the masks, without touching the points again.
+    if (LITE) {
+      for (int pc = tid; pc < n_pieces; pc += NT) {
+        unsigned m = S.piece_mask[pc];
+        int dst = (int)(S.piece_lc[pc] >> 16);
+        const int st = S.piece_start[pc];
+        while (m) {
+          const int b = __ffs((int)m) - 1;
+          m &= m - 1u;
+          if (gmode) gpos[dst] = st + b; else POS[dst] = st + b;
+          dst++;
+        }
+      }
+    }
     const unsigned long long lt_grp = lt_mask & grp_mask;  // lower lanes of my lane group
-    for (int pp0 = wid; pp0 < n_sets; pp0 += 4 * NW) {
+    for (int pp0 = wid; !LITE && pp0 < n_sets; pp0 += 4 * NW) {
       int pb[4], pl[4], po[4];
       float4 pv[4];
 #pragma unroll
@@ -797,10 +827,8 @@ k_sweep(SweepArgs A) {
           const unsigned long long mask = __ballot(cls == 3);
           if (cls == 3) {
             const int dst = dst0 + __popcll(mask & lt_grp);
-            if (!LITE) {
-              PX[dst] = d.x; PY[dst] = d.y; PZ[dst] = d.z;
-            }
-            if (LITE && gmode) gpos[dst] = pb[u] + j; else POS[dst] = pb[u] + j;
+            PX[dst] = d.x; PY[dst] = d.y; PZ[dst] = d.z;
+            POS[dst] = pb[u] + j;
           }
           dst0 += __popcll(mask & grp_mask);
           o += kGrp;
@@ -863,12 +891,18 @@ k_sweep(SweepArgs A) {
         }
       }
     };
-    unsigned blk_acc[RMAX], flg_acc[RMAX];  // flg bit0: some point has y < top, bit1: y < bottom
+    // Exact path: blk_acc (final slot bits), flg_acc (bit0: some point has y < top, bit1: y < bottom).
+    // Fast path: raw_acc holds bit (position + 2) of the clamped slot lattice, converted once at the
+    // end; its two flags are wave-uniform (ballots), kept per orientation in the scalars s_below /
+    // s_behind -- the loop body below is what the kernel's VALU time goes to, so it is kept short.
+    unsigned blk_acc[RMAX], flg_acc[RMAX], raw_acc[RMAX];
 #pragma unroll
     for (int i = 0; i < RMAX; i++) {
       blk_acc[i] = 0;
       flg_acc[i] = 0;
+      raw_acc[i] = 0;
     }
+    unsigned s_below = 0, s_behind = 0;
     {
       const float n0 = (float)F[0][0], n1 = (float)F[1][0], n2 = (float)F[2][0];
       const float b0 = (float)F[0][1], b1 = (float)F[1][1], b2 = (float)F[2][1];
@@ -900,32 +934,37 @@ k_sweep(SweepArgs A) {
         const float u = (n0 * px + n1 * py) + n2 * pz;
         const float v = (b0 * px + b1 * py) + b2 * pz;
         unsigned need_exact = 0;  // orientations whose estimate is too close to a threshold
-        unsigned behind = 0;      // orientations for which THIS point has y < bottom
+        unsigned newly = 0;       // (uniform) orientations found blocked from behind in this step
 #pragma unroll
         for (int i = 0; i < RMAX; i++) {
           if (i < R && ((alive >> i) & 1u)) {  // wave-uniform
             const float cf = S.cosf_t[i], sf = S.sinf_t[i];
-            const float xa = cf * u + sf * v, ya = cf * v - sf * u;
-            const bool near_y = (__builtin_fabsf(ya - top0f) < mY) | (__builtin_fabsf(ya - bot0f) < mY);
-            float rel = xa * invs;
-            rel = __builtin_fminf(__builtin_fmaxf(rel, -13.5f), 13.5f);
+            const float xa = __builtin_fmaf(cf, u, sf * v), ya = __builtin_fmaf(cf, v, -(sf * u));
+            // distance of the estimates to the nearest threshold, in y and in slot spacings
+            const float dy = __builtin_fminf(__builtin_fabsf(ya - top0f), __builtin_fabsf(ya - bot0f));
+            const float rel = xa * invs;
             const float kff = __builtin_floorf(rel);
             const float frac = rel - kff;
-            const int kb = (int)kff + 9;  // bit of position p in the 19-bit position mask
-            const bool near = (frac < eX) | (frac > 1.f - eX) | (__builtin_fabsf(frac - rm1) < eX);
-            // position p holds x (0 < frac < 1 < width); position p - 1 holds it iff frac + 1 < width
-            unsigned pm = ((unsigned)kb < 19u) ? (1u << (kb & 31)) : 0u;
-            pm |= ((frac < rm1) & ((unsigned)(kb - 1) < 19u)) ? (1u << ((kb - 1) & 31)) : 0u;
+            const float dx = __builtin_fminf(__builtin_fminf(frac, 1.f - frac), __builtin_fabsf(frac - rm1));
             const bool below = ya < top0f;
-            if (fast_ok && !near_y && !(near && below)) {
-              if (below && valid) {
-                const bool bh = ya < bot0f;
-                flg_acc[i] |= bh ? 3u : 1u;
-                behind |= bh ? (1u << i) : 0u;
-                blk_acc[i] |= (pm & 0x3FFu) | ((pm >> 9) << 10);
+            const bool fast = fast_ok && !(dy < mY) && !((dx < eX) && below);
+            const bool hit = fast && below && valid;
+            if (hit) {
+              // position p = floor(x / spacing) holds x (0 < frac < 1 < width); position p - 1 holds
+              // it iff frac + 1 < width.  Bit (p + 11), clamped: positions outside -9 .. 9 land on
+              // bits the conversion below drops.
+              int pb = (int)kff + 11;
+              pb = min(max(pb, 0), 22);
+              const unsigned bit = 1u << pb;
+              raw_acc[i] |= bit | ((frac < rm1) ? (bit >> 1) : 0u);
+            }
+            if (!fast && valid) need_exact |= 1u << i;
+            if (__ballot(hit)) {
+              s_below |= 1u << i;
+              if (__ballot(hit && ya < bot0f)) {
+                s_behind |= 1u << i;
+                newly |= 1u << i;
               }
-            } else if (valid) {
-              need_exact |= 1u << i;
             }
           }
         }
@@ -935,14 +974,12 @@ k_sweep(SweepArgs A) {
           need_exact &= need_exact - 1u;
           unsigned flg = 0, bits = 0;
           exact_A(ie, px, py, pz, flg, bits);
-          behind |= (flg & 2u) ? (1u << ie) : 0u;
 #pragma unroll
           for (int i = 0; i < RMAX; i++) {
             flg_acc[i] |= (i == ie) ? flg : 0u;
             blk_acc[i] |= (i == ie) ? bits : 0u;
           }
         }
-        const unsigned newly = wave_or_u(behind);
         if (newly) {
           alive &= ~newly;
           if (lane == 0) atomicOr(&S.dead, newly);
@@ -952,7 +989,9 @@ k_sweep(SweepArgs A) {
 #pragma unroll
     for (int i = 0; i < RMAX; i++) {
       if (i < R) {
-        const unsigned bsum = wave_or_u(blk_acc[i]), fsum = wave_or_u(flg_acc[i]);
+        const unsigned pm = (raw_acc[i] >> 2) & 0x7FFFFu;  // the 19 positions -9 .. 9
+        const unsigned bsum = wave_or_u(blk_acc[i] | (pm & 0x3FFu) | ((pm >> 9) << 10));
+        const unsigned fsum = wave_or_u(flg_acc[i]) | ((s_below >> i) & 1u) | (((s_behind >> i) & 1u) ? 3u : 0u);
         if (lane == 0) {
           S.res_a[wid][i][0] = bsum;
           S.res_a[wid][i][1] = fsum;
