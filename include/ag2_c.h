@@ -101,7 +101,7 @@ typedef struct ag2_times {
   float lenet_fc_ms;    /* K5 k_lenet_fc */
   float select_ms;      /* K6 score scatter, threshold compaction, record gather */
   float total_ms;       /* first to last event of the call */
-  float sweep_overflow_ms; /* K3 k_sweep, later stages for oversized neighbourhoods (160 KiB of LDS, then global scratch) */
+  float sweep_overflow_ms; /* K3 k_sweep, second stage for oversized neighbourhoods (global scratch) */
   float preprocess_ms;  /* workspace filter + voxel grid (ag2_preprocess_cloud*), without the grid build */
 } ag2_times;
 
