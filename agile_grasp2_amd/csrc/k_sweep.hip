@@ -20,9 +20,9 @@ namespace ag2 {
 // Threads per workgroup of the sweep's stages.  The sweep is bound by the latencies of its ~40
 // dependent phases per sample (SQ: waves wait > 50 % of their cycles), not by issue: halving the
 // threads of a workgroup costs 3-4 %, doubling the samples in flight per CU gains 12 %.  Stage 0
-// therefore runs FOUR 256-thread workgroups per CU; the stages for long lists keep 512 threads.
+// therefore runs FOUR 256-thread workgroups per CU, and so does the stage for long lists.
 constexpr int kSweepThreads0 = 256;   // stage 0
-constexpr int kSweepThreads1 = 512;   // stage 1 (long lists, global scratch)
+constexpr int kSweepThreads1 = 256;   // stage 1 (long lists, global scratch)
 constexpr int sweep_threads(int stage) { return stage == 0 ? kSweepThreads0 : kSweepThreads1; }
 
 // ---------------------------------------------------------------------------------------------
@@ -422,11 +422,11 @@ static_assert(kGposCap <= 65536, "in-box indices are 16 bits");
 //   STAGE 0: every sample; positions of the cropped list in 40 KiB of LDS (four 256-thread
 //            workgroups per CU), or in the workgroup's global slice up to kGposCap points
 //   STAGE 1: the samples stage 0 handed on (dense clouds); centred coordinates + positions of the
-//            cropped list in a per-workgroup global scratch (two 512-thread workgroups per CU)
+//            cropped list in a per-workgroup global scratch (four 256-thread workgroups per CU)
 // RMAX: compile-time bound on num_orientations (8, 16 or 32) for the per-orientation registers
 template <int STAGE, int RMAX>
 __global__ void __launch_bounds__(sweep_threads(STAGE),
-                                  (STAGE == 0 ? kStage0WgPerCu : 2) * sweep_threads(STAGE) / 256)
+                                  (STAGE == 0 ? kStage0WgPerCu : 4) * sweep_threads(STAGE) / 256)
 k_sweep(SweepArgs A) {
   constexpr int NT = sweep_threads(STAGE), NW = NT / kWave;
   constexpr int kRowsPerThread = (kMaxRows + NT - 1) / NT;
@@ -1429,7 +1429,7 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
   // Samples whose cropped list exceeds stage 0 were queued on the device; the second stage is always
   // launched and reads the queue length itself (st->n_overflow), so no host round trip sits between
   // the launches.
-  const int gcap = 1 << 16, g2 = 512;  // two workgroups per CU x 5 x 64 Ki words = 671 MB of scratch
+  const int gcap = 1 << 16, g2 = 1024;  // four workgroups per CU x 5 x 64 Ki words = 1.3 GB of scratch
   AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 5 * gcap * 4));
   A.gscratch = c->d_gscratch.as<float>();
   A.gcap = gcap;
