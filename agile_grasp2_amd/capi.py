@@ -22,7 +22,7 @@ SYMBOLS = [
     "ag2_lenet_load", "ag2_lenet_forward", "ag2_detect", "ag2_export_candidates_device",
     "ag2_get_counters", "ag2_get_stage_times",
     "ag2_preprocess_cloud", "ag2_preprocess_cloud_device", "ag2_get_cloud", "ag2_subsample_uniformly",
-    "ag2_find_clusters", "ag2_set_min_inliers", "ag2_set_grid_origin",
+    "ag2_find_clusters", "ag2_set_min_inliers", "ag2_set_grid_origin", "ag2_set_stage_timing",
 ]
 
 
@@ -326,6 +326,10 @@ class Detector:
         o = None if origin is None else np.ascontiguousarray(origin, dtype=np.float32)
         assert o is None or o.shape == (3,)
         self._ck(self.L.ag2_set_grid_origin(self.h, _ptr(o)))
+
+    def set_stage_timing(self, level: int):
+        """2: events around every stage (default), 1: around the sweep only, 0: none."""
+        self._ck(self.L.ag2_set_stage_timing(self.h, C.c_int(level)))
 
     def find_clusters(self, hands, min_inliers: int):
         """HandleSearch::findClusters(hand_list) on the GPU; hands: HYP_DTYPE array."""

@@ -100,13 +100,14 @@ static int check_params(ag2_ctx* c) {
 // k_normals is launched without a host sync; its duration and neighbour counter are read here.
 int collect_normals_stats(ag2_ctx* c) {
   if (c->grid_pending) {
-    AG2_HIP(c, hipEventSynchronize(c->ev[13]));
-    (void)hipEventElapsedTime(&c->times.grid_ms, c->ev[12], c->ev[13]);
+    AG2_HIP(c, stage_sync(c, 13));
+    stage_elapsed(c, &c->times.grid_ms, 12, 13);
     c->grid_pending = false;
   }
   if (!c->normals_pending) return 0;
-  AG2_HIP(c, hipEventSynchronize(c->ev[10]));
-  (void)hipEventElapsedTime(&c->times.normals_ms, c->ev[9], c->ev[10]);
+  if (stage_event_on(c, 10)) AG2_HIP(c, hipEventSynchronize(c->ev[10]));
+  else AG2_HIP(c, hipStreamSynchronize(c->stream));  // k_normals must be done before its counter is read
+  stage_elapsed(c, &c->times.normals_ms, 9, 10);
   unsigned long long k1 = 0;
   AG2_HIP(c, hipMemcpy(&k1, (const char*)c->d_stats.p + offsetof(DevStats, sum_k1), 8, hipMemcpyDeviceToHost));
   c->cnt.sum_k1 = (int64_t)k1;
@@ -138,10 +139,10 @@ int after_cloud(ag2_ctx* c) {
   c->s = 0;
   c->n_img = 0;
   c->n_resident_samples = 0;
-  AG2_HIP(c, hipEventRecord(c->ev[12], c->stream));
+  AG2_HIP(c, stage_event(c, 12));
   const int rc = build_grid(c);  // one host round trip inside (cloud bounds -> grid dimensions)
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[13], c->stream));
+  AG2_HIP(c, stage_event(c, 13));
   c->grid_pending = true;        // duration collected at the next synchronisation point
   c->cnt.n_points = (int64_t)c->n;
   c->cnt.n_valid_points = (int64_t)c->n_valid;
@@ -206,6 +207,7 @@ ag2_ctx* ag2_create(const ag2_params* p, int device_id) {
   }
   c->own_stream = true;
   for (auto& e : c->ev) (void)hipEventCreate(&e);
+
   derive_constants(c);
   if (c->d_stats.reserve(sizeof(DevStats)) != hipSuccess || upload_constants(c) != 0 ||
       pin_reserve(c, (size_t)1 << 20) != 0) {
@@ -323,10 +325,10 @@ int ag2_compute_normals(ag2_ctx* c) {
   // only a repeated call on the same cloud has to clear it again
   if (c->has_normals)
     AG2_HIP(c, hipMemsetAsync((char*)c->d_stats.p + offsetof(DevStats, sum_k1), 0, 8, c->stream));
-  AG2_HIP(c, hipEventRecord(c->ev[9], c->stream));
+  AG2_HIP(c, stage_event(c, 9));
   const int rc = launch_normals(c);
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[10], c->stream));
+  AG2_HIP(c, stage_event(c, 10));
   c->normals_pending = true;
   c->has_normals = true;
   return 0;
@@ -363,6 +365,17 @@ int ag2_get_grid_perm(ag2_ctx* c, int32_t* perm, size_t cap, size_t* n_valid) {
     AG2_HIP(c, hipMemcpyAsync(perm, c->d_perm.p, c->n_valid * 4, hipMemcpyDeviceToHost, c->stream));
     AG2_HIP(c, hipStreamSynchronize(c->stream));
   }
+  return 0;
+}
+
+int ag2_set_stage_timing(ag2_ctx* c, int level) {
+  if (!c) return AG2_ERR_ARG;
+  if (level < 0 || level > 2) return set_err(c, AG2_ERR_ARG, "stage timing level must be 0, 1 or 2");
+  (void)hipSetDevice(c->device);
+  if (c->stream) AG2_HIP(c, hipStreamSynchronize(c->stream));  // no half-recorded pairs
+  c->stage_timing = level;
+  memset(&c->times, 0, sizeof(c->times));
+  c->grid_pending = false;  // (its events may not exist at the new level)
   return 0;
 }
 

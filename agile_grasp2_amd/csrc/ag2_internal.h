@@ -162,6 +162,7 @@ struct ag2_ctx {
   std::vector<int32_t> h_slots;         // their slot ids
   std::vector<int64_t> h_offsets;       // their arena offsets
   std::vector<uint8_t> h_keep;          // their prune flags
+  int stage_timing = 2;    // which per-stage HIP events are recorded (ag2_set_stage_timing)
   size_t n_img = 0;
   int max_p = 0;           // largest in-box point list of the last hypothesis run
 
@@ -191,6 +192,27 @@ inline char* pin_small(ag2_ctx* c) { return (char*)c->h_pin; }
 inline char* pin_bulk(ag2_ctx* c) { return (char*)c->h_pin + kPinSmall; }
 // k_grid.hip
 int build_grid(ag2_ctx* c);
+// Per-stage timing events cost a few microseconds of stream serialisation each (about 3 % of a cfg2
+// step for all of them), so how many are recorded is a setting (ag2_set_stage_timing): 0 none,
+// 1 only the three around the sweep's two stages (the dominant kernel), 2 all.  Stages whose events
+// are not recorded report 0 ms.
+inline bool stage_event_on(const ag2_ctx* c, int i) {
+  return c->stage_timing >= 2 || (c->stage_timing == 1 && (i == 1 || i == 2 || i == 11));
+}
+inline hipError_t stage_event(ag2_ctx* c, int i) {
+  return stage_event_on(c, i) ? hipEventRecord(c->ev[i], c->stream) : hipSuccess;
+}
+inline void stage_elapsed(ag2_ctx* c, float* ms, int a, int b) {
+  *ms = 0.f;
+  if (stage_event_on(c, a) && stage_event_on(c, b) &&
+      hipEventElapsedTime(ms, c->ev[a], c->ev[b]) != hipSuccess) {
+    *ms = 0.f;                  // (an event of the pair was never recorded at this level)
+    (void)hipGetLastError();    // not an error of the path: do not leave it for the next check
+  }
+}
+inline hipError_t stage_sync(ag2_ctx* c, int i) {
+  return stage_event_on(c, i) ? hipEventSynchronize(c->ev[i]) : hipSuccess;
+}
 int gather_normals(ag2_ctx* c);  // d_tmp (float4, original order) -> d_nrm (sorted order)
 int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, float4* dst,
                     bool with_bounds = false);
@@ -225,6 +247,6 @@ int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, con
 int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const float* c2w,
                        const float* c2b, const float* f1w, const float* f1b, const float* f2w,
                        const float* f2b);
-int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits, hipEvent_t ev_mid);
+int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits, int ev_mid);
 
 }  // namespace ag2

@@ -52,10 +52,10 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     if (rc) return rc;
     rc = upload_samples(c, sample_idx, sample_xyz, s);
     if (rc) return rc;
-    AG2_HIP(c, hipEventRecord(c->ev[0], c->stream));
+    AG2_HIP(c, stage_event(c, 0));
     rc = launch_frames(c, s, slot_base, seed);
     if (rc) return rc;
-    AG2_HIP(c, hipEventRecord(c->ev[1], c->stream));
+    AG2_HIP(c, stage_event(c, 1));
     rc = launch_sweep(c, s, slot_base, emit_lists);  // records ev[2] (LDS variant) and ev[11]
     if (rc) return rc;
     if (compact_mode >= 0) {
@@ -82,15 +82,15 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     c->cnt.n_overflow_samples = hs.n_overflow;  // handed to the sweep's global-scratch stage
     if (compact_mode >= 0) c->n_img = hs.n_list;
     c->max_p = (int)hs.max_p;
-    (void)hipEventElapsedTime(&c->times.frames_ms, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&c->times.sweep_ms, c->ev[1], c->ev[2]);
-    (void)hipEventElapsedTime(&c->times.sweep_overflow_ms, c->ev[2], c->ev[11]);
+    stage_elapsed(c, &c->times.frames_ms, 0, 1);
+    stage_elapsed(c, &c->times.sweep_ms, 1, 2);
+    stage_elapsed(c, &c->times.sweep_overflow_ms, 2, 11);
     if (c->grid_pending) {
-      (void)hipEventElapsedTime(&c->times.grid_ms, c->ev[12], c->ev[13]);
+      stage_elapsed(c, &c->times.grid_ms, 12, 13);
       c->grid_pending = false;
     }
     if (c->normals_pending) {  // the stream has been synchronised: k_normals is long done
-      (void)hipEventElapsedTime(&c->times.normals_ms, c->ev[9], c->ev[10]);
+      stage_elapsed(c, &c->times.normals_ms, 9, 10);
       c->cnt.sum_k1 = (int64_t)hs.sum_k1;
       c->normals_pending = false;
     }
@@ -182,7 +182,7 @@ int ag2_render_images(ag2_ctx* c, size_t first, size_t count, uint8_t* out) {
   (void)hipSetDevice(c->device);
   if (first + count > c->h_hyps.size()) return set_err(c, AG2_ERR_ARG, "render: range");
   if (count == 0) return 0;
-  AG2_HIP(c, hipEventRecord(c->ev[3], c->stream));
+  AG2_HIP(c, stage_event(c, 3));
   int rc = make_image_descs(c, c->d_list.as<int>() + first, count);
   if (rc) return rc;
   AG2_HIP(c, c->d_images.reserve(count * 10800));
@@ -190,10 +190,10 @@ int ag2_render_images(ag2_ctx* c, size_t first, size_t count, uint8_t* out) {
                      (const int*)(c->d_desc.as<long long>() + count), count,
                      c->d_images.as<uint8_t>(), c->max_p);
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[4], c->stream));
+  AG2_HIP(c, stage_event(c, 4));
   AG2_HIP(c, hipMemcpyAsync(out, c->d_images.p, count * 10800, hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipEventElapsedTime(&c->times.render_ms, c->ev[3], c->ev[4]);
+  stage_elapsed(c, &c->times.render_ms, 3, 4);
   return 0;
 }
 
@@ -252,14 +252,14 @@ int ag2_lenet_forward(ag2_ctx* c, const uint8_t* images, size_t n, float* out) {
   AG2_HIP(c, c->d_images.reserve(n * 10800));
   AG2_HIP(c, c->d_logits.reserve(n * 8));
   AG2_HIP(c, hipMemcpyAsync(c->d_images.p, images, n * 10800, hipMemcpyHostToDevice, c->stream));
-  AG2_HIP(c, hipEventRecord(c->ev[4], c->stream));
-  const int rc = launch_lenet(c, c->d_images.as<uint8_t>(), n, c->d_logits.as<float>(), c->ev[5]);
+  AG2_HIP(c, stage_event(c, 4));
+  const int rc = launch_lenet(c, c->d_images.as<uint8_t>(), n, c->d_logits.as<float>(), 5);
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[6], c->stream));
+  AG2_HIP(c, stage_event(c, 6));
   AG2_HIP(c, hipMemcpyAsync(out, c->d_logits.p, n * 8, hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipEventElapsedTime(&c->times.lenet_conv_ms, c->ev[4], c->ev[5]);
-  (void)hipEventElapsedTime(&c->times.lenet_fc_ms, c->ev[5], c->ev[6]);
+  stage_elapsed(c, &c->times.lenet_conv_ms, 4, 5);
+  stage_elapsed(c, &c->times.lenet_fc_ms, 5, 6);
   return 0;
 }
 
@@ -274,7 +274,7 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   if (!c->net.loaded) return set_err(c, AG2_ERR_STATE, "lenet weights not loaded");
   const size_t n_slots = s * (size_t)c->p.num_orientations;
   (void)n_slots;
-  AG2_HIP(c, hipEventRecord(c->ev[8], c->stream));
+  AG2_HIP(c, stage_event(c, 8));
   // 1. hypotheses + 2. prune (predicate evaluated in the sweep; the survivor list is compacted on
   // the device and its length comes back with the sweep's statistics: one host round trip)
   rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true, do_prune ? 1 : 0);
@@ -285,15 +285,15 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   AG2_HIP(c, c->d_logits.reserve(std::max<size_t>(n_img, 1) * 8));
   rc = make_image_descs(c, c->d_list2.as<int>(), n_img);                       // 3a. images
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[3], c->stream));
+  AG2_HIP(c, stage_event(c, 3));
   rc = launch_render(c, c->d_arena.as<double>(), c->d_desc.as<long long>(),
                      (const int*)(c->d_desc.as<long long>() + n_img), n_img,
                      c->d_images.as<uint8_t>(), c->max_p);
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[4], c->stream));
-  rc = launch_lenet(c, c->d_images.as<uint8_t>(), n_img, c->d_logits.as<float>(), c->ev[5]);  // 3b.
+  AG2_HIP(c, stage_event(c, 4));
+  rc = launch_lenet(c, c->d_images.as<uint8_t>(), n_img, c->d_logits.as<float>(), 5);  // 3b.
   if (rc) return rc;
-  AG2_HIP(c, hipEventRecord(c->ev[6], c->stream));
+  AG2_HIP(c, stage_event(c, 6));
   // 4. score = ip2[1] - ip2[0], keep score >= min_score_diff, gather in order -- all on the device;
   // one read-back brings the count and (for the usual small lists) the records themselves
   unsigned* d_nsel = &c->d_stats.as<DevStats>()->n_sel;
@@ -309,7 +309,7 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
     d_res = c->d_cluster.p;
     d_nres = d_nclu;
   }
-  AG2_HIP(c, hipEventRecord(c->ev[7], c->stream));
+  AG2_HIP(c, stage_event(c, 7));
   std::vector<ag2_hypothesis> anti;
   {
     // The records are followed by their count (trailer written by the gather / cluster kernel), so
@@ -352,12 +352,12 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
     if (n_img) memcpy(scored_all, all.data(), n_img * sizeof(ag2_hypothesis));
   }
   AG2_HIP(c, hipStreamSynchronize(c->stream));
-  (void)hipEventElapsedTime(&c->times.compact_ms, c->ev[11], c->ev[3]);
-  (void)hipEventElapsedTime(&c->times.render_ms, c->ev[3], c->ev[4]);
-  (void)hipEventElapsedTime(&c->times.lenet_conv_ms, c->ev[4], c->ev[5]);
-  (void)hipEventElapsedTime(&c->times.lenet_fc_ms, c->ev[5], c->ev[6]);
-  (void)hipEventElapsedTime(&c->times.select_ms, c->ev[6], c->ev[7]);
-  (void)hipEventElapsedTime(&c->times.total_ms, c->ev[8], c->ev[7]);
+  stage_elapsed(c, &c->times.compact_ms, 11, 3);
+  stage_elapsed(c, &c->times.render_ms, 3, 4);
+  stage_elapsed(c, &c->times.lenet_conv_ms, 4, 5);
+  stage_elapsed(c, &c->times.lenet_fc_ms, 5, 6);
+  stage_elapsed(c, &c->times.select_ms, 6, 7);
+  stage_elapsed(c, &c->times.total_ms, 8, 7);
   if (k > cap) return set_err(c, AG2_ERR_CAPACITY, "detect: output capacity too small");
   if (k) memcpy(selected, anti.data(), k * sizeof(ag2_hypothesis));
   return 0;

@@ -331,9 +331,9 @@ int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const flo
   return 0;
 }
 
-int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits, hipEvent_t ev_mid) {
+int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits, int ev_mid) {
   if (n == 0) {
-    if (ev_mid) AG2_HIP(c, hipEventRecord(ev_mid, c->stream));
+    if (ev_mid >= 0) AG2_HIP(c, stage_event(c, ev_mid));
     return 0;
   }
   LeNetDev& d = c->net;
@@ -354,7 +354,7 @@ int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits,
                        d.w1p.as<float>(), d.b1.as<float>(), d.w2p.as<float>(), d.b2.as<float>(),
                        c->d_act1.as<float>());
   }
-  if (ev_mid) AG2_HIP(c, hipEventRecord(ev_mid, c->stream));
+  if (ev_mid >= 0) AG2_HIP(c, stage_event(c, ev_mid));
   int n_pad = 0, ksplit = 0;
   if (d.use_x3) {  // ip1 with the same three-term split on the bf16 matrix cores
     const int rc = launch_lenet_fc1_x3(c, n, &n_pad, &ksplit);

@@ -305,11 +305,11 @@ static int preprocess_resident(ag2_ctx* c, size_t n, bool have_cam, bool have_nr
     return set_err(c, AG2_ERR_ARG, "normals do not survive voxelisation (cloud_camera.cpp:124-168)");
   if (voxelize && !((float)voxel_size > 0.f)) return set_err(c, AG2_ERR_ARG, "voxel_size must be positive");
   c->has_cloud = c->has_normals = false;
-  AG2_HIP(c, hipEventRecord(c->ev[14], c->stream));
+  AG2_HIP(c, stage_event(c, 14));
   auto finish = [&](size_t m) -> int {
     c->n = m;
     if (n_out) *n_out = m;
-    AG2_HIP(c, hipEventRecord(c->ev[15], c->stream));
+    AG2_HIP(c, stage_event(c, 15));
     int rc = after_cloud(c);
     if (rc) return rc;
     if (have_nrm && c->n_valid) {  // d_tmp holds the survivors' normals in cloud order
@@ -317,8 +317,8 @@ static int preprocess_resident(ag2_ctx* c, size_t n, bool have_cam, bool have_nr
       if (rc) return rc;
       c->has_normals = true;
     }
-    AG2_HIP(c, hipEventSynchronize(c->ev[15]));
-    (void)hipEventElapsedTime(&c->times.preprocess_ms, c->ev[14], c->ev[15]);
+    AG2_HIP(c, stage_sync(c, 15));
+    stage_elapsed(c, &c->times.preprocess_ms, 14, 15);
     return 0;
   };
   AG2_HIP(c, c->d_xyz_in.reserve(std::max<size_t>(n, 1) * 16));

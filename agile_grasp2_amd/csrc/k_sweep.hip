@@ -1416,7 +1416,7 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
   A.gpos = c->d_gpos.as<int>();
   hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads0), lds, c->stream, A);
   AG2_HIP(c, hipGetLastError());
-  AG2_HIP(c, hipEventRecord(c->ev[2], c->stream));
+  AG2_HIP(c, stage_event(c, 2));
   if (want_prof) {
     unsigned long long h[8];
     AG2_HIP(c, hipStreamSynchronize(c->stream));
@@ -1435,7 +1435,7 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
   A.gcap = gcap;
   hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads1), sweep_lds_bytes(1), c->stream, A);
   AG2_HIP(c, hipGetLastError());
-  AG2_HIP(c, hipEventRecord(c->ev[11], c->stream));
+  AG2_HIP(c, stage_event(c, 11));
   if (want_prof) {
     unsigned long long h[8];
     AG2_HIP(c, hipStreamSynchronize(c->stream));

@@ -195,6 +195,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Timed region: only the HIP events around the sweep (the dominant kernel) are recorded -- every
+    # stage event costs a few microseconds of stream serialisation, all of them about 3 % of a step.
+    # The other stages' durations come from an extra, untimed pass below.
+    d.set_stage_timing(1)
     for _ in range(args.warmup):
         step()
     sync()
@@ -235,6 +239,18 @@ def main():
 
     K = args.steps
     ms = {k: v / K for k, v in acc.items() if not k.startswith("reserved")}
+    # untimed pass with every stage event on: durations of the stages other than the sweep
+    d.set_stage_timing(2)
+    K2, acc2 = max(3, min(K, 10)), {}
+    for _ in range(K2):
+        step()
+        t = d.times()
+        for name, _ty in t._fields_:
+            acc2[name] = acc2.get(name, 0.0) + getattr(t, name)
+    torch.cuda.synchronize()
+    for k_, v_ in acc2.items():
+        if k_ not in ("sweep_ms", "sweep_overflow_ms") and not k_.startswith("reserved"):
+            ms[k_] = v_ / K2
     n_img = c.n_scored
     # algorithmic work per launch, measured neighbourhood sizes of this run
     kernels = {
@@ -251,12 +267,12 @@ def main():
                          if os.environ.get("AG2_LENET_F32") else
                          dict(bound="mfma", work=n_img * CONV_X3_ISSUED_FLOP, ms=ms["lenet_conv_ms"],
                               peak=PEAK_BF16_MFMA_TFLOPS,
-                              fp32_equivalent_tflops=n_img * CONV_FLOP / (ms["lenet_conv_ms"] * 1e-3) / 1e12)),
+                              fp32_equivalent_tflops=n_img * CONV_FLOP / (max(ms["lenet_conv_ms"], 1e-9) * 1e-3) / 1e12)),
         "k_lenet_fc": (dict(bound="mfma", work=n_img * FC_FLOP, ms=ms["lenet_fc_ms"])
                        if os.environ.get("AG2_LENET_F32") else
                        dict(bound="mfma", work=n_img * FC_X3_ISSUED_FLOP, ms=ms["lenet_fc_ms"],
                             peak=PEAK_BF16_MFMA_TFLOPS,
-                            fp32_equivalent_tflops=n_img * FC_FLOP / (ms["lenet_fc_ms"] * 1e-3) / 1e12)),
+                            fp32_equivalent_tflops=n_img * FC_FLOP / (max(ms["lenet_fc_ms"], 1e-9) * 1e-3) / 1e12)),
     }
     for k in kernels.values():
         if k["bound"] == "hbm":
@@ -326,6 +342,8 @@ def main():
                             f"table per rank"),
         },
         "stage_ms": {k: round(v, 4) for k, v in ms.items()},
+        "stage_ms_note": ("sweep_ms and sweep_overflow_ms: HIP events inside the timed region; the other stages: "
+                          f"an extra untimed pass of {K2} steps with all stage events on (they cost ~3 % of a step)"),
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu:
@@ -340,6 +358,8 @@ def main():
                 tot += fn()
             torch.cuda.synchronize()
             return (time.perf_counter() - t1) / reps, tot / reps
+
+        d.set_stage_timing(1)  # the side legs are throughput figures like the timed region
 
         def host_step():
             d.set_cloud(xyz)
@@ -384,6 +404,7 @@ def main():
             st_ = torch.cuda.Stream()
             dk = capi.Detector(device=local_rank, **launch_params(ws, R))
             dk.set_stream(st_.cuda_stream)
+            dk.set_stage_timing(1)
             dk.lenet_load(weights)
             pair.append(dk)
             streams.append(st_)

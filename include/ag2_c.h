@@ -181,6 +181,12 @@ int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes);
  * neighbourhood and prunes exactly as the unsplit run, so its hypotheses are identical.  Every point
  * of a cloud set afterwards must be >= the origin on every axis. */
 int ag2_set_grid_origin(ag2_ctx* c, const float* origin3);
+/* Which of the HIP events behind ag2_get_stage_times are recorded.  Each costs a few microseconds of
+ * stream serialisation (all of them about 3 % of a 1 ms detect step): 2 = every stage (default),
+ * 1 = only the sweep (sweep_ms, sweep_overflow_ms), 0 = none.  Stages without events report 0 ms.
+ * The reference has no counterpart (it times with std::clock() around whole calls,
+ * grasp_detector.cpp:86-88, :262-266). */
+int ag2_set_stage_timing(ag2_ctx* c, int level);
 
 /* ---- the step in front of the path: GraspDetector::preprocessPointCloud, grasp_detector.cpp:285-335 ----
  * Steps 1-2 on the GPU: CloudCamera::filterWorkspace (cloud_camera.cpp:89-121; bounds =

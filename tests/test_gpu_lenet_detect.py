@@ -188,3 +188,33 @@ def test_split_bf16_convolutions_are_as_accurate_as_the_fp32_mfma_path(monkeypat
     scale = np.abs(want).max()
     assert err["f32"] <= 2e-5 * scale and err["x3"] <= 2e-5 * scale, (err, scale)
     assert err["x3"] <= 4.0 * err["f32"] + 1e-6 * scale, (err, scale)
+
+
+def test_stage_timing_levels_do_not_change_results(small_scene):
+    """ag2_set_stage_timing only removes HIP events: same records, and the stages without events
+    report 0 ms."""
+    from agile_grasp2_amd import capi
+    from agile_grasp2_amd.weights import make_lenet_weights
+    xyz, ws, idx = small_scene
+    d = capi.Detector(**scene_params(ws, min_score_diff=-1e9))
+    d.lenet_load(make_lenet_weights(3))
+    outs = []
+    for level in (2, 1, 0, 2):
+        d.set_stage_timing(level)
+        d.set_cloud(xyz)
+        d.compute_normals()
+        sel, allh = d.detect(sample_idx=idx, seed=5)
+        outs.append((sel.tobytes(), allh.tobytes()))
+        t = d.times()
+        c = d.counters()
+        assert c.sum_k1 > 0
+        if level == 2:
+            assert t.sweep_ms > 0 and t.lenet_conv_ms > 0 and t.normals_ms > 0
+        elif level == 1:
+            assert t.sweep_ms > 0 and t.lenet_conv_ms == 0 and t.normals_ms == 0
+        else:
+            assert t.sweep_ms == 0 and t.total_ms == 0
+    assert all(o == outs[0] for o in outs[1:])
+    with pytest.raises(RuntimeError):
+        d.set_stage_timing(3)
+    d.close()
