@@ -165,6 +165,8 @@ struct ag2_ctx {
   int stage_timing = 2;    // which per-stage HIP events are recorded (ag2_set_stage_timing)
   size_t n_img = 0;
   int max_p = 0;           // largest in-box point list of the last hypothesis run
+  size_t desc_stride = 0;  // > 0: the compaction also left the image descriptors in d_desc (offsets,
+                           // then counts at + desc_stride)
 
   ag2::LeNetDev net;
   ag2_counters cnt{};
@@ -226,7 +228,8 @@ int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed);
 int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists);
 // k_select.hip
 int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out);
-int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count);
+int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count,
+                        bool with_descs = false);
 int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned* d_count);
 int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypothesis>& recs,
                    std::vector<int64_t>* offs, std::vector<uint8_t>* keep);

@@ -60,7 +60,7 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     if (rc) return rc;
     if (compact_mode >= 0) {
       rc = compact_slots_async(c, s * (size_t)c->p.num_orientations, compact_mode, c->d_list2,
-                               &c->d_stats.as<DevStats>()->n_list);
+                               &c->d_stats.as<DevStats>()->n_list, /*with_descs=*/true);
       if (rc) return rc;
     }
     DevStats hs;
@@ -283,11 +283,15 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   c->cnt.n_pruned = (int64_t)n_img;
   AG2_HIP(c, c->d_images.reserve(std::max<size_t>(n_img, 1) * 10800));
   AG2_HIP(c, c->d_logits.reserve(std::max<size_t>(n_img, 1) * 8));
-  rc = make_image_descs(c, c->d_list2.as<int>(), n_img);                       // 3a. images
-  if (rc) return rc;
+  size_t desc_stride = c->desc_stride;  // the compaction usually wrote the descriptors already
+  if (desc_stride == 0) {
+    rc = make_image_descs(c, c->d_list2.as<int>(), n_img);                     // 3a. images
+    if (rc) return rc;
+    desc_stride = n_img;
+  }
   AG2_HIP(c, stage_event(c, 3));
   rc = launch_render(c, c->d_arena.as<double>(), c->d_desc.as<long long>(),
-                     (const int*)(c->d_desc.as<long long>() + n_img), n_img,
+                     (const int*)(c->d_desc.as<long long>() + desc_stride), n_img,
                      c->d_images.as<uint8_t>(), c->max_p);
   if (rc) return rc;
   AG2_HIP(c, stage_event(c, 4));

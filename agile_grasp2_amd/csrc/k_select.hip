@@ -41,9 +41,15 @@ __global__ void k_slot_scatter(const unsigned* __restrict__ pref, int n_slots,
 // become one; at S*R = 40 000 slots the table is latency-, not bandwidth-sized.
 // Only the per-slot state byte is read (k_sweep: 0 empty, 1 hypothesis that survives the prune,
 // 4 hypothesis pruned away), 16 slots per load, never the 176-byte records.
+// With desc_off / desc_cnt the image descriptors (arena offset, point count) of the listed slots are
+// written in the same pass (one launch less between the sweep and the renderer).
 __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __restrict__ keep,
                                                         int n_slots, int mode, int* __restrict__ list,
-                                                        unsigned* __restrict__ count) {
+                                                        unsigned* __restrict__ count,
+                                                        const ag2_hypothesis* __restrict__ table,
+                                                        const long long* __restrict__ tab_off,
+                                                        long long* __restrict__ desc_off,
+                                                        int* __restrict__ desc_cnt) {
   __shared__ unsigned wsum[16];
   const int t = threadIdx.x;
   const int per = (((n_slots + 1023) / 1024) + 15) & ~15;  // 16 .. 64, a multiple of 16
@@ -80,21 +86,37 @@ __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __r
   while (mask) {
     const int b = __ffsll((long long)mask) - 1;
     mask &= mask - 1ull;
-    list[pos++] = s0 + b;
+    const int sl = s0 + b;
+    list[pos] = sl;
+    if (desc_off) {
+      desc_off[pos] = tab_off[sl];
+      desc_cnt[pos] = table[sl].n_points;
+    }
+    pos++;
   }
   if (t == 0) *count = all;
 }
 
 // Asynchronous: the list length is left on the device (*d_count) -- no host round trip.
-int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count) {
+int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count,
+                        bool with_descs) {
+  c->desc_stride = 0;
   if (n_slots == 0) {
     AG2_HIP(c, hipMemsetAsync(d_count, 0, 4, c->stream));
     return 0;
   }
   AG2_HIP(c, out_list.reserve(n_slots * 4));
   if (n_slots <= 65536 && mode <= 1) {
+    long long* d_off = nullptr;
+    if (with_descs) {  // descriptors for up to n_slots images: offsets, then counts
+      AG2_HIP(c, c->d_desc.reserve(n_slots * 12));
+      d_off = c->d_desc.as<long long>();
+      c->desc_stride = n_slots;
+    }
     hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, c->stream,
-                       c->d_tab_keep.as<unsigned char>(), (int)n_slots, mode, out_list.as<int>(), d_count);
+                       c->d_tab_keep.as<unsigned char>(), (int)n_slots, mode, out_list.as<int>(), d_count,
+                       c->d_table.as<ag2_hypothesis>(), c->d_tab_off.as<long long>(), d_off,
+                       d_off ? (int*)(d_off + n_slots) : (int*)nullptr);
     AG2_HIP(c, hipGetLastError());
     return 0;
   }
@@ -116,7 +138,7 @@ int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t
   *n_out = 0;
   if (n_slots == 0) return 0;
   unsigned* d_count = &c->d_stats.as<DevStats>()->n_list;
-  const int rc = compact_slots_async(c, n_slots, mode, out_list, d_count);
+  const int rc = compact_slots_async(c, n_slots, mode, out_list, d_count, false);
   if (rc) return rc;
   unsigned total = 0;
   AG2_HIP(c, hipMemcpyAsync(&total, d_count, 4, hipMemcpyDeviceToHost, c->stream));
@@ -160,14 +182,78 @@ __global__ void k_gather_selected(const unsigned* __restrict__ pref, const int* 
   }
 }
 
+// The same three steps for the usual few hundred to few thousand scored images in ONE launch of one
+// workgroup (five launches of ~4 us each otherwise): thread t owns kSelPer consecutive list entries,
+// so a block scan of the per-thread counts gives every selected record its position in list order.
+constexpr int kSelThreads = 1024, kSelPer = 8, kSelSmall = kSelThreads * kSelPer;
+__global__ void __launch_bounds__(kSelThreads) k_select_small(
+    const float* __restrict__ logits, const int* __restrict__ list, int n, ag2_hypothesis* __restrict__ table,
+    unsigned char* __restrict__ keep, double thr, ag2_hypothesis* __restrict__ out,
+    unsigned* __restrict__ count) {
+  __shared__ unsigned wsum[kSelThreads / kWave];
+  const int tid = threadIdx.x;
+  int slot[kSelPer];
+  unsigned sel = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kSelPer; k++) {
+    const int i = tid * kSelPer + k;
+    slot[k] = 0;
+    if (i < n) {
+      const int s = list[i];
+      const float sc = logits[2 * i + 1] - logits[2 * i];
+      table[s].score = (double)sc;
+      keep[s] = 2;
+      slot[k] = s;
+      if ((double)sc >= thr) {
+        sel |= 1u << k;
+        tot++;
+      }
+    }
+  }
+  unsigned inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = (unsigned)__shfl_up((int)inc, o, 64);
+    if (lane_id() >= o) inc += t;
+  }
+  if (lane_id() == 63) wsum[wave_id()] = inc;
+  __syncthreads();
+  unsigned woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kSelThreads / kWave; w++) {
+    if (w < wave_id()) woff += wsum[w];
+    total += wsum[w];
+  }
+  unsigned run = woff + inc - tot;
+#pragma unroll
+  for (int k = 0; k < kSelPer; k++)
+    if (sel & (1u << k)) {
+      ag2_hypothesis h = table[slot[k]];  // (the score this thread has just written included)
+      h.full_antipodal = 1;               // grasp_detector.cpp:205
+      out[run++] = h;
+    }
+  if (tid == 0) {
+    *count = total;
+    *reinterpret_cast<unsigned*>(out + n) = total;  // trailer: one copy brings records + count
+  }
+}
+
 // Leaves the selected records (score >= threshold, list order) in d_tmp and their count in *d_count.
 int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned* d_count) {
   if (n_img == 0) {
     AG2_HIP(c, hipMemsetAsync(d_count, 0, 4, c->stream));
     return 0;
   }
-  AG2_HIP(c, c->d_flags.reserve((n_img + 1) * 4));
   AG2_HIP(c, c->d_tmp.reserve(n_img * sizeof(ag2_hypothesis) + 16));  // + the count trailer
+  if (n_img <= (size_t)kSelSmall) {
+    hipLaunchKernelGGL(k_select_small, dim3(1), dim3(kSelThreads), 0, c->stream, c->d_logits.as<float>(),
+                       d_list, (int)n_img, c->d_table.as<ag2_hypothesis>(),
+                       c->d_tab_keep.as<unsigned char>(), c->p.min_score_diff,
+                       c->d_tmp.as<ag2_hypothesis>(), d_count);
+    AG2_HIP(c, hipGetLastError());
+    return 0;
+  }
+  AG2_HIP(c, c->d_flags.reserve((n_img + 1) * 4));
   unsigned* fl = c->d_flags.as<unsigned>();
   const int nb = ((int)n_img + 1 + 255) / 256;
   hipLaunchKernelGGL(k_score_flags, dim3(nb), dim3(256), 0, c->stream, c->d_logits.as<float>(), d_list,
