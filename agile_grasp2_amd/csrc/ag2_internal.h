@@ -223,9 +223,10 @@ int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n, unsigned* zeroed_ctl = nu
 // k_normals.hip
 int launch_normals(ag2_ctx* c);
 // k_sweep.hip
-int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s);
+int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
+                   bool clear_run = false);
 int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed);
-int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists);
+int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool run_cleared = false);
 // k_select.hip
 int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out);
 int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count,

@@ -30,6 +30,16 @@ int reset_stats(ag2_ctx* c) {
   return 0;
 }
 
+// fixed-slot table for the exchange step: the record of every occupied slot, zeros for the empty
+// ones (their records in d_table are stale: the table is not cleared between runs)
+__global__ void k_export_table(const uint4* __restrict__ table, const unsigned char* __restrict__ keep,
+                               int n16, uint4* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n16) return;
+  constexpr int kPer = (int)(sizeof(ag2_hypothesis) / 16);
+  dst[i] = keep[i / kPer] ? table[i] : make_uint4(0u, 0u, 0u, 0u);
+}
+
 int read_stats(ag2_ctx* c, DevStats* hs) {
   AG2_HIP(c, hipMemcpyAsync(pin_small(c), c->d_stats.p, sizeof(DevStats), hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
@@ -48,15 +58,22 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
   c->s = s;
   c->slot_base = slot_base;
   for (int attempt = 0; attempt < 6; attempt++) {
-    int rc = reset_stats(c);
+    // with index samples the kernel that fetches them also clears the slot states and the per-run
+    // statistics (two fills less)
+    const bool fused_clear = s > 0 && (sample_idx || !sample_xyz);
+    int rc = 0;
+    if (fused_clear)
+      AG2_HIP(c, c->d_tab_keep.reserve(std::max<size_t>(s * (size_t)c->p.num_orientations, 1)));
+    else
+      rc = reset_stats(c);
     if (rc) return rc;
-    rc = upload_samples(c, sample_idx, sample_xyz, s);
+    rc = upload_samples(c, sample_idx, sample_xyz, s, fused_clear);
     if (rc) return rc;
     AG2_HIP(c, stage_event(c, 0));
     rc = launch_frames(c, s, slot_base, seed);
     if (rc) return rc;
     AG2_HIP(c, stage_event(c, 1));
-    rc = launch_sweep(c, s, slot_base, emit_lists);  // records ev[2] (LDS variant) and ev[11]
+    rc = launch_sweep(c, s, slot_base, emit_lists, fused_clear);  // records ev[2] and ev[11]
     if (rc) return rc;
     if (compact_mode >= 0) {
       rc = compact_slots_async(c, s * (size_t)c->p.num_orientations, compact_mode, c->d_list2,
@@ -372,7 +389,12 @@ int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes) {
   (void)hipSetDevice(c->device);
   const size_t need = c->s * (size_t)c->p.num_orientations * sizeof(ag2_hypothesis);
   if (bytes < need) return set_err(c, AG2_ERR_CAPACITY, "export: destination too small");
-  if (need) AG2_HIP(c, hipMemcpyAsync(d_dst, c->d_table.p, need, hipMemcpyDeviceToDevice, c->stream));
+  if (need) {
+    const int n16 = (int)(need / 16);
+    hipLaunchKernelGGL(k_export_table, dim3((n16 + 255) / 256), dim3(256), 0, c->stream,
+                       c->d_table.as<uint4>(), c->d_tab_keep.as<unsigned char>(), n16, (uint4*)d_dst);
+    AG2_HIP(c, hipGetLastError());
+  }
   return 0;
 }
 

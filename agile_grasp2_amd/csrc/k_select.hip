@@ -20,7 +20,7 @@ __global__ void k_slot_flags(const ag2_hypothesis* __restrict__ table,
   unsigned f = 0;
   if (i < n_slots) {
     // state byte: 0 empty, 1 survives the prune, 2 scored, 4 pruned away
-    const bool valid = table[i].n_points > 0;
+    const bool valid = keep[i] != 0;  // (the records of empty slots are stale: never read them)
     if (mode == 0) f = valid;
     else if (mode == 1) f = valid && (keep[i] == 1 || keep[i] == 2);
     else f = valid && keep[i] == 2 && table[i].score >= thr;

@@ -28,11 +28,20 @@ constexpr int sweep_threads(int stage) { return stage == 0 ? kSweepThreads0 : kS
 // ---------------------------------------------------------------------------------------------
 // sample queries: (x, y, z, valid) per sample
 // ---------------------------------------------------------------------------------------------
+// With tab_keep the kernel also clears what a hypothesis run starts from -- the slot states of its
+// sample and (thread 0) the per-run statistics -- instead of two separate fills.
 __global__ void k_sample_queries_idx(const int* __restrict__ idx, int s,
                                      const float4* __restrict__ xyz_in, int n,
-                                     float4* __restrict__ q) {
+                                     float4* __restrict__ q, unsigned char* __restrict__ tab_keep,
+                                     int R, DevStats* __restrict__ st) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tab_keep && i == 0) {
+    unsigned* w = reinterpret_cast<unsigned*>(st);
+    for (int k = 0; k < (int)(offsetof(DevStats, bounds) / 4); k++) w[k] = 0u;
+  }
   if (i >= s) return;
+  if (tab_keep)
+    for (int k = 0; k < R; k++) tab_keep[(size_t)i * R + k] = 0;
   const int id = idx[i];
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
   if (id >= 0 && id < n) {
@@ -1328,7 +1337,9 @@ int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed) {
   return 0;
 }
 
-int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s) {
+// clear_run: the index kernel also clears tab_keep (reserved by the caller) and the per-run statistics
+int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
+                   bool clear_run) {
   AG2_HIP(c, c->d_sample_q.reserve(std::max<size_t>(s, 1) * 16));
   AG2_HIP(c, c->d_frames.reserve(std::max<size_t>(s, 1) * 12 * 8));
   AG2_HIP(c, c->d_frame_ok.reserve(std::max<size_t>(s, 1) * 4));
@@ -1337,18 +1348,21 @@ int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
   if (sample_idx || !sample_xyz) {
     const int* d_idx = c->d_samples.as<int>();  // left by ag2_subsample_uniformly
     if (sample_idx) {
-      // through page-locked staging: the copy is a real asynchronous DMA, so the host goes on
-      // enqueueing the frames / sweep kernels while k_normals is still running
-      AG2_HIP(c, c->d_tmp.reserve(s * 4));
+      // The kernel reads the indices straight from page-locked host memory (20 KB over PCIe:
+      // cheaper than a DMA operation of its own in front of the kernel); the staging area is not
+      // written again before this call has synchronised.
       const int rc = pin_reserve(c, s * 4);
       if (rc) return rc;
       __builtin_memcpy(pin_bulk(c), sample_idx, s * 4);
-      AG2_HIP(c, hipMemcpyAsync(c->d_tmp.p, pin_bulk(c), s * 4, hipMemcpyHostToDevice, c->stream));
-      d_idx = c->d_tmp.as<int>();  // consumed before d_tmp can be reused: same stream
+      void* dev_view = nullptr;
+      AG2_HIP(c, hipHostGetDevicePointer(&dev_view, pin_bulk(c), 0));
+      d_idx = (const int*)dev_view;
     }
     hipLaunchKernelGGL(k_sample_queries_idx, dim3(((unsigned)s + 255) / 256), dim3(256), 0, c->stream,
                        d_idx, (int)s, c->d_xyz_in.as<float4>(), (int)c->n,
-                       c->d_sample_q.as<float4>());
+                       c->d_sample_q.as<float4>(),
+                       clear_run ? c->d_tab_keep.as<unsigned char>() : (unsigned char*)nullptr,
+                       c->p.num_orientations, c->d_stats.as<DevStats>());
     AG2_HIP(c, hipGetLastError());
   } else {
     std::vector<float> q(s * 4);
@@ -1365,7 +1379,8 @@ int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
   return 0;
 }
 
-int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
+// run_cleared: tab_keep was cleared by k_sample_queries_idx already
+int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool run_cleared) {
   const int R = c->p.num_orientations;
   const size_t n_slots = s * (size_t)R;
   AG2_HIP(c, c->d_table.reserve(std::max<size_t>(n_slots, 1) * sizeof(ag2_hypothesis)));
@@ -1377,8 +1392,9 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists) {
     c->arena_points = (size_t)16 << 20;  // 16 Mi points = 768 MiB; grown on AG2_ERR_CAPACITY
   }
   if (emit_lists) AG2_HIP(c, c->d_arena.reserve(c->arena_points * 48));
-  AG2_HIP(c, hipMemsetAsync(c->d_table.p, 0, n_slots * sizeof(ag2_hypothesis), c->stream));
-  AG2_HIP(c, hipMemsetAsync(c->d_tab_keep.p, 0, n_slots, c->stream));
+  // (the records of empty slots are never read: every consumer goes through the slot states, and
+  // ag2_export_candidates_device writes zeros for them)
+  if (!run_cleared) AG2_HIP(c, hipMemsetAsync(c->d_tab_keep.p, 0, n_slots, c->stream));
   SweepArgs A{};
   A.pts = c->d_sorted.as<float4>();
   A.nrm = c->d_nrm.as<float4>();
