@@ -193,3 +193,34 @@ def test_images_from_points_edge_cases():
         want = o.render_image_from_points(a, b) if a.shape[1] else np.zeros((60, 60, 3), np.uint8)
         assert np.array_equal(got[k], want), k
     d.close()
+
+
+def test_export_candidates_is_the_fixed_slot_table(small_scene):
+    """ag2_export_candidates_device: occupied slots carry their record, every other slot is zero --
+    also after an earlier run left other records in the (never cleared) slot table."""
+    import ctypes as C
+    from agile_grasp2_amd import capi, sharding
+    xyz, ws, idx = small_scene
+    R = 8
+    d = capi.Detector(**scene_params(ws))
+    d.set_cloud(xyz)
+    d.compute_normals()
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    nbytes = len(idx) * R * sharding.SLOT_BYTES
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), nbytes) == 0
+    for samples, seed in ((idx, 3), (idx[::-1].copy(), 4), (idx[: len(idx) // 3], 5)):
+        recs = d.generate_hypotheses(sample_idx=samples, slot_base=0, seed=seed)
+        assert len(recs) > 3
+        nb = len(samples) * R * sharding.SLOT_BYTES
+        d.export_candidates_device(dptr.value, nb)
+        assert hip.hipDeviceSynchronize() == 0
+        got = np.zeros(len(samples) * R, dtype=capi.HYP_DTYPE)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dptr, nb, 2) == 0
+        want = sharding.table_from_records(recs, 0, len(samples), R, len(samples))
+        assert got.tobytes() == want.tobytes()
+    hip.hipFree(dptr)
+    d.close()
