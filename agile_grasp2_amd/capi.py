@@ -23,6 +23,7 @@ SYMBOLS = [
     "ag2_get_counters", "ag2_get_stage_times",
     "ag2_preprocess_cloud", "ag2_preprocess_cloud_device", "ag2_get_cloud", "ag2_subsample_uniformly",
     "ag2_find_clusters", "ag2_set_min_inliers", "ag2_set_grid_origin", "ag2_set_stage_timing",
+    "ag2_export_candidates_compact_device",
 ]
 
 
@@ -343,6 +344,10 @@ class Detector:
 
     def export_candidates_device(self, dptr: int, nbytes: int):
         self._ck(self.L.ag2_export_candidates_device(self.h, C.c_void_p(dptr), C.c_size_t(nbytes)))
+
+    def export_candidates_compact_device(self, dptr: int, nbytes: int, cap_records: int):
+        self._ck(self.L.ag2_export_candidates_compact_device(self.h, C.c_void_p(dptr), C.c_size_t(nbytes),
+                                                             C.c_size_t(cap_records)))
 
     def counters(self) -> Counters:
         c = Counters()

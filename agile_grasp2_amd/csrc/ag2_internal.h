@@ -102,6 +102,7 @@ struct ag2_ctx {
   ag2::DevBuf d_key;       // int2 per original point: cell key (-1 invalid), arrival rank in the cell
   ag2::DevBuf d_bounds;    // per-workgroup extent partials of k_bounds (8 ints each)
   ag2::DevBuf d_gpos;      // sweep stage 0: per-workgroup position lists that exceed its LDS
+  ag2::DevBuf d_export_list;  // occupied slots, for ag2_export_candidates_compact_device
   int bounds_blocks = 0;   // > 0: the fused pack left that many partials for build_grid
   ag2::DevBuf d_cell;      // uint32 cell_start[ncells+1]
   ag2::DevBuf d_perm;      // int32 sorted position -> original index
@@ -234,6 +235,7 @@ int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, 
 int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned* d_count);
 int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypothesis>& recs,
                    std::vector<int64_t>* offs, std::vector<uint8_t>* keep);
+int export_candidates_compact(ag2_ctx* c, void* d_dst, size_t cap_records);
 int make_image_descs(ag2_ctx* c, const int* d_list, size_t n);
 // k_lenet_x3.hip
 int lenet_pack_weights_x3(ag2_ctx* c, const float* conv1_w, const float* conv2_w);

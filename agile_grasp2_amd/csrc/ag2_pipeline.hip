@@ -398,4 +398,13 @@ int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes) {
   return 0;
 }
 
+int ag2_export_candidates_compact_device(ag2_ctx* c, void* d_dst, size_t bytes, size_t cap_records) {
+  if (!c || !d_dst) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (cap_records > ((size_t)1 << 30)) return set_err(c, AG2_ERR_ARG, "export: cap too large");
+  if (bytes < 16 + cap_records * sizeof(ag2_hypothesis))
+    return set_err(c, AG2_ERR_CAPACITY, "export: destination too small");
+  return export_candidates_compact(c, d_dst, cap_records);
+}
+
 }  // extern "C"

@@ -326,6 +326,34 @@ int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypo
   return 0;
 }
 
+// ---- compact form of the candidate table for the exchange step -------------------------------
+// header (16 B): {count, cap, 0, 0}; then min(count, cap) records in slot order.  One thread per 16
+// bytes; the count is read on the device (written by the compaction just before).
+__global__ void k_export_compact(const uint4* __restrict__ table, const int* __restrict__ list,
+                                 unsigned cap, uint4* __restrict__ dst) {
+  constexpr unsigned kPer = (unsigned)(sizeof(ag2_hypothesis) / 16);
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned count = reinterpret_cast<const unsigned*>(dst)[0];
+  const unsigned n = count < cap ? count : cap;
+  if (i == 0) reinterpret_cast<unsigned*>(dst)[1] = cap;  // (words 2, 3 cleared by the caller)
+  const unsigned r = i / kPer, k = i % kPer;
+  if (r < n) dst[1 + i] = table[(size_t)list[r] * kPer + k];
+}
+
+int export_candidates_compact(ag2_ctx* c, void* d_dst, size_t cap_records) {
+  const size_t n_slots = c->s * (size_t)c->p.num_orientations;
+  AG2_HIP(c, hipMemsetAsync(d_dst, 0, 16, c->stream));
+  if (n_slots == 0 || cap_records == 0) return 0;
+  // every hypothesis (slot state != 0), slot order; the count lands in the header's first word
+  const int rc = compact_slots_async(c, n_slots, 0, c->d_export_list, (unsigned*)d_dst);
+  if (rc) return rc;
+  const size_t threads = cap_records * (sizeof(ag2_hypothesis) / 16);
+  hipLaunchKernelGGL(k_export_compact, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
+                     c->d_table.as<uint4>(), c->d_export_list.as<int>(), (unsigned)cap_records, (uint4*)d_dst);
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
 int make_image_descs(ag2_ctx* c, const int* d_list, size_t n) {
   AG2_HIP(c, c->d_desc.reserve(std::max<size_t>(n, 1) * 12));
   if (n == 0) return 0;

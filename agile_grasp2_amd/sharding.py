@@ -118,3 +118,41 @@ def tile_points(xyz: np.ndarray, ordered_sample_idx: np.ndarray, rank: int, worl
     local = np.searchsorted(keep, mine).astype(np.int32)
     assert (keep[local] == mine).all()
     return keep, local, b
+
+
+# ---- compact exchange: only the occupied slots travel -----------------------------------------
+#
+# The fixed-slot table is mostly empty (cfg2: 2 400 of 40 000 slots), so a rank puts a 16-byte header
+# {count, cap, 0, 0} and its min(count, cap) records in slot order on the wire
+# (ag2_export_candidates_compact_device).  Records carry (sample_slot, orientation): the rank-order
+# concatenation is the reference's output order, exactly compact_table() of the gathered full tables.
+
+COMPACT_HEADER = 16
+
+
+def compact_bytes(cap_records: int) -> int:
+    return COMPACT_HEADER + cap_records * SLOT_BYTES
+
+
+def pack_compact(records: np.ndarray, cap_records: int) -> np.ndarray:
+    """Host twin of ag2_export_candidates_compact_device (records already in slot order)."""
+    buf = np.zeros(compact_bytes(cap_records), dtype=np.uint8)
+    buf[:8].view(np.uint32)[:] = (len(records), cap_records)
+    n = min(len(records), cap_records)
+    if n:
+        buf[COMPACT_HEADER:COMPACT_HEADER + n * SLOT_BYTES] = records[:n].view(np.uint8).reshape(-1)
+    return buf
+
+
+def unpack_compact(gathered_u8: np.ndarray, world: int, cap_records: int, dtype):
+    """(records of all ranks in rank order, truncated?) from the gathered compact buffers."""
+    per = compact_bytes(cap_records)
+    g = np.asarray(gathered_u8, dtype=np.uint8).reshape(world, per)
+    parts, cut = [], False
+    for r in range(world):
+        count, cap = (int(v) for v in g[r, :8].view(np.uint32))
+        assert cap == cap_records
+        cut = cut or count > cap
+        n = min(count, cap)
+        parts.append(g[r, COMPACT_HEADER:COMPACT_HEADER + n * SLOT_BYTES].copy().view(dtype))
+    return (np.concatenate(parts) if parts else np.zeros(0, dtype)), cut

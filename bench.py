@@ -174,8 +174,16 @@ def main():
     d.set_grid_origin(origin)
     xyz_dev = torch.from_numpy(xyz).cuda()          # HBM-resident input (this rank's tile when N > 1)
     torch.cuda.synchronize()
-    slot_bytes = S * R * sharding.SLOT_BYTES
-    local_tab = torch.empty(slot_bytes, dtype=torch.uint8, device="cuda") if dist_on else None
+    # exchange buffer: the candidates in compact form (header + occupied slots, sharding.py); its
+    # capacity is fixed after the warm-up from the largest list any rank produced
+    xch = {"cap": S * R, "buf": None}
+
+    def size_exchange(cap):
+        xch["cap"] = int(cap)
+        xch["buf"] = torch.empty(sharding.compact_bytes(xch["cap"]), dtype=torch.uint8, device="cuda")
+
+    if dist_on:
+        size_exchange(S * R)
 
     acc = {}
 
@@ -185,9 +193,9 @@ def main():
         sel, n_scored = d.detect(sample_idx=idx, slot_base=slot_base, seed=args.seed, do_prune=True,
                                  want_all=False)
         if dist_on:
-            # the path's one exchange step: fixed-slot candidate tables, RCCL all-gather over xGMI
-            d.export_candidates_device(local_tab.data_ptr(), slot_bytes)
-            sharding.all_gather_tables(local_tab, world)
+            # the path's one exchange step: candidates of every rank, RCCL all-gather over xGMI
+            d.export_candidates_compact_device(xch["buf"].data_ptr(), xch["buf"].numel(), xch["cap"])
+            xch["out"] = sharding.all_gather_tables(xch["buf"], world)
         return n_scored
 
     def sync():
@@ -199,7 +207,13 @@ def main():
     # stage event costs a few microseconds of stream serialisation, all of them about 3 % of a step.
     # The other stages' durations come from an extra, untimed pass below.
     d.set_stage_timing(1)
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup) if dist_on else args.warmup):
+        step()
+    if dist_on:
+        # every rank sizes the exchange for twice the largest candidate list seen (same on all ranks)
+        nh = torch.tensor([float(d.counters().n_hypotheses)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nh, op=dist.ReduceOp.MAX)
+        size_exchange(min(S * R, max(1024, 2 * int(nh.item()))))
         step()
     sync()
     t0 = time.perf_counter()
@@ -213,6 +227,10 @@ def main():
     elapsed = time.perf_counter() - t0
     c = d.counters()
 
+    if dist_on:  # no rank's list may have been cut (the headers say): else the bench line is void
+        hdr = xch["out"].view(world, -1)[:, :8].cpu().numpy().view(np.uint32)
+        if (hdr[:, 0] > hdr[:, 1]).any():
+            raise SystemExit(f"exchange capacity {xch['cap']} too small: {hdr[:, 0].tolist()}")
     tt = torch.tensor([elapsed, float(scored), float(c.n_hypotheses)], dtype=torch.float64, device="cuda")
     if dist_on:
         tmax = tt.clone()
@@ -338,8 +356,8 @@ def main():
             "parallelism": ("single GPU" if not dist_on else
                             f"{world} spatial tiles along the cloud's longest axis (interval of the rank's {S} "
                             f"samples + 0.11 m halo, "
-                            f"{tile_note}), one RCCL all-gather of the {S * R}-slot x 176 B candidate "
-                            f"table per rank"),
+                            f"{tile_note}), one RCCL all-gather of the candidates in compact form "
+                            f"(16 B header + up to {xch['cap']} records x 176 B per rank)"),
         },
         "stage_ms": {k: round(v, 4) for k, v in ms.items()},
         "stage_ms_note": ("sweep_ms and sweep_overflow_ms: HIP events inside the timed region; the other stages: "

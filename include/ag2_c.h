@@ -173,6 +173,14 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
  * (i * R + orientation), n_points == 0 where empty, score filled where scored.  Copied
  * device-to-device into d_dst (e.g. a torch tensor) for the RCCL all-gather. */
 int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes);
+/* The same candidates in compact form (what a multi-GPU job should put on the wire: the table is
+ * mostly empty): a 16-byte header {uint32 count, uint32 cap_records, 0, 0} followed by
+ * min(count, cap_records) records in slot order -- the occupied slots of the table above, so the
+ * rank-order concatenation of all ranks' records is the reference's output order
+ * (hand_search.cpp:223-228).  count > cap_records tells the receiver the list was cut: exchange the
+ * full table instead.  bytes >= 16 + cap_records * sizeof(ag2_hypothesis); asynchronous on the
+ * context's stream. */
+int ag2_export_candidates_compact_device(ag2_ctx* c, void* d_dst, size_t bytes, size_t cap_records);
 /* Spatial tiles (multi-GPU, for clouds too large to replicate): origin of the search grid -- and the
  * cloud minimum the prune test uses (pcl::getMinMax3D, grasp_detector.cpp:152-153) -- for the clouds
  * set afterwards; NULL = automatic (per-axis minimum of the cloud).  A rank that holds only a tile

@@ -222,5 +222,17 @@ def test_export_candidates_is_the_fixed_slot_table(small_scene):
         assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dptr, nb, 2) == 0
         want = sharding.table_from_records(recs, 0, len(samples), R, len(samples))
         assert got.tobytes() == want.tobytes()
+        # compact form: header + the occupied slots in slot order; a cap below the count cuts the list
+        for cap in (len(recs) + 5, max(1, len(recs) // 2)):
+            cb = sharding.compact_bytes(cap)
+            assert cb <= nbytes
+            d.export_candidates_compact_device(dptr.value, cb, cap)
+            assert hip.hipDeviceSynchronize() == 0
+            raw = np.zeros(cb, dtype=np.uint8)
+            assert hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), dptr, cb, 2) == 0
+            used = sharding.COMPACT_HEADER + min(cap, len(recs)) * sharding.SLOT_BYTES  # the rest is not written
+            assert raw[:used].tobytes() == sharding.pack_compact(recs, cap)[:used].tobytes()
+            out, cut = sharding.unpack_compact(raw, 1, cap, capi.HYP_DTYPE)
+            assert cut == (cap < len(recs)) and out.tobytes() == recs[:cap].tobytes()
     hip.hipFree(dptr)
     d.close()

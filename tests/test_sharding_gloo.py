@@ -58,6 +58,16 @@ def _worker(rank, world, port, q, tiles=False):
     local = torch.from_numpy(tab.view(np.uint8).copy())
     gathered = sharding.all_gather_tables(local, world).numpy().view(api.HYP_DTYPE)
     merged = sharding.compact_table(gathered)
+    # the compact exchange (only occupied slots on the wire) must deliver the same records
+    cap = 64
+    while True:
+        local_c = torch.from_numpy(sharding.pack_compact(sharding.compact_table(tab), cap))
+        got, cut = sharding.unpack_compact(sharding.all_gather_tables(local_c, world).numpy(), world, cap,
+                                           api.HYP_DTYPE)
+        if not cut:
+            break
+        cap *= 4        # a rank's list was cut: every rank sees it in the headers and retries
+    assert got.tobytes() == merged.tobytes()
     if rank == 0:
         q.put(merged.tobytes())
     dist.barrier()
