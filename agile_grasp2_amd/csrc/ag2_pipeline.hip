@@ -332,10 +332,11 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   }
   AG2_HIP(c, stage_event(c, 7));
   std::vector<ag2_hypothesis> anti;
+  const ag2_hypothesis* recs = nullptr;  // the selected records, in list order
+  unsigned n_anti = 0;
   {
     // The records are followed by their count (trailer written by the gather / cluster kernel), so
     // for the usual small lists ONE copy into page-locked memory brings both.
-    unsigned n_anti = 0;
     const size_t rec_bytes = n_img * sizeof(ag2_hypothesis);
     const bool small = rec_bytes <= ((size_t)2 << 20);
     if (small && n_img) {
@@ -344,8 +345,7 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
       AG2_HIP(c, hipMemcpyAsync(pin_bulk(c), d_res, rec_bytes + 4, hipMemcpyDeviceToHost, c->stream));
       AG2_HIP(c, hipStreamSynchronize(c->stream));
       memcpy(&n_anti, pin_bulk(c) + rec_bytes, 4);
-      anti.resize(n_anti);
-      if (n_anti) memcpy(anti.data(), pin_bulk(c), (size_t)n_anti * sizeof(ag2_hypothesis));
+      recs = (const ag2_hypothesis*)pin_bulk(c);  // (nothing below writes the staging area)
     } else {
       AG2_HIP(c, hipMemcpyAsync(pin_small(c), d_nres, 4, hipMemcpyDeviceToHost, c->stream));
       AG2_HIP(c, hipStreamSynchronize(c->stream));
@@ -354,13 +354,21 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
       if (n_anti)
         AG2_HIP(c, hipMemcpy(anti.data(), d_res, (size_t)n_anti * sizeof(ag2_hypothesis),
                              hipMemcpyDeviceToHost));
+      recs = anti.data();
     }
   }
-  // 5. top num_selected by score, descending (grasp_detector.cpp:239-252); ties by position
-  std::stable_sort(anti.begin(), anti.end(),
-                   [](const ag2_hypothesis& a, const ag2_hypothesis& b) { return a.score > b.score; });
-  size_t k = anti.size();
+  // 5. top num_selected by score, descending (grasp_detector.cpp:239-252); ties by position.  Only
+  // the order of the first k is needed: indices are (partially) sorted, the 176-byte records are
+  // copied once.
+  size_t k = n_anti;
   if (c->p.num_selected >= 0 && k > (size_t)c->p.num_selected) k = (size_t)c->p.num_selected;
+  std::vector<uint32_t> order(n_anti);
+  for (uint32_t i = 0; i < n_anti; i++) order[i] = i;
+  const auto better = [recs](uint32_t a, uint32_t b) {
+    return recs[a].score > recs[b].score || (recs[a].score == recs[b].score && a < b);
+  };
+  if (k < n_anti) std::partial_sort(order.begin(), order.begin() + k, order.end(), better);
+  else std::sort(order.begin(), order.end(), better);
   *n_selected = k;
   c->cnt.n_scored = (int64_t)n_img;
   c->cnt.n_selected = (int64_t)k;
@@ -380,7 +388,7 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   stage_elapsed(c, &c->times.select_ms, 6, 7);
   stage_elapsed(c, &c->times.total_ms, 8, 7);
   if (k > cap) return set_err(c, AG2_ERR_CAPACITY, "detect: output capacity too small");
-  if (k) memcpy(selected, anti.data(), k * sizeof(ag2_hypothesis));
+  for (size_t i = 0; i < k; i++) selected[i] = recs[order[i]];
   return 0;
 }
 
