@@ -8,7 +8,7 @@
 // k_render_sparse (P <= 1024, the usual case: P ~ 250 << 3600 cells): every point finds, among the
 // earlier points, how many share its cell (its rank) and the first that does (the cell's leader).
 // Round r then adds the normals of all rank-r points to their leader's accumulator -- distinct
-// cells within a round, list order across rounds -- and only the leaders quantise a pixel.  43 KB of
+// cells within a round, list order across rounds -- and only the leaders quantise a pixel.  40 KB of
 // LDS: three workgroups per CU.
 // k_render_sorted (1024 < P <= 16384): cell-major sort of the points in LDS, then one run per cell.
 // k_render (any P): every cell is owned by one thread (cell % 256) which adds the normals of its
@@ -190,8 +190,6 @@ struct SparseShared {
   double acc[kSparseMax * 3];     // per leader point; the staged output image aliases it afterwards
   unsigned pix[kCells];
   short cid[kSparseMax];
-  short lead[kSparseMax];
-  unsigned char rank[kSparseMax];
   double red[kImgThreads / kWave];
   int max_rank;
 };

@@ -179,7 +179,7 @@ def test_images_from_points_edge_cases():
     # normal sums) and the first size the dense renderer takes
     # ... the sorted renderer's two ranges (1025..4096 and ..16384, keys padded to a power of two)
     # and the first size beyond them
-    for npts in (1024, 1025, 7, 64, 257, 2047, 2048, 2049, 3000, 4096, 4097, 9000, 16384, 16385):
+    for npts in (1023, 1024, 1025, 7, 64, 257, 2047, 2048, 2049, 3000, 4096, 4097, 9000, 16384, 16385):
         u3 = rng.uniform(0.2, 0.8, size=(3, npts))
         u3[:2, : npts // 2] = np.round(u3[:2, : npts // 2] * 6) / 6.0
         n3 = rng.normal(size=(3, npts))
