@@ -127,6 +127,12 @@ def main():
         sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 control flow on a box with ONE GPU (RCCL refuses two ranks on one
+    # device): AG2_BENCH_REHEARSAL=1 puts every rank on GPU 0 and runs the collectives over gloo with
+    # the buffers staged through host memory.  Timings of such a run mean nothing.
+    rehearsal = os.environ.get("AG2_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     # Exactly ONE line goes to stdout (the JSON, rank 0).  Libraries print banners there (RCCL's
     # version block, for one), so fd 1 points at stderr until the result is ready.
     sys.stdout.flush()
@@ -146,8 +152,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29518")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if rehearsal else "cuda"   # where tensors handed to collectives live
 
     n_points, S, R, voxelised, kind = CONFIGS[args.config]
     xyz, ws = scene.make_scene(args.seed, n_points, kind=kind, voxel=scene.VOXEL if voxelised else None)
@@ -187,15 +197,19 @@ def main():
 
     acc = {}
 
-    def step():
+    def local_step():  # this rank's part of a step: no collective
         d.set_cloud_device(xyz_dev.data_ptr(), xyz.shape[0], 12)
         d.compute_normals()
         sel, n_scored = d.detect(sample_idx=idx, slot_base=slot_base, seed=args.seed, do_prune=True,
                                  want_all=False)
+        return n_scored
+
+    def step():
+        n_scored = local_step()
         if dist_on:
             # the path's one exchange step: candidates of every rank, RCCL all-gather over xGMI
             d.export_candidates_compact_device(xch["buf"].data_ptr(), xch["buf"].numel(), xch["cap"])
-            xch["out"] = sharding.all_gather_tables(xch["buf"], world)
+            xch["out"] = sharding.all_gather_tables(xch["buf"].cpu() if rehearsal else xch["buf"], world)
         return n_scored
 
     def sync():
@@ -211,7 +225,7 @@ def main():
         step()
     if dist_on:
         # every rank sizes the exchange for twice the largest candidate list seen (same on all ranks)
-        nh = torch.tensor([float(d.counters().n_hypotheses)], dtype=torch.float64, device="cuda")
+        nh = torch.tensor([float(d.counters().n_hypotheses)], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(nh, op=dist.ReduceOp.MAX)
         size_exchange(min(S * R, max(1024, 2 * int(nh.item()))))
         step()
@@ -231,7 +245,7 @@ def main():
         hdr = xch["out"].view(world, -1)[:, :8].cpu().numpy().view(np.uint32)
         if (hdr[:, 0] > hdr[:, 1]).any():
             raise SystemExit(f"exchange capacity {xch['cap']} too small: {hdr[:, 0].tolist()}")
-    tt = torch.tensor([elapsed, float(scored), float(c.n_hypotheses)], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([elapsed, float(scored), float(c.n_hypotheses)], dtype=torch.float64, device=coll_dev)
     if dist_on:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -261,7 +275,7 @@ def main():
     d.set_stage_timing(2)
     K2, acc2 = max(3, min(K, 10)), {}
     for _ in range(K2):
-        step()
+        local_step()  # (rank 0 alone by now: no collective here)
         t = d.times()
         for name, _ty in t._fields_:
             acc2[name] = acc2.get(name, 0.0) + getattr(t, name)
