@@ -94,16 +94,34 @@ __global__ void __launch_bounds__(256) k_bounds(const char* __restrict__ src, si
 __global__ void k_cell_count(const float4* __restrict__ xyz, int n, GridDesc g,
                              int2* __restrict__ key, unsigned* __restrict__ cell) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = xyz[i];
+  const float4 p = (i < n) ? xyz[i] : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
   int k = -1, r = 0;
-  if (finite3(p.x, p.y, p.z)) {
+  if (i < n && finite3(p.x, p.y, p.z)) {
     const int cx = cell_of(p.x, g.o[0], g.inv), cy = cell_of(p.y, g.o[1], g.inv),
               cz = cell_of(p.z, g.o[2], g.inv);
     k = (cz * g.dims[1] + cy) * g.dims[0] + cx;
-    r = (int)atomicAdd(&cell[k], 1u);
   }
-  key[i] = make_int2(k, r);
+  // Consecutive points of a sensor cloud fall into a handful of cells, so the 64 lanes of a wave
+  // would queue up on the same few counters: the lanes that share a cell send ONE atomic (their
+  // count) and split the range it returns among themselves by lane order.
+  // (a wave whose points are scattered over many cells falls back to one atomic per lane after a
+  // few rounds)
+  unsigned long long todo = __ballot(k >= 0);
+  for (int round = 0; todo && round < 8; round++) {
+    const int lead = __ffsll((long long)todo) - 1;
+    const int k0 = __builtin_amdgcn_readlane(k, lead);
+    const unsigned long long same = __ballot(k == k0) & todo;
+    unsigned base = 0;
+    if (lane_id() == lead) base = atomicAdd(&cell[k0], (unsigned)__popcll(same));
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, lead);
+    if (k == k0) {
+      const unsigned long long below = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
+      r = (int)(base + (unsigned)__popcll(same & below));
+    }
+    todo &= ~same;
+  }
+  if ((todo >> lane_id()) & 1ull) r = (int)atomicAdd(&cell[k], 1u);
+  if (i < n) key[i] = make_int2(k, r);
 }
 
 // ---- exclusive scan of uint32, one pass (2048 elements per tile) ---------------------------------
