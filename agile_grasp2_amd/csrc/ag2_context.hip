@@ -118,7 +118,8 @@ int collect_normals_stats(ag2_ctx* c) {
 int pin_reserve(ag2_ctx* c, size_t bulk_bytes) {
   const size_t need = kPinSmall + bulk_bytes;
   if (need <= c->h_pin_bytes) return 0;
-  if (c->stream) AG2_HIP(c, hipStreamSynchronize(c->stream));  // nothing may still be copying
+  // (unconditional: a NULL handle is the HIP default stream, a supported setting -- ag2_set_stream)
+  AG2_HIP(c, hipStreamSynchronize(c->stream));  // nothing may still be copying
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   c->h_pin = nullptr;
   c->h_pin_bytes = 0;
@@ -196,6 +197,7 @@ ag2_ctx* ag2_create(const ag2_params* p, int device_id) {
   ag2_ctx* c = new ag2_ctx();
   c->p = *p;
   c->device = device_id;
+  if (p->debug_flags & 2) c->sweep_gcap = 1024;  // test knob: forces the scratch-resize path on small clouds
   if (check_params(c) != 0) {
     fprintf(stderr, "ag2_create: %s\n", c->err.c_str());
     delete c;
@@ -221,7 +223,7 @@ ag2_ctx* ag2_create(const ag2_params* p, int device_id) {
 void ag2_destroy(ag2_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream);  // NULL = the default stream: still to be waited for
   DevBuf* bufs[] = {&c->d_xyz_in, &c->d_key, &c->d_bounds, &c->d_gpos, &c->d_export_list, &c->d_cell, &c->d_perm, &c->d_sorted,
                     &c->d_nrm, &c->d_scan, &c->d_stats, &c->d_hc, &c->d_sample_q, &c->d_frames,
                     &c->d_frame_ok, &c->d_table, &c->d_tab_off, &c->d_tab_keep, &c->d_arena,
@@ -244,7 +246,7 @@ const char* ag2_last_error(const ag2_ctx* c) { return c ? c->err.c_str() : "null
 int ag2_set_stream(ag2_ctx* c, void* hip_stream) {
   if (!c) return AG2_ERR_ARG;
   (void)hipSetDevice(c->device);
-  if (c->stream) AG2_HIP(c, hipStreamSynchronize(c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   c->own_stream = false;
   c->stream = (hipStream_t)hip_stream;  // NULL = the HIP default (null) stream, torch's default
@@ -372,7 +374,7 @@ int ag2_set_stage_timing(ag2_ctx* c, int level) {
   if (!c) return AG2_ERR_ARG;
   if (level < 0 || level > 2) return set_err(c, AG2_ERR_ARG, "stage timing level must be 0, 1 or 2");
   (void)hipSetDevice(c->device);
-  if (c->stream) AG2_HIP(c, hipStreamSynchronize(c->stream));  // no half-recorded pairs
+  AG2_HIP(c, hipStreamSynchronize(c->stream));  // no half-recorded pairs
   c->stage_timing = level;
   memset(&c->times, 0, sizeof(c->times));
   c->grid_pending = false;  // (its events may not exist at the new level)

@@ -45,6 +45,8 @@ struct DevStats {
   unsigned int n_clu;                // selected hypotheses that survive the clustering
   unsigned int max_p;                // largest in-box list of the run (picks the image renderers)
   unsigned int work_next[3];         // k_sweep work queues, one per stage (items beyond the first grid)
+  unsigned int max_k_over;           // longest cropped list that did not fit the sweep's global scratch
+  unsigned int pad0[3];
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
   unsigned int pad1;
@@ -143,6 +145,8 @@ struct ag2_ctx {
   size_t arena_points = 0;
   ag2::DevBuf d_overflow;  // int sample ids that need the global-memory sweep
   ag2::DevBuf d_gscratch;  // global cropped-list scratch for the overflow path
+  int sweep_gcap = 1 << 16;  // points per workgroup of that scratch; grows to the longest list met
+  int sweep_g2 = 1024;       // workgroups of the stage that uses it
   ag2::DevBuf d_list;      // int compacted slot ids (hypotheses in order)
   ag2::DevBuf d_list2;     // int compacted slot ids after prune / for scoring
   ag2::DevBuf d_images;    // uint8 n_img x 10800 (HWC)

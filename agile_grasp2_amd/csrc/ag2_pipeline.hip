@@ -83,9 +83,27 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     DevStats hs;
     rc = read_stats(c, &hs);
     if (rc) return rc;
-    if (hs.err_flags & 8u)
-      return set_err(c, AG2_ERR_CAPACITY,
-                     "a cropped neighbourhood exceeds the global sweep scratch (65536 points)");
+    if (hs.err_flags & 8u) {
+      // A cropped neighbourhood is longer than the sweep's global scratch: size the scratch to the
+      // longest list of this run and repeat the run.  The reference crops into a list of any
+      // length (hand_search.cpp:329-349); the only limit here is device memory.
+      const size_t need = (((size_t)hs.max_k_over + 1023) / 1024) * 1024;
+      if (need > (size_t)0x7fffffff - 1024)
+        return set_err(c, AG2_ERR_CAPACITY, "a cropped neighbourhood exceeds 2^31 points");
+      size_t free_b = 0, total_b = 0;
+      AG2_HIP(c, hipMemGetInfo(&free_b, &total_b));
+      // memory the resized scratch may take: what is free now plus what the old scratch returns
+      const size_t budget = std::min<size_t>((free_b + c->d_gscratch.bytes) / 2, (size_t)64 << 30);
+      const size_t per_wg = need * 5 * 4;
+      const size_t g2 = std::min<size_t>(1024, budget / (per_wg + per_wg / 4 + 1));
+      if (g2 < 1)
+        return set_err(c, AG2_ERR_CAPACITY,
+                       "a cropped neighbourhood of " + std::to_string(hs.max_k_over) +
+                           " points does not fit the device memory left for the sweep scratch");
+      c->sweep_gcap = (int)need;
+      c->sweep_g2 = (int)g2;
+      continue;
+    }
     if (hs.err_flags & 1u) {  // arena too small: grow to what this run asked for, retry
       c->arena_points = std::max<size_t>((size_t)hs.arena_top + ((size_t)hs.arena_top >> 3), c->arena_points * 2);
       continue;

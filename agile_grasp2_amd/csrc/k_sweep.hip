@@ -392,8 +392,11 @@ struct SweepShared {
   int row_start[kMaxRows];       // per stencil row (cy, cz): first sorted position, length
   int row_len[kMaxRows];
   int piece_start[kMaxPieces];   // rows cut into pieces of <= PL points
-  unsigned piece_lc[kMaxPieces]; // low 16 bits: length; high 16: survivor count, then offset
-  unsigned piece_mask[kMaxPieces]; // stage 0: which points of the piece survive the crop (pieces <= 32)
+  // Stage 0 (pieces <= 32 points, lists <= kGposCap): piece_lc = length (low 16 bits) | survivor
+  // count, then list offset (high 16); piece_mask = which points of the piece survive the crop.
+  // Stage 1 (no bound on either): piece_lc = length, piece_mask = survivor count, then list offset.
+  unsigned piece_lc[kMaxPieces];
+  unsigned piece_mask[kMaxPieces];
   double fs[20], fsr[20];        // finger-slot table (exact path of pass A, deepen)
   double depths[kMaxDepths];
   double cosd[kMaxOrient], sind[kMaxOrient];    // hand angles, f64 (exact path)
@@ -708,7 +711,7 @@ k_sweep(SweepArgs A) {
         const int pc = kGpw * (pp0 + u * NW) + grp;
         const bool ok = pc < n_pieces;
         pb[u] = ok ? S.piece_start[pc] : 0;
-        pl[u] = ok ? (int)(S.piece_lc[pc] & 0xFFFFu) : 0;
+        pl[u] = ok ? (int)(LITE ? (S.piece_lc[pc] & 0xFFFFu) : S.piece_lc[pc]) : 0;
         pv[u] = make_float4(0, 0, 0, 0);
         if (lg < pl[u]) pv[u] = A.pts[pb[u] + lg];
       }
@@ -730,8 +733,12 @@ k_sweep(SweepArgs A) {
           my_k2 += (cls != 0) ? 1 : 0;
         }
         if (lg == 0 && pc < n_pieces) {
-          S.piece_lc[pc] = (unsigned)pl[u] | ((unsigned)keep << 16);
-          if (LITE) S.piece_mask[pc] = pm;
+          if (LITE) {
+            S.piece_lc[pc] = (unsigned)pl[u] | ((unsigned)keep << 16);
+            S.piece_mask[pc] = pm;
+          } else {
+            S.piece_mask[pc] = (unsigned)keep;
+          }
         }
       }
     }
@@ -746,7 +753,7 @@ k_sweep(SweepArgs A) {
 #pragma unroll
       for (int k = 0; k < kPiecesPerThread; k++) {
         const int pc = tid * kPiecesPerThread + k;
-        c[k] = (pc < n_pieces) ? (int)(S.piece_lc[pc] >> 16) : 0;
+        c[k] = (pc < n_pieces) ? (int)(LITE ? (S.piece_lc[pc] >> 16) : S.piece_mask[pc]) : 0;
         tot += c[k];
       }
       int inc = tot;
@@ -764,12 +771,15 @@ k_sweep(SweepArgs A) {
         K += S.wave_cnt[k];
         k2 += S.red.i[0][k][0];
       }
-      if (K <= CAP) {  // offsets fit 16 bits: CAP <= 65536 and an offset is < K
+      if (K <= CAP) {  // (stage 0: offsets fit 16 bits, kGposCap <= 65536 and an offset is < K)
         int run = woff + inc - tot;
 #pragma unroll
         for (int k = 0; k < kPiecesPerThread; k++) {
           const int pc = tid * kPiecesPerThread + k;
-          if (pc < n_pieces) S.piece_lc[pc] = (S.piece_lc[pc] & 0xFFFFu) | ((unsigned)run << 16);
+          if (pc < n_pieces) {
+            if (LITE) S.piece_lc[pc] = (S.piece_lc[pc] & 0xFFFFu) | ((unsigned)run << 16);
+            else S.piece_mask[pc] = (unsigned)run;
+          }
           run += c[k];
         }
       }
@@ -782,6 +792,10 @@ k_sweep(SweepArgs A) {
           const unsigned at = atomicAdd(&A.st->n_overflow, 1u);
           A.overflow[at] = t;
         } else {
+          // Longer than this launch's scratch: the host sizes the scratch to the longest list of the
+          // run and repeats it (run_hypotheses) -- hand_search.cpp:329-349 crops into a list of any
+          // length, so no list length is an error.
+          atomicMax(&A.st->max_k_over, (unsigned)K);
           atomicOr(&A.st->err_flags, 8u);
         }
       }
@@ -819,10 +833,9 @@ k_sweep(SweepArgs A) {
       for (int u = 0; u < 4; u++) {
         const int pc = kGpw * (pp0 + u * NW) + grp;
         const bool ok = pc < n_pieces;
-        const unsigned lc = ok ? S.piece_lc[pc] : 0u;
         pb[u] = ok ? S.piece_start[pc] : 0;
-        pl[u] = (int)(lc & 0xFFFFu);
-        po[u] = (int)(lc >> 16);
+        pl[u] = ok ? (int)S.piece_lc[pc] : 0;
+        po[u] = ok ? (int)S.piece_mask[pc] : 0;
         pv[u] = make_float4(0, 0, 0, 0);
         if (lg < pl[u]) pv[u] = A.pts[pb[u] + lg];
       }
@@ -1445,8 +1458,10 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   // Samples whose cropped list exceeds stage 0 were queued on the device; the second stage is always
   // launched and reads the queue length itself (st->n_overflow), so no host round trip sits between
   // the launches.
-  const int gcap = 1 << 16, g2 = 1024;  // four workgroups per CU x 5 x 64 Ki words = 1.3 GB of scratch
-  AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 5 * gcap * 4));
+  // (default: four workgroups per CU x 5 x 64 Ki words = 1.3 GB of scratch; run_hypotheses resizes
+  // it when a list of the run is longer)
+  const int gcap = c->sweep_gcap, g2 = c->sweep_g2;
+  AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 5 * (size_t)gcap * 4));
   A.gscratch = c->d_gscratch.as<float>();
   A.gcap = gcap;
   hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads1), sweep_lds_bytes(1), c->stream, A);

@@ -145,17 +145,41 @@ def test_config1_scene_500_samples():
     d.close()
 
 
-def test_dense_unvoxelised_cloud_overflow_path():
+@pytest.mark.parametrize("debug_flags", [0, 2])
+def test_dense_unvoxelised_cloud_overflow_path(debug_flags):
     """Un-voxelised dense clutter (config 3 style): cropped neighbourhoods exceed the LDS stage,
-    so the global-scratch instantiation of the sweep must give the same answers."""
+    so the global-scratch instantiation of the sweep must give the same answers.  debug_flags=2
+    starts that scratch at 1 024 points per workgroup: every list of the stage is then too long for
+    it and the run is repeated with the scratch sized to the longest list."""
     xyz, ws = scene.make_scene(seed=4, n_target=120000, kind="objects", voxel=None)
     idx = scene.draw_samples(4, xyz.shape[0], 60)
-    o, d = make_pair(xyz, ws, num_orientations=16)
+    o, d = make_pair(xyz, ws, num_orientations=16, debug_flags=debug_flags)
     got = d.generate_hypotheses(sample_idx=idx, seed=9)
     want = o.generate_hypotheses(sample_idx=idx, seed=9)
     assert_hyps_equal(got, want)
     assert d.counters().n_overflow_samples > 0
     check_lists_and_images(o, d, want, stride=5)
+    # a second run on the same context reuses the resized scratch
+    got = d.generate_hypotheses(sample_idx=idx[::-1].copy(), seed=10)
+    want = o.generate_hypotheses(sample_idx=idx[::-1].copy(), seed=10)
+    assert_hyps_equal(got, want)
+    d.close()
+
+
+def test_cropped_list_longer_than_default_scratch():
+    """hand_search.cpp:329-349 crops into a list of ANY length.  This scene (round 1's
+    tools/fuzz_more.py third dense scene: 320 k un-voxelised tabletop points, 12 orientations) has
+    samples whose cropped neighbourhood exceeds 65 536 points, the default size of the sweep's
+    global scratch; round 1 returned AG2_ERR_CAPACITY for the whole call."""
+    xyz, ws = scene.make_scene(seed=3, n_target=320000, kind="tabletop", voxel=None)
+    idx = scene.draw_samples(3, xyz.shape[0], 120)
+    o, d = make_pair(xyz, ws, num_orientations=12)
+    got = d.generate_hypotheses(sample_idx=idx, seed=3)
+    want = o.generate_hypotheses(sample_idx=idx, seed=3)
+    assert len(want) > 50
+    assert_hyps_equal(got, want)
+    assert got.tobytes() == want.tobytes()
+    check_lists_and_images(o, d, want, stride=3)
     d.close()
 
 

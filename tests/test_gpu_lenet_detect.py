@@ -132,6 +132,31 @@ def test_detect_threshold_and_topk(small_scene):
     d.close()
 
 
+def test_detect_on_the_null_stream_with_growing_lists(small_scene):
+    """ag2_set_stream(NULL) = the HIP default stream (what torch's default stream handle is).  The
+    page-locked staging area is re-allocated while the lists grow; every such re-allocation has to
+    wait for the stream although its handle is NULL."""
+    from agile_grasp2_amd import capi
+    from oracle import api
+    xyz, ws, idx = small_scene
+    prm = scene_params(ws, min_score_diff=-1e30, num_selected=100000)
+    d = capi.Detector(**prm)
+    d.set_stream(0)
+    o = api.Oracle(**dict(prm, num_threads=4))
+    w = make_lenet_weights(3)
+    for x in (d, o):
+        x.set_cloud(xyz)
+        x.compute_normals()
+        x.lenet_load(w)
+    big = scene.draw_samples(11, xyz.shape[0], 3000)
+    for k, samples in enumerate((idx[:10], idx, big[:700], big)):
+        gs, ga = d.detect(sample_idx=samples, seed=k, do_prune=False)
+        ws_, wa = o.detect(sample_idx=samples, seed=k, do_prune=False)
+        _check_scored(ga, wa)
+        assert len(gs) == len(ws_)
+    d.close()
+
+
 def test_detect_no_hypotheses():
     """A bare plane yields no hand placements: every stage must cope with zero work."""
     from agile_grasp2_amd import capi
