@@ -23,7 +23,7 @@ SYMBOLS = [
     "ag2_get_counters", "ag2_get_stage_times",
     "ag2_preprocess_cloud", "ag2_preprocess_cloud_device", "ag2_get_cloud", "ag2_subsample_uniformly",
     "ag2_find_clusters", "ag2_set_min_inliers", "ag2_set_grid_origin", "ag2_set_stage_timing",
-    "ag2_export_candidates_compact_device",
+    "ag2_export_candidates_compact_device", "ag2_hand_constants",
 ]
 
 
@@ -92,6 +92,18 @@ def default_params(**kw) -> Params:
     p = Params()
     load().ag2_default_params(C.byref(p))
     return apply_params(p, **kw)
+
+
+def hand_constants(params: Params | None = None, **kw):
+    """finger_spacing[20], angles[R], depths[] the hand sweep derives from the parameters (host
+    only: no device is touched)."""
+    p = params if params is not None else default_params(**kw)
+    fs, ang, dep = np.zeros(20), np.zeros(int(p.num_orientations)), np.zeros(32)
+    nd = C.c_int32(0)
+    rc = load().ag2_hand_constants(C.byref(p), _ptr(fs), _ptr(ang), _ptr(dep), C.byref(nd))
+    if rc:
+        raise RuntimeError(f"ag2_hand_constants rc={rc}")
+    return fs, ang, dep[: nd.value].copy()
 
 
 def apply_params(p, **kw):

@@ -15,9 +15,7 @@ int set_err(ag2_ctx* c, int code, const std::string& msg) {
 }
 
 // Host-side derivation of the constants the kernels read (computed once, in double, with libm).
-static void derive_constants(ag2_ctx* c) {
-  const ag2_params& p = c->p;
-  HandConst& h = c->hc;
+static void derive_constants(const ag2_params& p, HandConst& h, double* angles = nullptr) {
   memset(&h, 0, sizeof(h));
   // FingerHand ctor, finger_hand.cpp:7-12 (Eigen LinSpaced(i) = low + i * ((high-low)/(n-1)))
   const int n = 10;
@@ -39,6 +37,7 @@ static void derive_constants(ag2_ctx* c) {
   const double astep = (hi - low) / (double)R;
   for (int i = 0; i < R; i++) {
     const double a = low + (double)i * astep;
+    if (angles) angles[i] = a;
     h.cos_t[i] = cos(a);
     h.sin_t[i] = sin(a);
   }
@@ -182,6 +181,17 @@ void ag2_default_params(ag2_params* p) {
   p->num_selected = 50;
 }
 
+int ag2_hand_constants(const ag2_params* p, double* finger_spacing20, double* angles,
+                       double* depths32, int32_t* n_depths) {
+  if (!p || p->num_orientations < 1 || p->num_orientations > kMaxOrient) return AG2_ERR_ARG;
+  HandConst h;
+  derive_constants(*p, h, angles);
+  if (finger_spacing20) memcpy(finger_spacing20, h.fs, sizeof(h.fs));
+  if (depths32) memcpy(depths32, h.depths, sizeof(double) * (size_t)h.n_depths);
+  if (n_depths) *n_depths = h.n_depths;
+  return 0;
+}
+
 ag2_ctx* ag2_create(const ag2_params* p, int device_id) {
   if (!p) return nullptr;
   int ndev = 0;
@@ -210,7 +220,7 @@ ag2_ctx* ag2_create(const ag2_params* p, int device_id) {
   c->own_stream = true;
   for (auto& e : c->ev) (void)hipEventCreate(&e);
 
-  derive_constants(c);
+  derive_constants(c->p, c->hc);
   if (c->d_stats.reserve(sizeof(DevStats)) != hipSuccess || upload_constants(c) != 0 ||
       pin_reserve(c, (size_t)1 << 20) != 0) {
     fprintf(stderr, "ag2_create: device allocation failed\n");

@@ -926,13 +926,16 @@ GraspDetector::GraspDetector(const Params& params) : p_(params), num_samples_(pa
   if (p_.antipodal_mode == PREDICTION)
     classifier_.reset(new Classifier(p_.model_file, p_.trained_file, p_.label_file));
   learning_.reset(new Learning(60, p_.num_threads));  // grasp_detector.cpp:56
+  handle_search_.setMinInliers(p_.min_inliers);       // grasp_detector.cpp:58-67
+  handle_search_.setMinLength(p_.min_length);
+  handle_search_.setReuseInliers(p_.reuse_inliers);
 }
 
 GraspDetector::~GraspDetector() {}
 
-void GraspDetector::setIndicesFromMsg(const agile_grasp2::CloudIndexedIndices& msg) {
+void GraspDetector::setIndicesFromMsg(const agile_grasp2::CloudIndexed& msg) {  // grasp_detector.cpp:353-361
   indices_.resize(msg.indices.size());
-  for (size_t i = 0; i < indices_.size(); i++) indices_[i] = (int)msg.indices[i];
+  for (size_t i = 0; i < indices_.size(); i++) indices_[i] = (int)msg.indices[i].data;
 }
 
 void GraspDetector::cameraPoses(Matrix4d* left, Matrix4d* right) const {
@@ -999,7 +1002,8 @@ std::vector<GraspHypothesis> GraspDetector::detectGraspPoses(const CloudCamera& 
 std::vector<GraspHypothesis> GraspDetector::detectImpl(const CloudCamera& cloud_cam, bool clusters_grasps,
                                                        const Matrix3Xd* samples_xyz, bool cloud_is_resident) {
   std::vector<GraspHypothesis> out;
-  const int min_inliers = (clusters_grasps && p_.min_inliers > 0) ? p_.min_inliers : 0;  // :228-236
+  const int hs_inliers = handle_search_.getMinInliers();
+  const int min_inliers = (clusters_grasps && hs_inliers > 0) ? hs_inliers : 0;  // :228-236
   if (cloud_cam.getCloudOriginal()->size() == 0) {  // grasp_detector.cpp:86-91
     fprintf(stderr, "Point cloud is empty!\n");
     return out;
@@ -1311,11 +1315,9 @@ std::vector<GraspHypothesis> ImportanceSampling::detectGraspPoses(const CloudCam
     const std::vector<GraspHypothesis> hands_new = detectImpl(cloud_cam, false, &samples, true);
     hands.insert(hands.end(), hands_new.begin(), hands_new.end());
   }
-  if (params().min_inliers > 0) {  // :107-111
-    HandleSearch hs;
-    hs.setMinInliers(params().min_inliers);
-    hs.setContext(context());
-    hands = hs.findClusters(hands);
+  if (getHandleSearch().getMinInliers() > 0) {  // :104-108
+    getHandleSearch().setContext(context());
+    hands = getHandleSearch().findClusters(hands);
   }
   return hands;
 }

@@ -109,6 +109,12 @@ typedef struct ag2_times {
 
 int ag2_abi_version(void);
 void ag2_default_params(ag2_params* p);
+/* The constants the hand sweep derives from the parameters, computed on the host (no device is
+ * touched): finger_spacing[20] = FingerHand's finger_spacing_ (finger_hand.cpp:7-12), angles[R] =
+ * the hand orientations (hand_search.cpp:179-180), depths[<= 32] = deepenHand's depth sequence
+ * (finger_hand.cpp:118-122).  Any output pointer may be NULL. */
+int ag2_hand_constants(const ag2_params* p, double* finger_spacing20, double* angles,
+                       double* depths32, int32_t* n_depths);
 
 /* Replaces the constructors of GraspDetector (grasp_detector.cpp:15-81) / HandSearch::setParameters
  * (hand_search.cpp:64-80).  NULL when no HIP device is usable. */

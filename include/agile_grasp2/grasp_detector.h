@@ -13,6 +13,7 @@
 #include "agile_grasp2/cloud_camera.h"
 #include "agile_grasp2/grasp_hypothesis.h"
 #include "agile_grasp2/hand_search.h"
+#include "agile_grasp2/handle_search.h"
 #include "agile_grasp2/learning.h"
 #include "agile_grasp2/messages.h"
 
@@ -75,8 +76,11 @@ class GraspDetector {
   const std::vector<double>& getWorkspace() const { return p_.workspace; }
   int getNumSamples() const { return num_samples_; }
   void setNumSamples(int n) { num_samples_ = n; }
-  void setIndicesFromMsg(const agile_grasp2::CloudIndexedIndices& msg);
+  void setIndicesFromMsg(const agile_grasp2::CloudIndexed& msg);               // grasp_detector.h:111, .cpp:353-361
   void setSamplesMsg(const agile_grasp2::SamplesMsg& msg) { samples_msg_ = msg; }
+  // grasp_detector.h:123.  The clustering step of detectGraspPoses reads getMinInliers() from this
+  // object (grasp_detector.cpp:228-236), so a caller may change it between calls as in the reference.
+  HandleSearch& getHandleSearch() { return handle_search_; }
 
   // grasp_detection_node.cpp:296-313 (createGraspListMsg)
   static agile_grasp2::GraspListMsg createGraspListMsg(const std::vector<GraspHypothesis>& hands);
@@ -85,6 +89,9 @@ class GraspDetector {
   bool findGrasps(const CloudCamera& cloud_in, const agile_grasp2::FindGraspsRequest& req,
                   agile_grasp2::FindGraspsResponse* resp);
 
+  // not in the reference: the camera poses detectGraspPoses hands to the hand search
+  // (grasp_detector.cpp:108-137: the launch file's camera_pose, else the 2-camera Baxter defaults)
+  void cameraPoses(ag2::Matrix4d* left, ag2::Matrix4d* right) const;
   const ag2_times& lastStageTimes() const { return times_; }
   const ag2_counters& lastCounters() const { return counters_; }
   const std::string& lastError() const { return err_; }
@@ -104,7 +111,6 @@ class GraspDetector {
                                                            float max_y, float min_z);
   std::shared_ptr<ag2::Context> contextFor(int n_cams);
   bool preprocessOnDevice(CloudCamera& cloud_cam);
-  void cameraPoses(ag2::Matrix4d* left, ag2::Matrix4d* right) const;
 
   Params p_;
   int num_samples_;
@@ -114,6 +120,7 @@ class GraspDetector {
   agile_grasp2::SamplesMsg samples_msg_;
   std::unique_ptr<Classifier> classifier_;
   std::unique_ptr<Learning> learning_;
+  HandleSearch handle_search_;
   std::shared_ptr<ag2::Context> ctx_;
   int ctx_cams_ = 0;
   // cloud left in the context by preprocessPointCloud: detectGraspPoses does not upload it again

@@ -48,6 +48,21 @@ class HandSearch {
 
   HandSearch() {}
   explicit HandSearch(const Parameters& params) : params_(params) {}
+  // hand_search.h:114-118: the 7-argument form fixes nn_radius_taubin_ = 0.03 and nn_radius_hands_ =
+  // 0.08; it leaves num_orientations_ and the camera poses uninitialised in the reference -- here
+  // they keep the Parameters defaults (8 orientations, identity poses).
+  HandSearch(double finger_width, double hand_outer_diameter, double hand_depth, double hand_height,
+             double init_bite, int num_threads, int num_samples) {
+    params_.finger_width_ = finger_width;
+    params_.hand_outer_diameter_ = hand_outer_diameter;
+    params_.hand_depth_ = hand_depth;
+    params_.hand_height_ = hand_height;
+    params_.init_bite_ = init_bite;
+    params_.num_threads_ = num_threads;
+    params_.num_samples_ = num_samples;
+    params_.nn_radius_taubin_ = 0.03;
+    params_.nn_radius_hands_ = 0.08;
+  }
 
   // hand_search.cpp:4-61.  antipodal_mode and forces_PSD are ignored by the reference body too;
   // plots_* have no effect (no visualisation is built).  Returns hypotheses in sample order, each

@@ -38,8 +38,34 @@ struct SamplesMsg {  // msg/SamplesMsg.msg
   std::vector<Point> samples;
 };
 
-struct CloudIndexedIndices {  // the std_msgs/Int64[] indices part of msg/CloudIndexed.msg
-  std::vector<int64_t> indices;
+struct Int64 { int64_t data = 0; };               // std_msgs/Int64
+
+// sensor_msgs/PointCloud2, the fields the node reads (grasp_detection_node.cpp:216-275): the cloud
+// itself travels as a CloudCamera on this side, so only the layout description is mirrored.
+struct PointField {
+  std::string name;
+  uint32_t offset = 0;
+  uint8_t datatype = 0;
+  uint32_t count = 0;
+};
+struct PointCloud2 {
+  Header header;
+  uint32_t height = 0, width = 0;
+  std::vector<PointField> fields;
+  bool is_bigendian = false;
+  uint32_t point_step = 0, row_step = 0;
+  std::vector<uint8_t> data;
+  bool is_dense = false;
+};
+
+struct CloudIndexed {  // msg/CloudIndexed.msg:1-2
+  PointCloud2 cloud;
+  std::vector<Int64> indices;   // read as msg.indices[i].data, grasp_detector.cpp:353-361
+};
+
+struct CloudSized {  // msg/CloudSized.msg:1-2
+  PointCloud2 cloud;
+  Int64 size_left;
 };
 
 struct FindGraspsRequest {  // srv/FindGrasps.srv:9-30
@@ -54,6 +80,10 @@ struct FindGraspsRequest {  // srv/FindGrasps.srv:9-30
 
 struct FindGraspsResponse {  // srv/FindGrasps.srv:33-34
   GraspListMsg grasps_msg;
+};
+struct FindGrasps {  // the names roscpp generates for the service (grasp_detection_node.h:157)
+  typedef FindGraspsRequest Request;
+  typedef FindGraspsResponse Response;
 };
 
 // Fixed 152-byte little-endian payload of one GraspMsg (3 Points + 3 Vector3 as f64, width and

@@ -877,6 +877,21 @@ ag2o_ctx* ag2o_create(const ag2o_params* p) {
 }
 
 void ag2o_destroy(ag2o_ctx* c) { delete c; }
+
+int ag2o_hand_constants(const ag2o_params* p, double* finger_spacing20, double* angles,
+                        double* depths32, int32_t* n_depths) {
+  if (!p || p->num_orientations < 1) return -1;
+  ag2o_ctx* c = ag2o_create(p);
+  if (finger_spacing20) std::memcpy(finger_spacing20, c->fs, sizeof(c->fs));
+  const double low = -1.0 * M_PI / 2.0, astep = (M_PI / 2.0 - low) / (double)c->p.num_orientations;
+  if (angles)
+    for (int i = 0; i < c->p.num_orientations; i++) angles[i] = low + (double)i * astep;
+  const size_t nd = std::min<size_t>(c->depths.size(), 32);
+  if (depths32) std::memcpy(depths32, c->depths.data(), nd * sizeof(double));
+  if (n_depths) *n_depths = (int32_t)nd;
+  ag2o_destroy(c);
+  return 0;
+}
 const char* ag2o_last_error(const ag2o_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int ag2o_set_cloud(ag2o_ctx* c, const float* xyz, size_t n, size_t stride_bytes,

@@ -73,6 +73,10 @@ typedef struct ag2o_counters {
 } ag2o_counters;
 
 void ag2o_default_params(ag2o_params* p);
+/* finger_spacing_ (finger_hand.cpp:7-12), hand angles (hand_search.cpp:179-180), deepenHand depths
+ * (finger_hand.cpp:118-122) as this restatement derives them; any output may be NULL. */
+int ag2o_hand_constants(const ag2o_params* p, double* finger_spacing20, double* angles,
+                        double* depths32, int32_t* n_depths);
 ag2o_ctx* ag2o_create(const ag2o_params* p);
 void ag2o_destroy(ag2o_ctx* c);
 const char* ag2o_last_error(const ag2o_ctx* c);

@@ -80,6 +80,15 @@ def default_params(**kw) -> Params:
     return p
 
 
+def hand_constants(params: Params | None = None, **kw):
+    p = params if params is not None else default_params(**kw)
+    fs, ang, dep = np.zeros(20), np.zeros(int(p.num_orientations)), np.zeros(32)
+    nd = C.c_int32(0)
+    rc = lib().ag2o_hand_constants(C.byref(p), _ptr(fs), _ptr(ang), _ptr(dep), C.byref(nd))
+    assert rc == 0
+    return fs, ang, dep[: nd.value].copy()
+
+
 def apply_params(p, **kw):
     for k, v in kw.items():
         if k == "cam_origin":

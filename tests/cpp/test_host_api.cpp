@@ -154,7 +154,43 @@ static int run_pcd(const char* path, const char* out_path) {
   return 0;
 }
 
+// test_host_api --constants <out.txt>: what the mirror derives from the reference-held constants,
+// no GPU touched: default camera poses (grasp_detector.cpp:108-126) and the finger slots / hand
+// angles / deepen depths of the launch-file hand (finger_hand.cpp:7-12, hand_search.cpp:179-180).
+static int run_constants(const char* out_path) {
+  GraspDetector::Params prm;  // defaults: no camera_pose => Baxter matrices
+  prm.antipodal_mode = GraspDetector::NONE;  // no classifier files needed
+  GraspDetector det(prm);
+  ag2::Matrix4d l, r;
+  det.cameraPoses(&l, &r);
+  FILE* f = fopen(out_path, "w");
+  if (!f) return 3;
+  fprintf(f, "cam_tf_left");
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) fprintf(f, " %.17g", l(i, j));
+  fprintf(f, "\ncam_tf_right");
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) fprintf(f, " %.17g", r(i, j));
+  HandSearch::Parameters hp;
+  hp.init_bite_ = 0.01;  // launch/file_detect_grasps.launch
+  const ag2_params ap = HandSearch::toAbiParams(hp, 1);
+  double fs[20], ang[32], dep[32];
+  int32_t nd = 0;
+  if (ag2_hand_constants(&ap, fs, ang, dep, &nd)) return 4;
+  fprintf(f, "\nfinger_spacing");
+  for (int i = 0; i < 20; i++) fprintf(f, " %.17g", fs[i]);
+  fprintf(f, "\nangles");
+  for (int i = 0; i < ap.num_orientations; i++) fprintf(f, " %.17g", ang[i]);
+  fprintf(f, "\ndepths");
+  for (int i = 0; i < nd; i++) fprintf(f, " %.17g", dep[i]);
+  HandSearch seven(0.01, 0.09, 0.06, 0.02, 0.01, 4, 500);  // hand_search.h:114-118
+  fprintf(f, "\nseven_arg_ctor %.17g %.17g %d %d\n", seven.getParameters().nn_radius_taubin_,
+          seven.getParameters().nn_radius_hands_, seven.getParameters().num_threads_,
+          seven.getParameters().num_samples_);
+  fclose(f);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 3 && std::string(argv[1]) == "--constants") return run_constants(argv[2]);
   if (argc == 5 && std::string(argv[1]) == "--preprocess") return run_preprocess(argv[2], argv[3], argv[4]);
   if (argc == 4 && std::string(argv[1]) == "--caffemodel") return run_caffemodel(argv[2], argv[3]);
   if (argc == 4 && std::string(argv[1]) == "--pcd") return run_pcd(argv[2], argv[3]);
