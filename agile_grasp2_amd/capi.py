@@ -24,6 +24,7 @@ SYMBOLS = [
     "ag2_preprocess_cloud", "ag2_preprocess_cloud_device", "ag2_get_cloud", "ag2_subsample_uniformly",
     "ag2_find_clusters", "ag2_set_min_inliers", "ag2_set_grid_origin", "ag2_set_stage_timing",
     "ag2_export_candidates_compact_device", "ag2_hand_constants",
+    "ag2_stream_configure", "ag2_detect_frame", "ag2_get_frame_info",
 ]
 
 
@@ -48,6 +49,12 @@ class Counters(C.Structure):
         "n_points", "n_valid_points", "n_samples", "n_frames", "n_hypotheses", "n_pruned",
         "n_scored", "n_selected", "sum_k1", "sum_k2", "sum_kcrop", "sum_p", "n_overflow_samples",
         "reserved")]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "frames", "graph_replays", "plain_runs", "stepwise_runs", "captures", "capture_failed",
+        "capture_refused", "fallbacks", "max_points", "max_samples", "max_cells", "graph_ready")]
 
 
 class Times(C.Structure):
@@ -329,6 +336,34 @@ class Detector:
                                    _ptr(allh) if want_all else None,
                                    C.c_size_t(cap if want_all else 0), C.byref(na)))
         return sel[: ns.value].copy(), (allh[: na.value].copy() if want_all else na.value)
+
+    def stream_configure(self, max_points=0, max_samples=0, use_graph=True):
+        self._ck(self.L.ag2_stream_configure(self.h, C.c_size_t(max_points), C.c_size_t(max_samples),
+                                             C.c_int(1 if use_graph else 0)))
+
+    def detect_frame(self, xyz=None, sample_idx=None, seed=0, do_prune=True, dptr=None, n=None, stride=12):
+        """One frame of a cloud stream (ag2_detect_frame).  xyz: (n, 3) float32 in host memory, or
+        dptr / n / stride for a device-resident cloud.  Returns (selected records, n_scored)."""
+        si = np.ascontiguousarray(sample_idx, dtype=np.int32)
+        if dptr is None:
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+            n, stride, ptr, on_dev = xyz.shape[0], 12, _ptr(xyz), 0
+        else:
+            ptr, on_dev = C.c_void_p(dptr), 1
+        self.n = int(n)
+        cap = max(1, len(si) * int(self.params.num_orientations))
+        sel = np.zeros(cap, dtype=HYP_DTYPE)
+        ns, na = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self.L.ag2_detect_frame(self.h, ptr, C.c_int(on_dev), C.c_size_t(n), C.c_size_t(stride),
+                                         _ptr(si), C.c_size_t(len(si)), C.c_uint64(seed),
+                                         C.c_int(1 if do_prune else 0), _ptr(sel), C.c_size_t(cap),
+                                         C.byref(ns), C.byref(na)))
+        return sel[: ns.value].copy(), na.value
+
+    def frame_info(self) -> FrameInfo:
+        fi = FrameInfo()
+        self._ck(self.L.ag2_get_frame_info(self.h, C.byref(fi)))
+        return fi
 
     def set_min_inliers(self, k: int):
         """HandleSearch::setMinInliers: > 0 makes detect() cluster before the top-k."""

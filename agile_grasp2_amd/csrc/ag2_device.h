@@ -22,6 +22,15 @@ struct GridDesc {
   int dims[3];
   int ncells;
   int n_valid;
+  float min_z;   // smallest z of the (whole) cloud: pcl::getMinMax3D, grasp_detector.cpp:152-153
+};
+
+// Frame mode (ag2_frame.hip): what changes from frame to frame and would otherwise be a by-value
+// kernel argument frozen into the captured graph lives in page-locked host memory the kernels read
+// through its device view.
+struct FrameArgs {
+  unsigned long long seed;
+  unsigned long long slot_base;
 };
 
 // Per-context constants, built on the host (ag2_context.hip derive_constants) and read through a
@@ -44,6 +53,18 @@ struct HandConst {
   int R, n_depths, n_cams, filter_half;
   int slot_span, pad0;           // floor(finger_width / spacing) + 1
 };
+
+// k_lenet_fc1_x3: split of K (150 chunks of 48) for a batch of `mtiles` 128-image tiles, so that
+// small batches still put about two workgroups on every CU.  One rule for the host (exact-size
+// launches) and the device (frame mode, batch size known only there): the split decides the order
+// in which the partial sums are added, so it must not depend on who chose it.
+constexpr int kFc1X3MaxSplit = 30;
+__host__ __device__ inline int fc1_x3_ksplit(int mtiles) {
+  const int splits[9] = {1, 2, 3, 5, 6, 10, 15, 25, 30};
+  for (int i = 0; i < 9; i++)
+    if ((long long)mtiles * 4 * splits[i] >= 448) return splits[i];
+  return kFc1X3MaxSplit;
+}
 
 struct V3 {
   double x, y, z;

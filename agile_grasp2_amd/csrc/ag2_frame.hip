@@ -1,0 +1,507 @@
+// ag2_frame.hip -- BASELINE.json configuration 5: a stream of clouds, one `ag2_detect_frame` per
+// frame, the per-frame pipeline captured in a hipGraph.
+//
+// The caller this serves is the live-topic loop of the reference's node
+// (src/nodes/grasp_detection_node.cpp:69-95 run(), :123-143 detectGraspPosesInTopic): one cloud in,
+// one grasp list out, again and again with clouds of nearly the same size.  A frame is
+//   search grid -> PCA normals -> local frames -> hand sweep -> prune -> grasp images -> LeNet ->
+//   score threshold -> top-k
+// i.e. ag2_set_cloud_device + ag2_compute_normals + ag2_detect, and returns the same bytes.
+//
+// What makes the sequence capturable: nothing in it waits for the host.  The three read-backs of the
+// step-by-step path (grid extent, list length, results + host top-k) are gone --
+//   * the extent partials are reduced on the device into a GridDesc that the kernels read from
+//     memory (k_grid_desc),
+//   * every list length (hypotheses to score, selected hypotheses, sweep overflow queue) is consumed
+//     where it was produced; launches cover fixed maximum shapes and the surplus workgroups leave,
+//   * the top-k by score runs on the device (k_topk), and ONE copy at the end brings statistics,
+//     grid description and the selected records into page-locked memory.
+// Fixed maximum shapes: the cloud is padded with non-finite points to fm_n_max (no stage sees a
+// non-finite point), the sample list with -1 to fm_s_max, the cell table covers fm_cap_cells, the
+// image list S*R.  What changes per frame and would be a by-value kernel argument (seed, slot base)
+// sits in page-locked memory (FrameArgs).  The pack + extent kernel that reads the caller's buffer
+// runs in front of the graph, outside it (its pointer and count change with every frame).
+//
+// A frame that does not fit the captured shapes (more points, samples or cells; arena or sweep
+// scratch too small) is detected from the flags that come back with the results and is repeated on
+// the step-by-step path, which sizes the buffers; the graph is captured again afterwards.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "ag2_internal.h"
+
+using namespace ag2;
+
+namespace ag2 {
+
+struct FrameOut {  // copied back once per frame
+  DevStats st;
+  GridDesc g;
+  unsigned n_out;  // records that follow (top-k)
+  unsigned topk_overflow;
+};
+
+}  // namespace ag2
+
+struct ag2_frame_state {
+  bool use_graph = true;
+  bool shapes_known = false;
+  size_t cap_img = 0;        // = fm_s_max * R
+  size_t k_cap = 0;          // records copied back per frame
+  int do_prune = -1;         // of the captured sequence
+  // page-locked block: FrameArgs | idx[s_max] | FrameOut | records[k_cap]
+  char* h_pin = nullptr;
+  size_t h_pin_bytes = 0;
+  size_t off_idx = 0, off_out = 0, off_rec = 0;
+  ag2::DevBuf d_raw;         // staging of a cloud handed over in host memory
+  ag2::DevBuf d_out;         // top-k records + FrameOut tail
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  bool graph_valid = false;
+  unsigned long long sig_at_capture = 0;  // addresses / sizes the captured graph holds
+  ag2_frame_info info{};
+};
+
+namespace ag2 {
+
+// ---- grid description on the device -----------------------------------------------------------
+// Reduces the extent partials of k_bounds (one 32-B record per workgroup) and derives the grid the
+// way build_grid does on the host: same float expressions, so the same cells.  ncells <= 0 tells
+// every consumer "no grid": -1 more cells than the captured table holds, -2 a point below the origin
+// given to ag2_set_grid_origin, 0 no finite point.
+__global__ void __launch_bounds__(64) k_grid_desc(const int* __restrict__ part, int nb, float inv,
+                                                  int origin_set, float ox, float oy, float oz,
+                                                  int cap_cells, GridDesc* __restrict__ out) {
+  const int lane = lane_id();
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+  int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  int cnt = 0;
+  for (int b = lane; b < nb; b += 64) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      mn[a] = min(mn[a], part[b * 8 + a]);
+      mx[a] = max(mx[a], part[b * 8 + 3 + a]);
+    }
+    cnt += part[b * 8 + 6];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
+    }
+  }
+  cnt = wave_sum_i(cnt);
+  if (lane != 0) return;
+  GridDesc g{};
+  g.inv = inv;
+  if (cnt > 0) {
+    const float org[3] = {ox, oy, oz};
+    long long ncells = 1;
+    bool below = false;
+    for (int a = 0; a < 3; a++) {
+      const float bmin = ord2f(mn[a]), bmax = ord2f(mx[a]);
+      if (origin_set && bmin < org[a]) below = true;
+      g.o[a] = origin_set ? org[a] : bmin;
+      g.dims[a] = (int)__builtin_floorf((bmax - g.o[a]) * g.inv) + 1;
+      ncells *= g.dims[a];
+      if (ncells > (1ll << 30)) ncells = (1ll << 30) + 1;
+    }
+    g.min_z = g.o[2];  // pcl::getMinMax3D of the (whole) cloud, grasp_detector.cpp:152-153
+    g.n_valid = cnt;
+    g.ncells = below ? -2 : (ncells > (long long)cap_cells ? -1 : (int)ncells);
+    if (g.ncells <= 0) {
+      g.n_valid = 0;
+      g.dims[0] = g.dims[1] = g.dims[2] = 0;
+    }
+  }
+  *out = g;
+}
+
+// ---- top num_selected by score on the device ------------------------------------------------------
+// grasp_detector.cpp:239-252: partial_sort by score, descending; ties by position in the list (the
+// order the step-by-step path's host sort uses).  Every record finds its rank by counting the
+// records that come before it in that order -- n^2 compares over a few hundred to a few thousand
+// selected records, the scores staged through LDS -- and the first k are written at their rank.
+constexpr int kTopkThreads = 256;
+__global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __restrict__ recs,
+                                                       const unsigned* __restrict__ d_n, int cap,
+                                                       int k_want, int k_cap,
+                                                       ag2_hypothesis* __restrict__ out, FrameOut* fo) {
+  __shared__ double sc[kTopkThreads];
+  const int n = min((int)*d_n, cap);
+  int k = (k_want >= 0 && k_want < n) ? k_want : n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    fo->topk_overflow = (k > k_cap) ? (unsigned)k : 0u;
+    fo->n_out = (unsigned)min(k, k_cap);
+  }
+  k = min(k, k_cap);
+  const int base = blockIdx.x * kTopkThreads;
+  if (base >= n) return;  // uniform
+  const int i = base + threadIdx.x;
+  const double si = (i < n) ? recs[i].score : 0.0;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += kTopkThreads) {
+    __syncthreads();
+    if (j0 + (int)threadIdx.x < n) sc[threadIdx.x] = recs[j0 + threadIdx.x].score;
+    __syncthreads();
+    const int m = min(kTopkThreads, n - j0);
+    for (int t = 0; t < m; t++) {
+      const double sj = sc[t];
+      rank += (sj > si || (sj == si && j0 + t < i)) ? 1 : 0;
+    }
+  }
+  if (i < n && rank < k) out[rank] = recs[i];
+}
+
+__global__ void k_frame_out(const DevStats* __restrict__ st, const GridDesc* __restrict__ g, FrameOut* fo) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    fo->st = *st;
+    fo->g = *g;
+  }
+}
+
+namespace {
+
+int frame_pin_reserve(ag2_ctx* c, ag2_frame_state* f) {
+  const size_t off_idx = 64;
+  const size_t off_out = (off_idx + c->fm_s_max * 4 + 63) & ~size_t(63);
+  const size_t off_rec = (off_out + sizeof(FrameOut) + 63) & ~size_t(63);
+  const size_t need = off_rec + f->k_cap * sizeof(ag2_hypothesis) + 64;
+  f->off_idx = off_idx;
+  f->off_out = off_out;
+  f->off_rec = off_rec;
+  if (need <= f->h_pin_bytes) return 0;
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  if (f->h_pin) (void)hipHostFree(f->h_pin);
+  f->h_pin = nullptr;
+  f->h_pin_bytes = 0;
+  AG2_HIP(c, hipHostMalloc((void**)&f->h_pin, need, hipHostMallocDefault));
+  f->h_pin_bytes = need;
+  void* dv = nullptr;
+  AG2_HIP(c, hipHostGetDevicePointer(&dv, f->h_pin, 0));
+  c->fm_args_dev = (const FrameArgs*)dv;
+  return 0;
+}
+
+// A captured graph holds the addresses (and the few sizes) it was captured with: every buffer a frame
+// touches goes into this signature, and a graph is replayed only while it still matches.
+unsigned long long frame_signature(const ag2_ctx* c, const ag2_frame_state* f) {
+  const void* ptrs[] = {c->d_xyz_in.p, c->d_bounds.p, c->d_griddesc.p, c->d_key.p, c->d_cell.p, c->d_perm.p,
+                        c->d_sorted.p, c->d_nrm.p, c->d_stats.p, c->d_hc.p, c->d_sample_q.p, c->d_frames.p,
+                        c->d_frame_ok.p, c->d_table.p, c->d_tab_off.p, c->d_tab_keep.p, c->d_arena.p,
+                        c->d_overflow.p, c->d_gscratch.p, c->d_gpos.p, c->d_list2.p, c->d_images.p,
+                        c->d_logits.p, c->d_act1.p, c->d_fcpart.p, c->d_tmp.p, c->d_flags.p, c->d_desc.p,
+                        c->d_scan.p, f->d_out.p, f->h_pin, c->net.w1x.p, c->net.w2x.p, c->net.w3x.p,
+                        c->net.b1.p, c->net.b2.p, c->net.b3.p, c->net.w4.p, c->net.b4.p, (const void*)c->stream};
+  const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points,
+                                     (unsigned long long)c->sweep_gcap, (unsigned long long)c->sweep_g2,
+                                     (unsigned long long)c->p.num_selected, f->k_cap,
+                                     (unsigned long long)c->origin_set};
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&h](unsigned long long v) {
+    for (int b = 0; b < 8; b++) {
+      h ^= (v >> (8 * b)) & 255ull;
+      h *= 1099511628211ull;
+    }
+  };
+  for (const void* p : ptrs) mix((unsigned long long)(uintptr_t)p);
+  for (unsigned long long v : vals) mix(v);
+  for (int a = 0; a < 3; a++) {
+    unsigned u;
+    memcpy(&u, &c->origin[a], 4);
+    mix(u);
+  }
+  return h;
+}
+
+void drop_graph(ag2_frame_state* f) {
+  if (f->exec) (void)hipGraphExecDestroy(f->exec);
+  if (f->graph) (void)hipGraphDestroy(f->graph);
+  f->exec = nullptr;
+  f->graph = nullptr;
+  f->graph_valid = false;
+}
+
+// Everything of a frame behind the pack + extent kernel, on c->stream, at the fixed maximum shapes;
+// nothing in here waits for the host or allocates once the buffers have their size (the first,
+// uncaptured run gives them that).
+int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
+  const size_t n_max = c->fm_n_max, s_max = c->fm_s_max, cap_cells = c->fm_cap_cells;
+  const int R = c->p.num_orientations;
+  const size_t n_slots = s_max * (size_t)R;
+  DevStats* st = c->d_stats.as<DevStats>();
+  GridDesc* gp = c->d_griddesc.as<GridDesc>();
+  // -- K0 search grid ---------------------------------------------------------------------------
+  hipLaunchKernelGGL(k_grid_desc, dim3(1), dim3(64), 0, c->stream, c->d_bounds.as<int>(), c->bounds_blocks,
+                     1.0f / (float)c->p.grid_cell, c->origin_set ? 1 : 0, c->origin[0], c->origin[1],
+                     c->origin[2], (int)cap_cells, gp);
+  AG2_HIP(c, c->d_key.reserve(n_max * 8));
+  const size_t cell_words = ((cap_cells + 1) + 3) & ~size_t(3);
+  const size_t ctl_words = (scan_ctl_words((int)cap_cells + 1) + 3) & ~size_t(3);
+  AG2_HIP(c, c->d_cell.reserve((cell_words + ctl_words) * 4));
+  AG2_HIP(c, c->d_perm.reserve(n_max * 4));
+  AG2_HIP(c, c->d_sorted.reserve(n_max * 16));
+  AG2_HIP(c, c->d_nrm.reserve(n_max * 16));
+  unsigned* cell = c->d_cell.as<unsigned>();
+  AG2_HIP(c, hipMemsetAsync(cell, 0, (cell_words + ctl_words) * 4, c->stream));
+  int rc = launch_grid_frame(c, cell, cell + cell_words);
+  if (rc) return rc;
+  // -- K1 normals ----------------------------------------------------------------------------------
+  rc = launch_normals(c);
+  if (rc) return rc;
+  // -- samples (indices in the page-locked block, padded with -1), K2 frames, K3 sweep -------------
+  AG2_HIP(c, c->d_sample_q.reserve(s_max * 16));
+  AG2_HIP(c, c->d_frames.reserve(s_max * 12 * 8));
+  AG2_HIP(c, c->d_frame_ok.reserve(s_max * 4));
+  AG2_HIP(c, c->d_tab_keep.reserve(std::max<size_t>(n_slots, 1)));
+  rc = launch_sample_queries(c, (const int*)((const char*)c->fm_args_dev + f->off_idx), s_max, true);
+  if (rc) return rc;
+  rc = launch_frames(c, s_max, 0, 0);
+  if (rc) return rc;
+  rc = launch_sweep(c, s_max, 0, /*emit_lists=*/true, /*run_cleared=*/true);
+  if (rc) return rc;
+  // -- prune (predicate evaluated in the sweep) + image descriptors ------------------------------
+  rc = compact_slots_async(c, n_slots, do_prune ? 1 : 0, c->d_list2, &st->n_list, /*with_descs=*/true);
+  if (rc) return rc;
+  if (c->desc_stride == 0) return set_err(c, AG2_ERR_CAPACITY, "frame mode: more than 65536 table slots");
+  // -- K4 images, K5 LeNet, K6 score / threshold -----------------------------------------------------
+  AG2_HIP(c, c->d_images.reserve(n_slots * 10800));
+  AG2_HIP(c, c->d_logits.reserve(n_slots * 8));
+  const unsigned* d_n = &st->n_list;
+  rc = launch_render(c, c->d_arena.as<double>(), c->d_desc.as<long long>(),
+                     (const int*)(c->d_desc.as<long long>() + c->desc_stride), n_slots,
+                     c->d_images.as<uint8_t>(), 0x7fffffff, d_n);
+  if (rc) return rc;
+  rc = launch_lenet(c, c->d_images.as<uint8_t>(), n_slots, c->d_logits.as<float>(), -1, d_n);
+  if (rc) return rc;
+  rc = score_and_select_async(c, c->d_list2.as<int>(), n_slots, &st->n_sel, d_n);
+  if (rc) return rc;
+  // -- top-k on the device, one copy back ----------------------------------------------------------
+  AG2_HIP(c, f->d_out.reserve(f->k_cap * sizeof(ag2_hypothesis) + sizeof(FrameOut) + 64));
+  ag2_hypothesis* d_rec = f->d_out.as<ag2_hypothesis>();
+  FrameOut* d_fo = (FrameOut*)(d_rec + f->k_cap);
+  hipLaunchKernelGGL(k_topk, dim3((unsigned)((n_slots + kTopkThreads - 1) / kTopkThreads)), dim3(kTopkThreads), 0,
+                     c->stream, c->d_tmp.as<ag2_hypothesis>(), &st->n_sel, (int)n_slots, c->p.num_selected,
+                     (int)f->k_cap, d_rec, d_fo);
+  hipLaunchKernelGGL(k_frame_out, dim3(1), dim3(64), 0, c->stream, st, gp, d_fo);
+  AG2_HIP(c, hipGetLastError());
+  AG2_HIP(c, hipMemcpyAsync(f->h_pin + f->off_out, d_fo, sizeof(FrameOut), hipMemcpyDeviceToHost, c->stream));
+  if (f->k_cap)
+    AG2_HIP(c, hipMemcpyAsync(f->h_pin + f->off_rec, d_rec, f->k_cap * sizeof(ag2_hypothesis),
+                              hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+
+// the step-by-step path for one frame (also what sizes the buffers and teaches the shapes)
+int frame_stepwise(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride, const int32_t* sample_idx, size_t s,
+                   uint64_t seed, int do_prune, ag2_hypothesis* selected, size_t cap, size_t* n_selected,
+                   size_t* n_scored) {
+  c->fm_on = false;
+  int rc = ag2_set_cloud_device(c, d_xyz, n, stride);
+  if (!rc) rc = ag2_compute_normals(c);
+  if (!rc) rc = ag2_detect(c, sample_idx, nullptr, s, 0, seed, do_prune, selected, cap, n_selected, nullptr, 0, n_scored);
+  return rc;
+}
+
+}  // namespace
+
+void frame_release(ag2_ctx* c) {
+  ag2_frame_state* f = c->fm;
+  if (!f) return;
+  drop_graph(f);
+  if (f->h_pin) (void)hipHostFree(f->h_pin);
+  f->d_raw.release();
+  f->d_out.release();
+  delete f;
+  c->fm = nullptr;
+}
+
+}  // namespace ag2
+
+extern "C" {
+
+int ag2_stream_configure(ag2_ctx* c, size_t max_points, size_t max_samples, int use_graph) {
+  if (!c) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (!c->fm) c->fm = new ag2_frame_state();
+  ag2_frame_state* f = c->fm;
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  drop_graph(f);
+  f->use_graph = use_graph != 0;
+  f->shapes_known = false;
+  c->fm_n_max = max_points;
+  c->fm_s_max = max_samples;
+  c->fm_cap_cells = 0;
+  memset(&f->info, 0, sizeof(f->info));
+  return 0;
+}
+
+int ag2_detect_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                     const int32_t* sample_idx, size_t s, uint64_t seed, int do_prune,
+                     ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored) {
+  if (!c || !n_selected || (s && !sample_idx) || (n && !xyz)) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (c->p.n_cams != 1) return set_err(c, AG2_ERR_ARG, "frames are single-camera clouds");
+  if (stride_bytes < 12 || stride_bytes % 4 != 0) return set_err(c, AG2_ERR_ARG, "bad stride");
+  if (n > (size_t)1 << 30) return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 points");
+  if (!c->net.loaded) return set_err(c, AG2_ERR_STATE, "lenet weights not loaded");
+  if (!c->fm) c->fm = new ag2_frame_state();
+  ag2_frame_state* f = c->fm;
+  const int R = c->p.num_orientations;
+  // a cloud in host memory goes through a device staging buffer first
+  const void* d_xyz = xyz;
+  if (!xyz_on_device && n) {
+    AG2_HIP(c, f->d_raw.reserve(n * stride_bytes));
+    AG2_HIP(c, hipMemcpyAsync(f->d_raw.p, xyz, n * stride_bytes, hipMemcpyHostToDevice, c->stream));
+    d_xyz = f->d_raw.p;
+  }
+  f->info.frames++;
+  // Frames the captured sequence cannot take: clustering inside detect (k_cluster is not part of
+  // it), more than 65536 table slots, an empty frame, the f32-input LeNet kernels.
+  const bool unsupported = c->min_inliers > 0 || s * (size_t)R > 65536 || n == 0 || s == 0 || !c->net.use_x3;
+  bool stepwise = unsupported || !f->shapes_known || n > c->fm_n_max || s > c->fm_s_max;
+  if (!stepwise) {
+    // ---- the frame at fixed shapes: pack + extent in front, then the sequence (graph or plain) ----
+    c->fm_on = true;
+    int rc = frame_pin_reserve(c, f);
+    if (rc) return rc;
+    FrameArgs* fa = (FrameArgs*)f->h_pin;
+    fa->seed = seed;
+    fa->slot_base = 0;
+    int32_t* hidx = (int32_t*)(f->h_pin + f->off_idx);
+    memcpy(hidx, sample_idx, s * 4);
+    for (size_t i = s; i < c->fm_s_max; i++) hidx[i] = -1;
+    AG2_HIP(c, c->d_xyz_in.reserve(c->fm_n_max * 16));
+    AG2_HIP(c, c->d_bounds.reserve((size_t)128 * 8 * 4));
+    AG2_HIP(c, c->d_griddesc.reserve(sizeof(GridDesc)));
+    rc = pack_device_xyz(c, d_xyz, n, stride_bytes, c->d_xyz_in.as<float4>(), /*with_bounds=*/true, c->fm_n_max);
+    if (rc) return rc;
+    const bool replay = f->use_graph && f->graph_valid && f->do_prune == do_prune &&
+                        f->sig_at_capture == frame_signature(c, f);
+    if (replay) {
+      AG2_HIP(c, hipGraphLaunch(f->exec, c->stream));
+      f->info.graph_replays++;
+    } else {
+      drop_graph(f);
+      const int lvl = c->stage_timing;
+      c->stage_timing = 0;  // (events are not part of the sequence)
+      rc = enqueue_frame(c, f, do_prune);
+      c->stage_timing = lvl;
+      if (rc) {
+        c->fm_on = false;
+        return rc;
+      }
+      f->info.plain_runs++;
+    }
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+    const FrameOut* fo = (const FrameOut*)(f->h_pin + f->off_out);
+    const unsigned flags = fo->st.err_flags;
+    const bool bad = (flags & (1u | 8u)) != 0 || fo->g.ncells < 0 || fo->topk_overflow != 0;
+    if (bad) {
+      if (fo->g.ncells == -2) {
+        c->fm_on = false;
+        return set_err(c, AG2_ERR_ARG, "a point lies below the grid origin given to ag2_set_grid_origin");
+      }
+      f->info.fallbacks++;
+      f->shapes_known = false;  // learn the shapes again from the step-by-step run below
+      stepwise = true;
+    } else {
+      // capture for the frames to come (right after the run that gave every buffer its size)
+      if (!replay && f->use_graph) {
+        if (c->stream == nullptr) {
+          f->info.capture_refused++;  // the legacy default stream cannot be captured
+        } else {
+          const unsigned long long sig0 = frame_signature(c, f);
+          const int lvl = c->stage_timing;
+          c->stage_timing = 0;
+          hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+          int rc2 = (e == hipSuccess) ? enqueue_frame(c, f, do_prune) : AG2_ERR_HIP;
+          hipGraph_t g = nullptr;
+          if (e == hipSuccess) e = hipStreamEndCapture(c->stream, &g);
+          c->stage_timing = lvl;
+          if (e == hipSuccess && rc2 == 0 && g && sig0 == frame_signature(c, f) &&
+              hipGraphInstantiate(&f->exec, g, nullptr, nullptr, 0) == hipSuccess) {
+            f->graph = g;
+            f->graph_valid = true;
+            f->sig_at_capture = sig0;
+            f->do_prune = do_prune;
+            f->info.captures++;
+          } else {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            f->info.capture_failed++;
+          }
+        }
+      }
+      // results
+      c->n = n;
+      c->n_valid = (size_t)fo->g.n_valid;
+      c->grid = fo->g;
+      c->min_z = fo->g.min_z;
+      c->has_cloud = c->has_normals = true;
+      c->normals_pending = c->grid_pending = false;
+      c->s = s;
+      c->slot_base = 0;
+      c->n_img = fo->st.n_list;
+      c->max_p = (int)fo->st.max_p;
+      memset(&c->cnt, 0, sizeof(c->cnt));
+      c->cnt.n_points = (int64_t)n;
+      c->cnt.n_valid_points = fo->g.n_valid;
+      c->cnt.n_samples = (int64_t)s;
+      c->cnt.n_frames = fo->st.n_frames;
+      c->cnt.n_hypotheses = fo->st.n_hyp;
+      c->cnt.n_pruned = fo->st.n_list;
+      c->cnt.n_scored = fo->st.n_list;
+      c->cnt.sum_k1 = (int64_t)fo->st.sum_k1;
+      c->cnt.sum_k2 = (int64_t)fo->st.sum_k2;
+      c->cnt.sum_kcrop = (int64_t)fo->st.sum_kcrop;
+      c->cnt.sum_p = (int64_t)fo->st.sum_p;
+      c->cnt.n_overflow_samples = fo->st.n_overflow;
+      const size_t k = fo->n_out;
+      c->cnt.n_selected = (int64_t)k;
+      *n_selected = k;
+      if (n_scored) *n_scored = fo->st.n_list;
+      c->fm_on = false;
+      if (k > cap) return set_err(c, AG2_ERR_CAPACITY, "detect_frame: output capacity too small");
+      if (k) memcpy(selected, f->h_pin + f->off_rec, k * sizeof(ag2_hypothesis));
+      return 0;
+    }
+  }
+  // ---- step-by-step path: the first frame, frames that outgrow the shapes, unsupported settings ----
+  f->info.stepwise_runs++;
+  const int rc = frame_stepwise(c, d_xyz, n, stride_bytes, sample_idx, s, seed, do_prune, selected, cap,
+                                n_selected, n_scored);
+  if (rc) return rc;
+  if (!unsupported) {
+    // shapes for the frames to come: this frame's, with room for the cloud to move and grow
+    c->fm_n_max = std::max(c->fm_n_max, n + n / 8 + 1024);
+    c->fm_s_max = std::max(c->fm_s_max, s);
+    long long cells = 1;
+    for (int a = 0; a < 3; a++) cells *= (long long)(c->grid.dims[a] + 8);
+    cells = std::min<long long>(cells + cells / 2, 1ll << 30);
+    c->fm_cap_cells = std::max<size_t>(c->fm_cap_cells, (size_t)cells);
+    f->cap_img = c->fm_s_max * (size_t)R;
+    f->k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, f->cap_img) : f->cap_img;
+    f->shapes_known = c->fm_s_max * (size_t)R <= 65536;
+  }
+  return 0;
+}
+
+int ag2_get_frame_info(ag2_ctx* c, ag2_frame_info* out) {
+  if (!c || !out) return AG2_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  if (c->fm) {
+    *out = c->fm->info;
+    out->max_points = (int64_t)c->fm_n_max;
+    out->max_samples = (int64_t)c->fm_s_max;
+    out->max_cells = (int64_t)c->fm_cap_cells;
+    out->graph_ready = c->fm->graph_valid ? 1 : 0;
+  }
+  return 0;
+}
+
+}  // extern "C"

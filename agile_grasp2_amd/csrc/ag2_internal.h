@@ -173,6 +173,16 @@ struct ag2_ctx {
   size_t desc_stride = 0;  // > 0: the compaction also left the image descriptors in d_desc (offsets,
                            // then counts at + desc_stride)
 
+  // frame mode (ag2_frame.hip): the launchers use device-resident shapes (grid description, list
+  // lengths) and launch sizes fixed at the maxima below, so that a frame can be captured in a hipGraph
+  bool fm_on = false;
+  size_t fm_n_max = 0;       // points per frame (the cloud is padded with non-finite points up to it)
+  size_t fm_s_max = 0;       // samples per frame (the index list is padded with -1 up to it)
+  size_t fm_cap_cells = 0;   // grid cells
+  ag2::DevBuf d_griddesc;    // GridDesc written by k_grid_desc
+  const ag2::FrameArgs* fm_args_dev = nullptr;  // device view of the page-locked per-frame scalars
+  struct ag2_frame_state* fm = nullptr;         // owned by ag2_frame.hip
+
   ag2::LeNetDev net;
   ag2_counters cnt{};
   ag2_times times{};
@@ -222,7 +232,11 @@ inline hipError_t stage_sync(ag2_ctx* c, int i) {
 }
 int gather_normals(ag2_ctx* c);  // d_tmp (float4, original order) -> d_nrm (sorted order)
 int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, float4* dst,
-                    bool with_bounds = false);
+                    bool with_bounds = false, size_t n_pad = 0);
+// frame mode: cell count + scan + scatter + cell sort at the fixed maxima, grid description on the device
+int launch_grid_frame(ag2_ctx* c, unsigned* cell, unsigned* zeroed_ctl);
+// ag2_frame.hip
+void frame_release(ag2_ctx* c);
 size_t scan_ctl_words(int n);
 int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n, unsigned* zeroed_ctl = nullptr);
 // k_normals.hip
@@ -230,33 +244,38 @@ int launch_normals(ag2_ctx* c);
 // k_sweep.hip
 int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
                    bool clear_run = false);
+int launch_sample_queries(ag2_ctx* c, const int* d_idx, size_t s, bool clear_run);
 int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed);
 int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool run_cleared = false);
 // k_select.hip
 int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out);
 int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count,
                         bool with_descs = false);
-int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned* d_count);
+int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned* d_count,
+                           const unsigned* d_n = nullptr);
 int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypothesis>& recs,
                    std::vector<int64_t>* offs, std::vector<uint8_t>* keep);
 int export_candidates_compact(ag2_ctx* c, void* d_dst, size_t cap_records);
 int make_image_descs(ag2_ctx* c, const int* d_list, size_t n);
 // k_lenet_x3.hip
 int lenet_pack_weights_x3(ag2_ctx* c, const float* conv1_w, const float* conv2_w);
-int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_pooled2);
+int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_pooled2,
+                         const unsigned* d_n = nullptr);
 int lenet_pack_fc_x3(ag2_ctx* c, const float* w3p_7200x512);
-int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out);
+int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out,
+                        const unsigned* d_n = nullptr);
 // k_cluster.hip
 int cluster_async(ag2_ctx* c, const ag2_hypothesis* d_in, size_t n_max, const unsigned* d_n,
                   int min_inliers, unsigned* d_count);
 int launch_scatter_scores(ag2_ctx* c, const int* d_list, size_t n_img);
 // k_image.hip
 int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, const int* d_cnt,
-                  size_t n_img, uint8_t* d_out, int max_p);
+                  size_t n_img, uint8_t* d_out, int max_p, const unsigned* d_n = nullptr);
 // k_lenet.hip
 int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const float* c2w,
                        const float* c2b, const float* f1w, const float* f1b, const float* f2w,
                        const float* f2b);
-int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits, int ev_mid);
+int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits, int ev_mid,
+                 const unsigned* d_n = nullptr);
 
 }  // namespace ag2

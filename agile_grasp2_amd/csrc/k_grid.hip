@@ -32,19 +32,25 @@ __global__ void k_pack_xyz(const char* __restrict__ src, size_t stride, int n,
 // device statistics of the previous cloud.
 constexpr int kBoundsBlocks = 128;  // 128 records x 32 B = the small page-locked read-back area
 static_assert(kBoundsBlocks * 32 <= (int)kPinSmall, "extent partials must fit the small read-back area");
+// n_pad > n (frame mode): xyz[n .. n_pad) is filled with non-finite points, which no later stage
+// ever sees as a point -- the launches of a captured frame run over the fixed maximum n_pad.
 template <bool PACK>
 __global__ void __launch_bounds__(256) k_bounds(const char* __restrict__ src, size_t stride,
-                                                float4* __restrict__ xyz, int n, int* __restrict__ part,
-                                                DevStats* st) {
+                                                float4* __restrict__ xyz, int n, int n_pad,
+                                                int* __restrict__ part, DevStats* st) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *st = DevStats{};
   int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
   int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   int cnt = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
     float4 p;
     if (PACK) {
-      const float* q = (const float*)(src + (size_t)i * stride);
-      p = make_float4(q[0], q[1], q[2], __int_as_float(1));
+      if (i < n) {
+        const float* q = (const float*)(src + (size_t)i * stride);
+        p = make_float4(q[0], q[1], q[2], __int_as_float(1));
+      } else {
+        p = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
+      }
       xyz[i] = p;
     } else {
       p = xyz[i];
@@ -91,12 +97,15 @@ __global__ void __launch_bounds__(256) k_bounds(const char* __restrict__ src, si
 
 // key[i] = (cell key or -1, arrival rank inside the cell): the rank the counting atomic hands out
 // places the point in the scatter below without a second round of atomics.
-__global__ void k_cell_count(const float4* __restrict__ xyz, int n, GridDesc g,
-                             int2* __restrict__ key, unsigned* __restrict__ cell) {
+// gp (frame mode): the grid description is read from device memory, where k_grid_desc left it
+__global__ void k_cell_count(const float4* __restrict__ xyz, int n, GridDesc g_arg,
+                             const GridDesc* __restrict__ gp, int2* __restrict__ key,
+                             unsigned* __restrict__ cell) {
+  const GridDesc g = gp ? *gp : g_arg;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float4 p = (i < n) ? xyz[i] : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
   int k = -1, r = 0;
-  if (i < n && finite3(p.x, p.y, p.z)) {
+  if (i < n && g.ncells > 0 && finite3(p.x, p.y, p.z)) {
     const int cx = cell_of(p.x, g.o[0], g.inv), cy = cell_of(p.y, g.o[1], g.inv),
               cz = cell_of(p.z, g.o[2], g.inv);
     k = (cz * g.dims[1] + cy) * g.dims[0] + cx;
@@ -319,19 +328,37 @@ int gather_normals(ag2_ctx* c) {
 // with_bounds: the pack also produces the extent partials build_grid needs (c->bounds_blocks > 0
 // tells build_grid they are there), one pass over the source instead of two.
 int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, float4* dst,
-                    bool with_bounds) {
+                    bool with_bounds, size_t n_pad) {
   c->bounds_blocks = 0;
   if (n == 0) return 0;
+  if (n_pad < n) n_pad = n;  // (0 = no padding)
   if (with_bounds) {
-    const int nb = std::min(((int)n + 255) / 256, kBoundsBlocks);
+    const int nb = std::min(((int)n_pad + 255) / 256, kBoundsBlocks);  // (frame mode: a function of n_pad only)
     AG2_HIP(c, c->d_bounds.reserve((size_t)kBoundsBlocks * 8 * 4));
     hipLaunchKernelGGL(k_bounds<true>, dim3(nb), dim3(256), 0, c->stream, (const char*)d_xyz,
-                       stride_bytes, dst, (int)n, c->d_bounds.as<int>(), c->d_stats.as<DevStats>());
+                       stride_bytes, dst, (int)n, (int)n_pad, c->d_bounds.as<int>(), c->d_stats.as<DevStats>());
     c->bounds_blocks = nb;
   } else {
     hipLaunchKernelGGL(k_pack_xyz, dim3(((int)n + 255) / 256), dim3(256), 0, c->stream,
                        (const char*)d_xyz, stride_bytes, (int)n, dst);
   }
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+int launch_grid_frame(ag2_ctx* c, unsigned* cell, unsigned* zeroed_ctl) {
+  const int n = (int)c->fm_n_max, cap = (int)c->fm_cap_cells;
+  const GridDesc* gp = c->d_griddesc.as<GridDesc>();
+  const int g256 = (n + 255) / 256;
+  hipLaunchKernelGGL(k_cell_count, dim3(g256), dim3(256), 0, c->stream, c->d_xyz_in.as<float4>(), n,
+                     GridDesc{}, gp, c->d_key.as<int2>(), cell);
+  // the scan and the sort run over the whole table: cells beyond the frame's grid hold no point
+  const int rc = scan_exclusive_u32(c, cell, cap + 1, zeroed_ctl);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, c->stream, c->d_key.as<int2>(), n, cell,
+                     c->d_perm.as<int>());
+  hipLaunchKernelGGL(k_cell_sort, dim3((cap + 255) / 256), dim3(256), 0, c->stream, cell, cap,
+                     c->d_perm.as<int>(), c->d_xyz_in.as<float4>(), c->d_sorted.as<float4>());
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
@@ -365,7 +392,7 @@ int build_grid(ag2_ctx* c) {
       nb = std::min((n + 255) / 256, kBoundsBlocks);
       AG2_HIP(c, c->d_bounds.reserve((size_t)kBoundsBlocks * 8 * 4));
       hipLaunchKernelGGL(k_bounds<false>, dim3(nb), dim3(256), 0, c->stream, (const char*)nullptr,
-                         (size_t)0, c->d_xyz_in.as<float4>(), n, c->d_bounds.as<int>(), st);
+                         (size_t)0, c->d_xyz_in.as<float4>(), n, n, c->d_bounds.as<int>(), st);
     }
     AG2_HIP(c, hipMemcpyAsync(pin_small(c), c->d_bounds.p, (size_t)nb * 32, hipMemcpyDeviceToHost,
                               c->stream));
@@ -401,6 +428,7 @@ int build_grid(ag2_ctx* c) {
     ncells *= g.dims[a];
   }
   c->min_z = g.o[2];  // pcl::getMinMax3D of the (whole) cloud, grasp_detector.cpp:152-153
+  g.min_z = c->min_z;
   if (ncells > (1ll << 30))
     return set_err(c, AG2_ERR_CAPACITY, "search grid has more than 2^30 cells; raise grid_cell");
   g.ncells = (int)ncells;
@@ -419,7 +447,7 @@ int build_grid(ag2_ctx* c) {
   AG2_HIP(c, hipMemsetAsync(cell, 0, (cell_words + ctl_words) * 4, c->stream));
   const int g256 = (n + 255) / 256;
   hipLaunchKernelGGL(k_cell_count, dim3(g256), dim3(256), 0, c->stream, xyz, n, g,
-                     c->d_key.as<int2>(), cell);
+                     (const GridDesc*)nullptr, c->d_key.as<int2>(), cell);
   const int rc = scan_exclusive_u32(c, cell, (int)ncells + 1, cell + cell_words);
   if (rc) return rc;
   hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, c->stream, c->d_key.as<int2>(), n, cell,

@@ -119,9 +119,11 @@ __device__ __forceinline__ double block_min_y(const double* __restrict__ pts, in
 __global__ void __launch_bounds__(kImgThreads) k_render(const double* __restrict__ arena,
                                                         const long long* __restrict__ desc_off,
                                                         const int* __restrict__ desc_cnt, int n_img,
+                                                        const unsigned* __restrict__ d_n,
                                                         int p_min, unsigned char* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ImgShared& S = *reinterpret_cast<ImgShared*>(smem_raw);
+  if (d_n) n_img = min(n_img, (int)*d_n);  // frame mode: the list length is read on the device
   const int tid = threadIdx.x;
   {  // nothing to do for this workgroup (the usual case: the sparse kernel took every image)?
     bool any = false;
@@ -199,8 +201,10 @@ static_assert(kSparseMax * 3 * 8 >= kCells * 3, "output staging must fit the acc
 __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __restrict__ arena,
                                                                const long long* __restrict__ desc_off,
                                                                const int* __restrict__ desc_cnt,
-                                                               int n_img, unsigned char* __restrict__ out) {
+                                                               int n_img, const unsigned* __restrict__ d_n,
+                                                               unsigned char* __restrict__ out) {
   __shared__ SparseShared S;
+  if (d_n) n_img = min(n_img, (int)*d_n);  // frame mode: the list length is read on the device
   const int tid = threadIdx.x;
   constexpr int kPer = kSparseMax / kImgThreads;  // points per thread
   for (int im = blockIdx.x; im < n_img; im += gridDim.x) {
@@ -380,9 +384,10 @@ template <int NMAX, int NBITS, int NT>
 __global__ void __launch_bounds__(NT) k_render_sorted(const double* __restrict__ arena,
                                                                const long long* __restrict__ desc_off,
                                                                const int* __restrict__ desc_cnt,
-                                                               int n_img, int p_min,
-                                                               unsigned char* __restrict__ out) {
+                                                               int n_img, const unsigned* __restrict__ d_n,
+                                                               int p_min, unsigned char* __restrict__ out) {
   static_assert((1 << NBITS) >= NMAX && NBITS + 12 < 32, "key layout");
+  if (d_n) n_img = min(n_img, (int)*d_n);  // frame mode: the list length is read on the device
   constexpr unsigned kPosMask = (1u << NBITS) - 1u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_sorted[];
   SortedShared<NMAX, NT>& S = *reinterpret_cast<SortedShared<NMAX, NT>*>(smem_sorted);
@@ -506,8 +511,9 @@ __global__ void __launch_bounds__(NT) k_render_sorted(const double* __restrict__
 
 // max_p: an upper bound of the images' point counts (the sweep's statistics have it): renderers
 // none of whose images can occur are not launched.
+// d_n (frame mode): n_img is the capacity of the list, its length is read from *d_n on the device.
 int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, const int* d_cnt,
-                  size_t n_img, uint8_t* d_out, int max_p) {
+                  size_t n_img, uint8_t* d_out, int max_p, const unsigned* d_n) {
   if (n_img == 0) return 0;
   const size_t lds = sizeof(ImgShared);
   static bool attr_set = false;
@@ -521,19 +527,19 @@ int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, con
   }
   // images with at most kSparseMax points (nearly all) ...
   hipLaunchKernelGGL(k_render_sparse, dim3((int)std::min<size_t>(n_img, 256 * 12)), dim3(kImgThreads), 0,
-                     c->stream, d_arena, d_off, d_cnt, (int)n_img, d_out);
+                     c->stream, d_arena, d_off, d_cnt, (int)n_img, d_n, d_out);
   // ... the rest; each kernel skips the others' images by the point count alone
   if (max_p > kSparseMax)
     hipLaunchKernelGGL((k_render_sorted<kSortedMax, 12, kImgThreads>), dim3((int)std::min<size_t>(n_img, 256 * 3)),
                        dim3(kImgThreads), sizeof(SortedShared<kSortedMax, kImgThreads>), c->stream, d_arena, d_off, d_cnt,
-                       (int)n_img, kSparseMax + 1, d_out);
+                       (int)n_img, d_n, kSparseMax + 1, d_out);
   if (max_p > kSortedMax)
     hipLaunchKernelGGL((k_render_sorted<kSortedMaxBig, 14, 1024>), dim3((int)std::min<size_t>(n_img, 256)),
                        dim3(1024), sizeof(SortedShared<kSortedMaxBig, 1024>), c->stream, d_arena, d_off,
-                       d_cnt, (int)n_img, kSortedMax + 1, d_out);
+                       d_cnt, (int)n_img, d_n, kSortedMax + 1, d_out);
   if (max_p > kSortedMaxBig)
     hipLaunchKernelGGL(k_render, dim3((int)std::min<size_t>(n_img, 256 * 2)), dim3(kImgThreads), lds, c->stream,
-                       d_arena, d_off, d_cnt, (int)n_img, kSortedMaxBig + 1, d_out);
+                       d_arena, d_off, d_cnt, (int)n_img, d_n, kSortedMaxBig + 1, d_out);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }

@@ -235,9 +235,14 @@ k_lenet_fc1(const float* __restrict__ x, int n_img, int n_pad, const float* __re
 // ip1 finish (+ bias, ReLU in place: prototxt relu1) and ip2: one wave per image, partial sums
 // added in split order, the 512-wide dot products reduced with a fixed shuffle tree.
 __global__ void __launch_bounds__(256)
-k_lenet_fc_finish(const float* __restrict__ part, int n_img, int n_pad, int ksplit,
+k_lenet_fc_finish(const float* __restrict__ part, int n_img, const unsigned* __restrict__ d_n,
+                  int n_pad, int ksplit,
                   const float* __restrict__ b3, const float* __restrict__ w4,
                   const float* __restrict__ b4, float* __restrict__ logits) {
+  if (d_n) {  // frame mode: batch size and split as k_lenet_fc1_x3 derived them
+    n_img = min(n_img, (int)*d_n);
+    ksplit = fc1_x3_ksplit((n_img + 127) / 128);
+  }
   const int lane = threadIdx.x & 63;
   const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (img >= n_img) return;
@@ -331,7 +336,11 @@ int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const flo
   return 0;
 }
 
-int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits, int ev_mid) {
+// d_n (frame mode, three-term bf16 path only): n is the capacity of the image list, its length
+// is read from *d_n on the device.
+int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits, int ev_mid,
+                 const unsigned* d_n) {
+  if (d_n && !c->net.use_x3) return set_err(c, AG2_ERR_STATE, "frame mode needs the default LeNet path");
   if (n == 0) {
     if (ev_mid >= 0) AG2_HIP(c, stage_event(c, ev_mid));
     return 0;
@@ -346,7 +355,7 @@ int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits,
     attr_set = true;
   }
   if (d.use_x3) {  // bf16 matrix cores, operands split into three exact bf16 terms (k_lenet_x3.hip)
-    const int rc = launch_lenet_conv_x3(c, d_images, n, c->d_act1.as<float>());
+    const int rc = launch_lenet_conv_x3(c, d_images, n, c->d_act1.as<float>(), d_n);
     if (rc) return rc;
   } else {
     const int grid = (int)std::min<size_t>(n, 512);
@@ -357,7 +366,7 @@ int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits,
   if (ev_mid >= 0) AG2_HIP(c, stage_event(c, ev_mid));
   int n_pad = 0, ksplit = 0;
   if (d.use_x3) {  // ip1 with the same three-term split on the bf16 matrix cores
-    const int rc = launch_lenet_fc1_x3(c, n, &n_pad, &ksplit);
+    const int rc = launch_lenet_fc1_x3(c, n, &n_pad, &ksplit, d_n);
     if (rc) return rc;
   } else {
     const int mtiles = (int)((n + kFcBM - 1) / kFcBM);
@@ -376,7 +385,7 @@ int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits,
                        c->d_fcpart.as<float>());
   }
   hipLaunchKernelGGL(k_lenet_fc_finish, dim3(((int)n + 3) / 4), dim3(256), 0, c->stream,
-                     c->d_fcpart.as<float>(), (int)n, n_pad, ksplit, d.b3.as<float>(),
+                     c->d_fcpart.as<float>(), (int)n, d_n, n_pad, ksplit, d.b3.as<float>(),
                      d.w4.as<float>(), d.b4.as<float>(), d_logits);
   AG2_HIP(c, hipGetLastError());
   return 0;

@@ -237,11 +237,13 @@ __device__ __forceinline__ void x3_conv1(X3Shared& S, const uint4* __restrict__ 
 }
 
 __global__ void __launch_bounds__(kXThreads, 2)
-k_lenet_conv_x3(const unsigned char* __restrict__ images, int n_img, const uint4* __restrict__ w1x,
+k_lenet_conv_x3(const unsigned char* __restrict__ images, int n_img, const unsigned* __restrict__ d_n,
+                const uint4* __restrict__ w1x,
                 const float* __restrict__ b1, const uint4* __restrict__ w2x,
                 const float* __restrict__ b2, float* __restrict__ pooled2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   X3Shared& S = *reinterpret_cast<X3Shared*>(smem_raw);
+  if (d_n) n_img = min(n_img, (int)*d_n);  // frame mode: the list length is read on the device
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31;
   const float bias1 = b1[r];
@@ -338,9 +340,19 @@ struct FxShared {
 };
 
 __global__ void __launch_bounds__(256, 2)
-k_lenet_fc1_x3(const float* __restrict__ x, int n_img, int n_pad, const uint4* __restrict__ w3x,
-               int chunks_per_split, float* __restrict__ part) {
+k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restrict__ d_n, int n_pad,
+               const uint4* __restrict__ w3x, int chunks_per_split, float* __restrict__ part) {
   __shared__ FxShared S;
+  if (d_n) {
+    // frame mode: the launch covers the list's capacity and the finest split; the batch size is read
+    // here and the split chosen by the SAME rule the host applies to a known batch size, so the
+    // partial sums (and with them every logit) are bit-identical to those of an exact-size launch
+    n_img = min(n_img, (int)*d_n);
+    const int mtiles = (n_img + kFxBM - 1) / kFxBM;
+    const int ks = fc1_x3_ksplit(mtiles);
+    if ((int)blockIdx.x >= mtiles || (int)blockIdx.z >= ks) return;  // uniform
+    chunks_per_split = 150 / ks;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
   const int img0 = blockIdx.x * kFxBM;
@@ -448,22 +460,17 @@ int lenet_pack_fc_x3(ag2_ctx* c, const float* w3p) {
   return 0;
 }
 
-// partial sums into d_fcpart; *n_pad_out, *ksplit_out describe them for k_lenet_fc_finish
-int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out) {
+// partial sums into d_fcpart; *n_pad_out, *ksplit_out describe them for k_lenet_fc_finish.
+// d_n (frame mode): n is the capacity, the batch size is read on the device (grid: capacity x the
+// finest split, the surplus workgroups leave at once).
+int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out, const unsigned* d_n) {
   LeNetDev& d = c->net;
   const int mtiles = (int)((n + kFxBM - 1) / kFxBM);
   const int n_pad = mtiles * kFxBM;
-  // split K (150 chunks of 48) so that small batches still put about two workgroups on every CU
-  static const int kSplits[] = {1, 2, 3, 5, 6, 10, 15, 25, 30};
-  int ksplit = 30;
-  for (int ks : kSplits)
-    if ((long long)mtiles * 4 * ks >= 448) {
-      ksplit = ks;
-      break;
-    }
+  const int ksplit = d_n ? kFc1X3MaxSplit : fc1_x3_ksplit(mtiles);
   AG2_HIP(c, c->d_fcpart.reserve((size_t)ksplit * n_pad * kFxN * 4));
   hipLaunchKernelGGL(k_lenet_fc1_x3, dim3(mtiles, 4, ksplit), dim3(256), 0, c->stream,
-                     c->d_act1.as<float>(), (int)n, n_pad, d.w3x.as<uint4>(), 150 / ksplit,
+                     c->d_act1.as<float>(), (int)n, d_n, n_pad, d.w3x.as<uint4>(), 150 / ksplit,
                      c->d_fcpart.as<float>());
   AG2_HIP(c, hipGetLastError());
   *n_pad_out = n_pad;
@@ -471,7 +478,8 @@ int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out) {
   return 0;
 }
 
-int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_pooled2) {
+int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_pooled2,
+                         const unsigned* d_n) {
   LeNetDev& d = c->net;
   const size_t lds = sizeof(X3Shared);
   static bool attr_set = false;
@@ -482,7 +490,7 @@ int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d
   }
   const int grid = (int)std::min<size_t>(n, 256);
   hipLaunchKernelGGL(k_lenet_conv_x3, dim3(grid), dim3(kXThreads), lds, c->stream, d_images, (int)n,
-                     d.w1x.as<uint4>(), d.b1.as<float>(), d.w2x.as<uint4>(), d.b2.as<float>(),
+                     d_n, d.w1x.as<uint4>(), d.b1.as<float>(), d.w2x.as<uint4>(), d.b2.as<float>(),
                      d_pooled2);
   AG2_HIP(c, hipGetLastError());
   return 0;

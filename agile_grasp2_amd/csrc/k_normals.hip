@@ -14,9 +14,13 @@
 namespace ag2 {
 
 __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
-                                                 const unsigned* __restrict__ cell, GridDesc g,
+                                                 const unsigned* __restrict__ cell, GridDesc g_arg,
+                                                 const GridDesc* __restrict__ gp,
                                                  float r2f, float rq, float4* __restrict__ nrm,
                                                  DevStats* st) {
+  // gp (frame mode): grid description left in device memory by k_grid_desc; the launch covers the
+  // frame's maximum point count and the threads beyond n_valid leave
+  const GridDesc g = gp ? *gp : g_arg;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int cnt = 0;
   if (i < g.n_valid) {
@@ -162,10 +166,12 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
 }
 
 int launch_normals(ag2_ctx* c) {
-  if (c->n_valid == 0) return 0;
-  const int nb = ((int)c->n_valid + 255) / 256;
+  if (!c->fm_on && c->n_valid == 0) return 0;
+  const int nb = ((int)(c->fm_on ? c->fm_n_max : c->n_valid) + 255) / 256;
   hipLaunchKernelGGL(k_normals, dim3(nb), dim3(256), 0, c->stream, c->d_sorted.as<float4>(),
-                     c->d_cell.as<unsigned>(), c->grid, c->hc.r2_normals, c->hc.rq_normals,
+                     c->d_cell.as<unsigned>(), c->grid,
+                     c->fm_on ? c->d_griddesc.as<GridDesc>() : (const GridDesc*)nullptr,
+                     c->hc.r2_normals, c->hc.rq_normals,
                      c->d_nrm.as<float4>(), c->d_stats.as<DevStats>());
   AG2_HIP(c, hipGetLastError());
   return 0;

@@ -150,11 +150,18 @@ int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t
 // ---- tail of detectGraspPoses: score, threshold, ordered gather (grasp_detector.cpp:198-207) ----
 // per scored image i (list order = output order): score = ip2[1] - ip2[0] (:200) written into the
 // table slot, flag = score >= min_score_diff (:202)
+// d_n (frame mode): n is the list's capacity, *d_n its length; flags beyond the length are zero so
+// that the scan over the whole capacity leaves the total in pref[capacity].
 __global__ void k_score_flags(const float* __restrict__ logits, const int* __restrict__ list, int n,
+                              const unsigned* __restrict__ d_n,
                               ag2_hypothesis* __restrict__ table, unsigned char* __restrict__ keep,
                               double thr, unsigned* __restrict__ flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
+  if (d_n && i >= (int)*d_n) {
+    flags[i] = 0;
+    return;
+  }
   unsigned f = 0;
   if (i < n) {
     const int s = list[i];
@@ -187,10 +194,13 @@ __global__ void k_gather_selected(const unsigned* __restrict__ pref, const int* 
 // so a block scan of the per-thread counts gives every selected record its position in list order.
 constexpr int kSelThreads = 1024, kSelPer = 8, kSelSmall = kSelThreads * kSelPer;
 __global__ void __launch_bounds__(kSelThreads) k_select_small(
-    const float* __restrict__ logits, const int* __restrict__ list, int n, ag2_hypothesis* __restrict__ table,
+    const float* __restrict__ logits, const int* __restrict__ list, int n, const unsigned* __restrict__ d_n,
+    ag2_hypothesis* __restrict__ table,
     unsigned char* __restrict__ keep, double thr, ag2_hypothesis* __restrict__ out,
     unsigned* __restrict__ count) {
   __shared__ unsigned wsum[kSelThreads / kWave];
+  const int n_cap = n;  // the count trailer sits behind the list's capacity
+  if (d_n) n = min(n, (int)*d_n);
   const int tid = threadIdx.x;
   int slot[kSelPer];
   unsigned sel = 0, tot = 0;
@@ -234,12 +244,14 @@ __global__ void __launch_bounds__(kSelThreads) k_select_small(
     }
   if (tid == 0) {
     *count = total;
-    *reinterpret_cast<unsigned*>(out + n) = total;  // trailer: one copy brings records + count
+    *reinterpret_cast<unsigned*>(out + n_cap) = total;  // trailer: one copy brings records + count
   }
 }
 
 // Leaves the selected records (score >= threshold, list order) in d_tmp and their count in *d_count.
-int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned* d_count) {
+// d_n (frame mode): n_img is the capacity of the list, its length is read from *d_n on the device.
+int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned* d_count,
+                           const unsigned* d_n) {
   if (n_img == 0) {
     AG2_HIP(c, hipMemsetAsync(d_count, 0, 4, c->stream));
     return 0;
@@ -247,7 +259,7 @@ int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned
   AG2_HIP(c, c->d_tmp.reserve(n_img * sizeof(ag2_hypothesis) + 16));  // + the count trailer
   if (n_img <= (size_t)kSelSmall) {
     hipLaunchKernelGGL(k_select_small, dim3(1), dim3(kSelThreads), 0, c->stream, c->d_logits.as<float>(),
-                       d_list, (int)n_img, c->d_table.as<ag2_hypothesis>(),
+                       d_list, (int)n_img, d_n, c->d_table.as<ag2_hypothesis>(),
                        c->d_tab_keep.as<unsigned char>(), c->p.min_score_diff,
                        c->d_tmp.as<ag2_hypothesis>(), d_count);
     AG2_HIP(c, hipGetLastError());
@@ -257,7 +269,7 @@ int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned
   unsigned* fl = c->d_flags.as<unsigned>();
   const int nb = ((int)n_img + 1 + 255) / 256;
   hipLaunchKernelGGL(k_score_flags, dim3(nb), dim3(256), 0, c->stream, c->d_logits.as<float>(), d_list,
-                     (int)n_img, c->d_table.as<ag2_hypothesis>(), c->d_tab_keep.as<unsigned char>(),
+                     (int)n_img, d_n, c->d_table.as<ag2_hypothesis>(), c->d_tab_keep.as<unsigned char>(),
                      c->p.min_score_diff, fl);
   const int rc = scan_exclusive_u32(c, fl, (int)n_img + 1);
   if (rc) return rc;

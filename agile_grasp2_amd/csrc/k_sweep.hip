@@ -74,12 +74,21 @@ __device__ __forceinline__ QueryRange query_range(const GridDesc& g, float qx, f
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_frames(const float4* __restrict__ pts,
                                                const float4* __restrict__ nrm,
-                                               const unsigned* __restrict__ cell, GridDesc g,
+                                               const unsigned* __restrict__ cell, GridDesc g_arg,
+                                               const GridDesc* __restrict__ gp,
                                                const HandConst* __restrict__ hc,
                                                const float4* __restrict__ sample_q, int s,
                                                unsigned long long slot_base,
-                                               unsigned long long seed, double* __restrict__ frames,
+                                               unsigned long long seed,
+                                               const FrameArgs* __restrict__ fa,
+                                               double* __restrict__ frames,
                                                int* __restrict__ frame_ok, DevStats* st) {
+  // frame mode: grid description and the per-frame scalars come from memory (see FrameArgs)
+  const GridDesc g = gp ? *gp : g_arg;
+  if (fa) {
+    seed = fa->seed;
+    slot_base = fa->slot_base;
+  }
   __shared__ int buf[64];
   __shared__ double Nsh[50][3];
   __shared__ double Msh[6];
@@ -338,6 +347,8 @@ struct SweepArgs {
   const float4* nrm;
   const unsigned* cell;
   GridDesc g;
+  const GridDesc* gp;        // frame mode: g and min_z are read from here
+  const FrameArgs* fa;       // frame mode: slot_base is read from here
   const HandConst* hc;
   const float4* sample_q;
   const double* frames;
@@ -473,6 +484,10 @@ k_sweep(SweepArgs A) {
   }
 
   const HandConst& hc = *A.hc;
+  // frame mode: grid description, cloud minimum and slot base come from memory (uniform loads)
+  const GridDesc G = A.gp ? *A.gp : A.g;
+  const float cloud_min_z = A.gp ? G.min_z : A.min_z;
+  const int slot_base = A.fa ? (int)A.fa->slot_base : A.slot_base;
   const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int R = hc.R;
@@ -542,7 +557,7 @@ k_sweep(SweepArgs A) {
     const double F[3][3] = {{fr[3], fr[6], fr[9]}, {fr[4], fr[7], fr[10]}, {fr[5], fr[8], fr[11]}};
 
     // ---- row table: one contiguous span of the sorted cloud per (cy, cz) -------------------
-    const QueryRange qr = query_range(A.g, q.x, q.y, q.z, hc.rq_hands);
+    const QueryRange qr = query_range(G, q.x, q.y, q.z, hc.rq_hands);
     const int ny = qr.empty ? 0 : (qr.hi[1] - qr.lo[1] + 1);
     const int nz = qr.empty ? 0 : (qr.hi[2] - qr.lo[2] + 1);
     const int nrows = ny * nz;  // <= kMaxRows by check_params
@@ -556,9 +571,9 @@ k_sweep(SweepArgs A) {
         // every bound, three orders above the float rounding of these few operations): the exact
         // per-point tests below still decide, so the surviving set and its order are unchanged.
         const float mg = 3.0e-4f;
-        const float h = 1.0f / A.g.inv;
-        const float dyl = (A.g.o[1] + (float)cy * h) - q.y - mg, dyh = dyl + h + 2.0f * mg;
-        const float dzl = (A.g.o[2] + (float)cz * h) - q.z - mg, dzh = dzl + h + 2.0f * mg;
+        const float h = 1.0f / G.inv;
+        const float dyl = (G.o[1] + (float)cy * h) - q.y - mg, dyh = dyl + h + 2.0f * mg;
+        const float dzl = (G.o[2] + (float)cz * h) - q.z - mg, dzh = dzl + h + 2.0f * mg;
         const float dym = dyl > 0.f ? dyl : (dyh < 0.f ? -dyh : 0.f);
         const float dzm = dzl > 0.f ? dzl : (dzh < 0.f ? -dzh : 0.f);
         const float rm = hc.rq_hands + mg;
@@ -588,11 +603,11 @@ k_sweep(SweepArgs A) {
         if (empty) {
           cxb = cxa - 1;
         } else {
-          cxa = max(cxa, cell_of(q.x + xa - mg, A.g.o[0], A.g.inv));
-          cxb = min(cxb, cell_of(q.x + xb + mg, A.g.o[0], A.g.inv));
+          cxa = max(cxa, cell_of(q.x + xa - mg, G.o[0], G.inv));
+          cxb = min(cxb, cell_of(q.x + xb + mg, G.o[0], G.inv));
         }
       }
-      const int rowbase = (cz * A.g.dims[1] + cy) * A.g.dims[0];
+      const int rowbase = (cz * G.dims[1] + cy) * G.dims[0];
       int b = 0, e = 0;
       if (cxa <= cxb) {
         b = (int)A.cell[rowbase + cxa];
@@ -1291,7 +1306,7 @@ k_sweep(SweepArgs A) {
         }
         h.width = mxx - mnx;                                          // hand_search.cpp:397
         h.score = 0.0;
-        h.sample_slot = A.slot_base + t;
+        h.sample_slot = slot_base + t;
         h.orientation = oi;
         h.half_antipodal = (label >= 1) ? 1 : 0;                      // hand_search.cpp:417-418
         h.full_antipodal = (label == 2) ? 1 : 0;
@@ -1313,7 +1328,7 @@ k_sweep(SweepArgs A) {
             }
           }
           keep = h.width >= hc.min_aperture && h.width <= hc.max_aperture &&
-                 mn[2] >= (double)A.min_z && mn[1] >= (double)hc.ws_min_y &&
+                 mn[2] >= (double)cloud_min_z && mn[1] >= (double)hc.ws_min_y &&
                  mx[1] <= (double)hc.ws_max_y && mn[0] >= (double)hc.ws_min_x &&
                  mx[0] <= (double)hc.ws_max_x;
         }
@@ -1340,12 +1355,25 @@ int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed) {
   if (s == 0) return 0;
   hipLaunchKernelGGL(k_frames, dim3((unsigned)s), dim3(64), 0, c->stream, c->d_sorted.as<float4>(),
                      c->d_nrm.as<float4>(), c->d_cell.as<unsigned>(), c->grid,
+                     c->fm_on ? c->d_griddesc.as<GridDesc>() : (const GridDesc*)nullptr,
                      c->d_hc.as<HandConst>(), c->d_sample_q.as<float4>(), (int)s,
                      (unsigned long long)slot_base, (unsigned long long)seed,
+                     c->fm_on ? c->fm_args_dev : (const FrameArgs*)nullptr,
                      c->d_frames.as<double>(), c->d_frame_ok.as<int>(), c->d_stats.as<DevStats>());
   hipLaunchKernelGGL(k_frames_finish, dim3(((unsigned)s + 63) / 64), dim3(64), 0, c->stream,
                      c->d_hc.as<HandConst>(), c->d_sample_q.as<float4>(), (int)s, c->d_frames.as<double>(),
                      c->d_frame_ok.as<int>(), c->d_stats.as<DevStats>());
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+// d_idx: device-visible sample indices; clear_run as in upload_samples
+int launch_sample_queries(ag2_ctx* c, const int* d_idx, size_t s, bool clear_run) {
+  hipLaunchKernelGGL(k_sample_queries_idx, dim3(((unsigned)s + 255) / 256), dim3(256), 0, c->stream,
+                     d_idx, (int)s, c->d_xyz_in.as<float4>(), (int)(c->fm_on ? c->fm_n_max : c->n),
+                     c->d_sample_q.as<float4>(),
+                     clear_run ? c->d_tab_keep.as<unsigned char>() : (unsigned char*)nullptr,
+                     c->p.num_orientations, c->d_stats.as<DevStats>());
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
@@ -1371,12 +1399,8 @@ int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
       AG2_HIP(c, hipHostGetDevicePointer(&dev_view, pin_bulk(c), 0));
       d_idx = (const int*)dev_view;
     }
-    hipLaunchKernelGGL(k_sample_queries_idx, dim3(((unsigned)s + 255) / 256), dim3(256), 0, c->stream,
-                       d_idx, (int)s, c->d_xyz_in.as<float4>(), (int)c->n,
-                       c->d_sample_q.as<float4>(),
-                       clear_run ? c->d_tab_keep.as<unsigned char>() : (unsigned char*)nullptr,
-                       c->p.num_orientations, c->d_stats.as<DevStats>());
-    AG2_HIP(c, hipGetLastError());
+    const int rc = launch_sample_queries(c, d_idx, s, clear_run);
+    if (rc) return rc;
   } else {
     std::vector<float> q(s * 4);
     for (size_t i = 0; i < s; i++) {
@@ -1413,6 +1437,8 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   A.nrm = c->d_nrm.as<float4>();
   A.cell = c->d_cell.as<unsigned>();
   A.g = c->grid;
+  A.gp = c->fm_on ? c->d_griddesc.as<GridDesc>() : nullptr;
+  A.fa = c->fm_on ? c->fm_args_dev : nullptr;
   A.hc = c->d_hc.as<HandConst>();
   A.sample_q = c->d_sample_q.as<float4>();
   A.frames = c->d_frames.as<double>();
@@ -1430,7 +1456,7 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   A.min_z = c->min_z;
   A.flags = c->p.debug_flags & 1;
   static DevBuf prof_buf;  // diagnostic only: per-phase cycle sums when AG2_SWEEP_PROF is set
-  const bool want_prof = getenv("AG2_SWEEP_PROF") != nullptr;
+  const bool want_prof = !c->fm_on && getenv("AG2_SWEEP_PROF") != nullptr;
   if (want_prof) {
     AG2_HIP(c, prof_buf.reserve(16 * 8));
     AG2_HIP(c, hipMemsetAsync(prof_buf.p, 0, 16 * 8, c->stream));

@@ -107,6 +107,19 @@ typedef struct ag2_times {
   float preprocess_ms;  /* workspace filter + voxel grid (ag2_preprocess_cloud*), without the grid build */
 } ag2_times;
 
+/* Frame mode (BASELINE.json configuration 5), see ag2_detect_frame. */
+typedef struct ag2_frame_info {
+  int64_t frames;           /* ag2_detect_frame calls */
+  int64_t graph_replays;    /* ... served by launching the captured hipGraph */
+  int64_t plain_runs;       /* ... served by the same fixed-shape sequence, launched kernel by kernel */
+  int64_t stepwise_runs;    /* ... served by set_cloud_device + compute_normals + detect */
+  int64_t captures;         /* graphs captured and instantiated */
+  int64_t capture_failed, capture_refused;  /* refused: the legacy default stream cannot be captured */
+  int64_t fallbacks;        /* fixed-shape frames repeated step by step (a buffer or table was too small) */
+  int64_t max_points, max_samples, max_cells;  /* the fixed shapes in force */
+  int64_t graph_ready;
+} ag2_frame_info;
+
 int ag2_abi_version(void);
 void ag2_default_params(ag2_params* p);
 /* The constants the hand sweep derives from the parameters, computed on the host (no device is
@@ -180,6 +193,22 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
 /* Fixed-slot candidate table of the last detect call: s * num_orientations records, slot
  * (i * R + orientation), n_points == 0 where empty, score filled where scored.  Copied
  * device-to-device into d_dst (e.g. a torch tensor) for the RCCL all-gather. */
+/* One frame of a cloud stream = ag2_set_cloud_device + ag2_compute_normals + ag2_detect (with index
+ * samples, slot_base 0, without the scored-records output), same results byte for byte.  Replaces
+ * the body of the node's live-topic loop, src/nodes/grasp_detection_node.cpp:69-95 (run) / :123-143
+ * (detectGraspPosesInTopic -> GraspDetector::detectGraspPoses).  The per-frame pipeline runs at fixed
+ * maximum shapes with no host round trip before the results and is captured in a hipGraph that later
+ * frames replay; the first frame (and any frame that outgrows the shapes: more points, samples or
+ * grid cells, a longer point-list arena) runs step by step and sets them.  xyz: n points stride_bytes
+ * apart in device (xyz_on_device != 0) or host memory; single-camera clouds.
+ * ag2_stream_configure is optional: it presets the maxima (0 = learn from the first frame) and can
+ * turn the graph off (the fixed-shape sequence is then launched kernel by kernel). */
+int ag2_stream_configure(ag2_ctx* c, size_t max_points, size_t max_samples, int use_graph);
+int ag2_detect_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                     const int32_t* sample_idx, size_t s, uint64_t seed, int do_prune,
+                     ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored);
+int ag2_get_frame_info(ag2_ctx* c, ag2_frame_info* out);
+
 int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes);
 /* The same candidates in compact form (what a multi-GPU job should put on the wire: the table is
  * mostly empty): a 16-byte header {uint32 count, uint32 cap_records, 0, 0} followed by
