@@ -156,3 +156,71 @@ def draw_samples(seed: int, n_points: int, num_samples: int) -> np.ndarray:
     rng = np.random.default_rng(seed ^ 0x5A17)
     k = min(num_samples, n_points)
     return np.sort(rng.choice(n_points, size=k, replace=False)).astype(np.int32)
+
+
+def make_stream(seed: int, n_target: int, n_frames: int, motion: float = 0.004, voxel: float = VOXEL,
+                noise: float = 0.001):
+    """BASELINE.json configuration 5: n_frames clouds of ONE tabletop scene whose objects drift by
+    about `motion` metres per frame (each object its own direction in the table plane), seen by the
+    same camera with fresh sensor noise every frame, voxelised like make_scene.  Returns
+    (list of xyz float32 [N_k, 3], workspace[6]); N_k is within one per cent of n_target."""
+    rng = np.random.default_rng(seed)
+    per_pt = voxel * voxel
+    density = 4.0 / per_pt
+    area_table = 0.55 * n_target * per_pt
+    asp = 1.5
+    wx = max(np.sqrt(max(area_table, 1e-4) / asp), 0.25)
+    wy = wx * asp
+    x0, y0 = 0.48, -0.5 * wy
+    m = int(area_table * density)
+    table = np.stack([rng.uniform(x0, x0 + wx, m), rng.uniform(y0, y0 + wy, m), np.full(m, TABLE_Z)], axis=1)
+    objs, est, guard = [], int(area_table / per_pt), 0
+    while est < n_target and guard < 100000:
+        guard += 1
+        cx = rng.uniform(x0 + 0.08, x0 + wx - 0.08)
+        cy = rng.uniform(y0 + 0.08, y0 + wy - 0.08)
+        yaw = rng.uniform(0, np.pi)
+        k = int(rng.integers(0, 4))
+        dims = rng.uniform(0.0, 1.0, 3)
+        ang = rng.uniform(0, 2 * np.pi)
+        objs.append((k, cx, cy, yaw, dims, np.array([np.cos(ang), np.sin(ang), 0.0]), int(rng.integers(1 << 30))))
+        # visible area of the primitive, roughly (as in make_scene: counted after the visibility cut)
+        p, _ = _make_object(objs[-1], 0.0, density)
+        est += int(p.shape[0] / density / per_pt * 0.9)
+    clouds = []
+    for f in range(n_frames):
+        chunks = [table]
+        for o in objs:
+            p, _ = _make_object(o, f * motion, density)
+            chunks.append(p)
+        p = np.concatenate(chunks)
+        frng = np.random.default_rng([seed, f, 7])
+        p = p + frng.normal(scale=noise, size=p.shape)
+        cloud = voxelize(p.astype(np.float32), voxel)
+        # as make_scene: a random subset brings the count to the target -- here the target +- 0.7 %,
+        # a different count every frame
+        want = n_target + (f * 7919) % (n_target // 70 + 1) - n_target // 140
+        if cloud.shape[0] > want:
+            cloud = cloud[np.sort(frng.choice(cloud.shape[0], size=want, replace=False))]
+        clouds.append(np.ascontiguousarray(cloud, dtype=np.float32))
+    ws = np.array([x0 - 0.01, x0 + wx + 0.01, y0 - 0.01, y0 + wy + 0.01, TABLE_Z - 0.05, 1.0])
+    return clouds, ws
+
+
+def _make_object(o, shift: float, density: float):
+    """One primitive of make_stream, moved by `shift` along its drift direction, camera-visible side."""
+    k, cx, cy, yaw, dims, direction, oseed = o
+    rng = np.random.default_rng(oseed)  # the same surface samples in every frame: a rigid object
+    c = np.array([cx, cy, 0.0]) + shift * direction
+    if k == 0:
+        size = 0.03 + 0.05 * dims
+        p, n = _box(rng, np.array([c[0], c[1], TABLE_Z + 0.5 * size[2]]), size, yaw, density)
+    elif k in (1, 2):
+        r, h = 0.015 + 0.025 * dims[0], 0.05 + 0.15 * dims[1]
+        zc = TABLE_Z + (0.5 * h if k == 1 else r)
+        p, n = _cylinder(rng, np.array([c[0], c[1], zc]), r, h, k == 2, yaw, density)
+    else:
+        r = 0.02 + 0.02 * dims[0]
+        p, n = _sphere(rng, np.array([c[0], c[1], TABLE_Z + r]), r, density)
+    vis = _visible(p, n, CAMERA)
+    return p[vis], n[vis]
