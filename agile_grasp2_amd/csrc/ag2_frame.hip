@@ -48,7 +48,8 @@ struct FrameOut {  // copied back once per frame
 struct ag2_frame_state {
   bool use_graph = true;
   bool shapes_known = false;
-  size_t cap_img = 0;        // = fm_s_max * R
+  size_t cap_img = 0;        // images rendered / scored per frame at most (learned: a multiple of what the
+                             // frames so far needed, in whole batches of 256; at most fm_s_max * R)
   size_t k_cap = 0;          // records copied back per frame
   int do_prune = -1;         // of the captured sequence
   // page-locked block: FrameArgs | idx[s_max] | FrameOut | records[k_cap]
@@ -56,7 +57,7 @@ struct ag2_frame_state {
   size_t h_pin_bytes = 0;
   size_t off_idx = 0, off_out = 0, off_rec = 0;
   ag2::DevBuf d_raw;         // staging of a cloud handed over in host memory
-  ag2::DevBuf d_out;         // top-k records + FrameOut tail
+  int cap_p = 0;             // in-box points per image the captured renderers can take
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   bool graph_valid = false;
@@ -65,61 +66,6 @@ struct ag2_frame_state {
 };
 
 namespace ag2 {
-
-// ---- grid description on the device -----------------------------------------------------------
-// Reduces the extent partials of k_bounds (one 32-B record per workgroup) and derives the grid the
-// way build_grid does on the host: same float expressions, so the same cells.  ncells <= 0 tells
-// every consumer "no grid": -1 more cells than the captured table holds, -2 a point below the origin
-// given to ag2_set_grid_origin, 0 no finite point.
-__global__ void __launch_bounds__(64) k_grid_desc(const int* __restrict__ part, int nb, float inv,
-                                                  int origin_set, float ox, float oy, float oz,
-                                                  int cap_cells, GridDesc* __restrict__ out) {
-  const int lane = lane_id();
-  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-  int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-  int cnt = 0;
-  for (int b = lane; b < nb; b += 64) {
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      mn[a] = min(mn[a], part[b * 8 + a]);
-      mx[a] = max(mx[a], part[b * 8 + 3 + a]);
-    }
-    cnt += part[b * 8 + 6];
-  }
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
-      mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
-    }
-  }
-  cnt = wave_sum_i(cnt);
-  if (lane != 0) return;
-  GridDesc g{};
-  g.inv = inv;
-  if (cnt > 0) {
-    const float org[3] = {ox, oy, oz};
-    long long ncells = 1;
-    bool below = false;
-    for (int a = 0; a < 3; a++) {
-      const float bmin = ord2f(mn[a]), bmax = ord2f(mx[a]);
-      if (origin_set && bmin < org[a]) below = true;
-      g.o[a] = origin_set ? org[a] : bmin;
-      g.dims[a] = (int)__builtin_floorf((bmax - g.o[a]) * g.inv) + 1;
-      ncells *= g.dims[a];
-      if (ncells > (1ll << 30)) ncells = (1ll << 30) + 1;
-    }
-    g.min_z = g.o[2];  // pcl::getMinMax3D of the (whole) cloud, grasp_detector.cpp:152-153
-    g.n_valid = cnt;
-    g.ncells = below ? -2 : (ncells > (long long)cap_cells ? -1 : (int)ncells);
-    if (g.ncells <= 0) {
-      g.n_valid = 0;
-      g.dims[0] = g.dims[1] = g.dims[2] = 0;
-    }
-  }
-  *out = g;
-}
 
 // ---- top num_selected by score on the device ------------------------------------------------------
 // grasp_detector.cpp:239-252: partial_sort by score, descending; ties by position in the list (the
@@ -130,13 +76,19 @@ constexpr int kTopkThreads = 256;
 __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __restrict__ recs,
                                                        const unsigned* __restrict__ d_n, int cap,
                                                        int k_want, int k_cap,
-                                                       ag2_hypothesis* __restrict__ out, FrameOut* fo) {
+                                                       ag2_hypothesis* __restrict__ out, FrameOut* fo,
+                                                       const DevStats* __restrict__ st,
+                                                       const GridDesc* __restrict__ gp) {
+  // out / fo: page-locked host memory seen through its device view -- the last kernel of a frame
+  // writes the results where the host reads them, no copy operation follows
   __shared__ double sc[kTopkThreads];
   const int n = min((int)*d_n, cap);
   int k = (k_want >= 0 && k_want < n) ? k_want : n;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     fo->topk_overflow = (k > k_cap) ? (unsigned)k : 0u;
     fo->n_out = (unsigned)min(k, k_cap);
+    fo->st = *st;  // (every kernel that updates the statistics has finished)
+    fo->g = *gp;
   }
   k = min(k, k_cap);
   const int base = blockIdx.x * kTopkThreads;
@@ -155,13 +107,6 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
     }
   }
   if (i < n && rank < k) out[rank] = recs[i];
-}
-
-__global__ void k_frame_out(const DevStats* __restrict__ st, const GridDesc* __restrict__ g, FrameOut* fo) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    fo->st = *st;
-    fo->g = *g;
-  }
 }
 
 namespace {
@@ -195,11 +140,11 @@ unsigned long long frame_signature(const ag2_ctx* c, const ag2_frame_state* f) {
                         c->d_frame_ok.p, c->d_table.p, c->d_tab_off.p, c->d_tab_keep.p, c->d_arena.p,
                         c->d_overflow.p, c->d_gscratch.p, c->d_gpos.p, c->d_list2.p, c->d_images.p,
                         c->d_logits.p, c->d_act1.p, c->d_fcpart.p, c->d_tmp.p, c->d_flags.p, c->d_desc.p,
-                        c->d_scan.p, f->d_out.p, f->h_pin, c->net.w1x.p, c->net.w2x.p, c->net.w3x.p,
+                        c->d_scan.p, f->h_pin, c->net.w1x.p, c->net.w2x.p, c->net.w3x.p,
                         c->net.b1.p, c->net.b2.p, c->net.b3.p, c->net.w4.p, c->net.b4.p, (const void*)c->stream};
-  const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points,
+  const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points, f->cap_img,
                                      (unsigned long long)c->sweep_gcap, (unsigned long long)c->sweep_g2,
-                                     (unsigned long long)c->p.num_selected, f->k_cap,
+                                     (unsigned long long)c->p.num_selected, f->k_cap, (unsigned long long)f->cap_p,
                                      (unsigned long long)c->origin_set};
   unsigned long long h = 1469598103934665603ull;
   auto mix = [&h](unsigned long long v) {
@@ -235,10 +180,7 @@ int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
   const size_t n_slots = s_max * (size_t)R;
   DevStats* st = c->d_stats.as<DevStats>();
   GridDesc* gp = c->d_griddesc.as<GridDesc>();
-  // -- K0 search grid ---------------------------------------------------------------------------
-  hipLaunchKernelGGL(k_grid_desc, dim3(1), dim3(64), 0, c->stream, c->d_bounds.as<int>(), c->bounds_blocks,
-                     1.0f / (float)c->p.grid_cell, c->origin_set ? 1 : 0, c->origin[0], c->origin[1],
-                     c->origin[2], (int)cap_cells, gp);
+  // -- K0 search grid (its description derived from the extent partials inside k_cell_count) --------
   AG2_HIP(c, c->d_key.reserve(n_max * 8));
   const size_t cell_words = ((cap_cells + 1) + 3) & ~size_t(3);
   const size_t ctl_words = (scan_ctl_words((int)cap_cells + 1) + 3) & ~size_t(3);
@@ -268,31 +210,27 @@ int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
   rc = compact_slots_async(c, n_slots, do_prune ? 1 : 0, c->d_list2, &st->n_list, /*with_descs=*/true);
   if (rc) return rc;
   if (c->desc_stride == 0) return set_err(c, AG2_ERR_CAPACITY, "frame mode: more than 65536 table slots");
-  // -- K4 images, K5 LeNet, K6 score / threshold -----------------------------------------------------
-  AG2_HIP(c, c->d_images.reserve(n_slots * 10800));
-  AG2_HIP(c, c->d_logits.reserve(n_slots * 8));
+  // -- K4 images, K5 LeNet, K6 score / threshold (at most cap_img images: the kernels clamp the list
+  // length they read, the host sees a longer list in the statistics and repeats the frame) -----------
+  const size_t cap_img = std::min(f->cap_img, n_slots);
+  AG2_HIP(c, c->d_images.reserve(cap_img * 10800));
+  AG2_HIP(c, c->d_logits.reserve(cap_img * 8));
   const unsigned* d_n = &st->n_list;
   rc = launch_render(c, c->d_arena.as<double>(), c->d_desc.as<long long>(),
-                     (const int*)(c->d_desc.as<long long>() + c->desc_stride), n_slots,
-                     c->d_images.as<uint8_t>(), 0x7fffffff, d_n);
+                     (const int*)(c->d_desc.as<long long>() + c->desc_stride), cap_img,
+                     c->d_images.as<uint8_t>(), f->cap_p, d_n);
   if (rc) return rc;
-  rc = launch_lenet(c, c->d_images.as<uint8_t>(), n_slots, c->d_logits.as<float>(), -1, d_n);
+  rc = launch_lenet(c, c->d_images.as<uint8_t>(), cap_img, c->d_logits.as<float>(), -1, d_n);
   if (rc) return rc;
-  rc = score_and_select_async(c, c->d_list2.as<int>(), n_slots, &st->n_sel, d_n);
+  rc = score_and_select_async(c, c->d_list2.as<int>(), cap_img, &st->n_sel, d_n);
   if (rc) return rc;
-  // -- top-k on the device, one copy back ----------------------------------------------------------
-  AG2_HIP(c, f->d_out.reserve(f->k_cap * sizeof(ag2_hypothesis) + sizeof(FrameOut) + 64));
-  ag2_hypothesis* d_rec = f->d_out.as<ag2_hypothesis>();
-  FrameOut* d_fo = (FrameOut*)(d_rec + f->k_cap);
-  hipLaunchKernelGGL(k_topk, dim3((unsigned)((n_slots + kTopkThreads - 1) / kTopkThreads)), dim3(kTopkThreads), 0,
-                     c->stream, c->d_tmp.as<ag2_hypothesis>(), &st->n_sel, (int)n_slots, c->p.num_selected,
-                     (int)f->k_cap, d_rec, d_fo);
-  hipLaunchKernelGGL(k_frame_out, dim3(1), dim3(64), 0, c->stream, st, gp, d_fo);
+  // -- top-k on the device, written straight into the page-locked block ------------------------------
+  ag2_hypothesis* d_rec = (ag2_hypothesis*)((char*)c->fm_args_dev + f->off_rec);
+  FrameOut* d_fo = (FrameOut*)((char*)c->fm_args_dev + f->off_out);
+  hipLaunchKernelGGL(k_topk, dim3((unsigned)((cap_img + kTopkThreads - 1) / kTopkThreads)), dim3(kTopkThreads), 0,
+                     c->stream, c->d_tmp.as<ag2_hypothesis>(), &st->n_sel, (int)cap_img, c->p.num_selected,
+                     (int)f->k_cap, d_rec, d_fo, st, gp);
   AG2_HIP(c, hipGetLastError());
-  AG2_HIP(c, hipMemcpyAsync(f->h_pin + f->off_out, d_fo, sizeof(FrameOut), hipMemcpyDeviceToHost, c->stream));
-  if (f->k_cap)
-    AG2_HIP(c, hipMemcpyAsync(f->h_pin + f->off_rec, d_rec, f->k_cap * sizeof(ag2_hypothesis),
-                              hipMemcpyDeviceToHost, c->stream));
   return 0;
 }
 
@@ -315,7 +253,6 @@ void frame_release(ag2_ctx* c) {
   drop_graph(f);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
   f->d_raw.release();
-  f->d_out.release();
   delete f;
   c->fm = nullptr;
 }
@@ -336,6 +273,8 @@ int ag2_stream_configure(ag2_ctx* c, size_t max_points, size_t max_samples, int 
   c->fm_n_max = max_points;
   c->fm_s_max = max_samples;
   c->fm_cap_cells = 0;
+  f->cap_img = f->k_cap = 0;
+  f->cap_p = 0;
   memset(&f->info, 0, sizeof(f->info));
   return 0;
 }
@@ -400,7 +339,9 @@ int ag2_detect_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, s
     AG2_HIP(c, hipStreamSynchronize(c->stream));
     const FrameOut* fo = (const FrameOut*)(f->h_pin + f->off_out);
     const unsigned flags = fo->st.err_flags;
-    const bool bad = (flags & (1u | 8u)) != 0 || fo->g.ncells < 0 || fo->topk_overflow != 0;
+    const bool bad = (flags & (1u | 8u)) != 0 || fo->g.ncells < 0 || fo->topk_overflow != 0 ||
+                     (size_t)fo->st.n_list > std::min(f->cap_img, c->fm_s_max * (size_t)R) ||
+                     (int)fo->st.max_p > render_capacity_for(f->cap_p);
     if (bad) {
       if (fo->g.ncells == -2) {
         c->fm_on = false;
@@ -484,7 +425,11 @@ int ag2_detect_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, s
     for (int a = 0; a < 3; a++) cells *= (long long)(c->grid.dims[a] + 8);
     cells = std::min<long long>(cells + cells / 2, 1ll << 30);
     c->fm_cap_cells = std::max<size_t>(c->fm_cap_cells, (size_t)cells);
-    f->cap_img = c->fm_s_max * (size_t)R;
+    // images: twice what this frame scored, in whole batches of 256 (BASELINE.json configs[4]:
+    // batch_size 256), never below the shapes already in force
+    const size_t want_img = (((size_t)c->n_img * 2 + 512) + 255) / 256 * 256;
+    f->cap_p = std::max(f->cap_p, 2 * c->max_p);  // which renderers the sequence launches
+    f->cap_img = std::min(std::max(f->cap_img, want_img), c->fm_s_max * (size_t)R);
     f->k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, f->cap_img) : f->cap_img;
     f->shapes_known = c->fm_s_max * (size_t)R <= 65536;
   }
@@ -499,6 +444,7 @@ int ag2_get_frame_info(ag2_ctx* c, ag2_frame_info* out) {
     out->max_points = (int64_t)c->fm_n_max;
     out->max_samples = (int64_t)c->fm_s_max;
     out->max_cells = (int64_t)c->fm_cap_cells;
+    out->max_images = (int64_t)c->fm->cap_img;
     out->graph_ready = c->fm->graph_valid ? 1 : 0;
   }
   return 0;

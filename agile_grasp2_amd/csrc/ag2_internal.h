@@ -233,7 +233,8 @@ inline hipError_t stage_sync(ag2_ctx* c, int i) {
 int gather_normals(ag2_ctx* c);  // d_tmp (float4, original order) -> d_nrm (sorted order)
 int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, float4* dst,
                     bool with_bounds = false, size_t n_pad = 0);
-// frame mode: cell count + scan + scatter + cell sort at the fixed maxima, grid description on the device
+// frame mode: grid description derived on the device + cell count + scan + scatter + cell sort at the
+// fixed maxima
 int launch_grid_frame(ag2_ctx* c, unsigned* cell, unsigned* zeroed_ctl);
 // ag2_frame.hip
 void frame_release(ag2_ctx* c);
@@ -271,6 +272,7 @@ int launch_scatter_scores(ag2_ctx* c, const int* d_list, size_t n_img);
 // k_image.hip
 int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, const int* d_cnt,
                   size_t n_img, uint8_t* d_out, int max_p, const unsigned* d_n = nullptr);
+int render_capacity_for(int max_p);
 // k_lenet.hip
 int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const float* c2w,
                        const float* c2b, const float* f1w, const float* f1b, const float* f2w,

@@ -95,13 +95,84 @@ __global__ void __launch_bounds__(256) k_bounds(const char* __restrict__ src, si
   }
 }
 
+// Frame mode: the grid description is derived on the device from the extent partials of k_bounds (one
+// 32-B record per workgroup), the way build_grid derives it on the host -- same float expressions, so
+// the same cells.  ncells <= 0 tells every consumer "no grid": -1 more cells than the captured table
+// holds, -2 a point below the origin given to ag2_set_grid_origin, 0 no finite point.  Executed by
+// the first wave of EVERY workgroup of k_cell_count (4 KB of L2-resident partials: cheaper than a
+// launch of its own); workgroup 0 leaves the result in memory for the kernels that follow.
+struct GridFromParts {
+  const int* part;  // nullptr: not frame mode
+  int nb;
+  float inv;
+  int origin_set;
+  float org[3];
+  int cap_cells;
+  GridDesc* out;
+};
+__device__ __forceinline__ GridDesc grid_from_partials(const GridFromParts& f) {
+  const int lane = lane_id();
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+  int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  int cnt = 0;
+  for (int b = lane; b < f.nb; b += 64) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      mn[a] = min(mn[a], f.part[b * 8 + a]);
+      mx[a] = max(mx[a], f.part[b * 8 + 3 + a]);
+    }
+    cnt += f.part[b * 8 + 6];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
+    }
+  }
+  cnt = wave_sum_i(cnt);
+  GridDesc g{};
+  g.inv = f.inv;
+  if (cnt > 0) {
+    long long ncells = 1;
+    bool below = false;
+    for (int a = 0; a < 3; a++) {
+      const float bmin = ord2f(mn[a]), bmax = ord2f(mx[a]);
+      if (f.origin_set && bmin < f.org[a]) below = true;
+      g.o[a] = f.origin_set ? f.org[a] : bmin;
+      g.dims[a] = (int)__builtin_floorf((bmax - g.o[a]) * g.inv) + 1;
+      ncells *= g.dims[a];
+      if (ncells > (1ll << 30)) ncells = (1ll << 30) + 1;
+    }
+    g.min_z = g.o[2];  // pcl::getMinMax3D of the (whole) cloud, grasp_detector.cpp:152-153
+    g.n_valid = cnt;
+    g.ncells = below ? -2 : (ncells > (long long)f.cap_cells ? -1 : (int)ncells);
+    if (g.ncells <= 0) {
+      g.n_valid = 0;
+      g.dims[0] = g.dims[1] = g.dims[2] = 0;
+    }
+  }
+  return g;
+}
+
 // key[i] = (cell key or -1, arrival rank inside the cell): the rank the counting atomic hands out
 // places the point in the scatter below without a second round of atomics.
-// gp (frame mode): the grid description is read from device memory, where k_grid_desc left it
-__global__ void k_cell_count(const float4* __restrict__ xyz, int n, GridDesc g_arg,
-                             const GridDesc* __restrict__ gp, int2* __restrict__ key,
-                             unsigned* __restrict__ cell) {
-  const GridDesc g = gp ? *gp : g_arg;
+__global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ xyz, int n, GridDesc g_arg,
+                                                    GridFromParts fp, int2* __restrict__ key,
+                                                    unsigned* __restrict__ cell) {
+  __shared__ GridDesc g_sh;
+  if (fp.part) {  // frame mode (uniform)
+    if (wave_id() == 0) {
+      const GridDesc gd = grid_from_partials(fp);
+      if (lane_id() == 0) {
+        g_sh = gd;
+        if (blockIdx.x == 0) *fp.out = gd;
+      }
+    }
+    __syncthreads();
+  }
+  const GridDesc g = fp.part ? g_sh : g_arg;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float4 p = (i < n) ? xyz[i] : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
   int k = -1, r = 0;
@@ -348,10 +419,17 @@ int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes
 
 int launch_grid_frame(ag2_ctx* c, unsigned* cell, unsigned* zeroed_ctl) {
   const int n = (int)c->fm_n_max, cap = (int)c->fm_cap_cells;
-  const GridDesc* gp = c->d_griddesc.as<GridDesc>();
+  GridFromParts fp{};
+  fp.part = c->d_bounds.as<int>();
+  fp.nb = std::min((n + 255) / 256, kBoundsBlocks);  // as pack_device_xyz launched k_bounds for n_pad = n
+  fp.inv = 1.0f / (float)c->p.grid_cell;
+  fp.origin_set = c->origin_set ? 1 : 0;
+  for (int a = 0; a < 3; a++) fp.org[a] = c->origin[a];
+  fp.cap_cells = cap;
+  fp.out = c->d_griddesc.as<GridDesc>();
   const int g256 = (n + 255) / 256;
   hipLaunchKernelGGL(k_cell_count, dim3(g256), dim3(256), 0, c->stream, c->d_xyz_in.as<float4>(), n,
-                     GridDesc{}, gp, c->d_key.as<int2>(), cell);
+                     GridDesc{}, fp, c->d_key.as<int2>(), cell);
   // the scan and the sort run over the whole table: cells beyond the frame's grid hold no point
   const int rc = scan_exclusive_u32(c, cell, cap + 1, zeroed_ctl);
   if (rc) return rc;
@@ -447,7 +525,7 @@ int build_grid(ag2_ctx* c) {
   AG2_HIP(c, hipMemsetAsync(cell, 0, (cell_words + ctl_words) * 4, c->stream));
   const int g256 = (n + 255) / 256;
   hipLaunchKernelGGL(k_cell_count, dim3(g256), dim3(256), 0, c->stream, xyz, n, g,
-                     (const GridDesc*)nullptr, c->d_key.as<int2>(), cell);
+                     GridFromParts{}, c->d_key.as<int2>(), cell);
   const int rc = scan_exclusive_u32(c, cell, (int)ncells + 1, cell + cell_words);
   if (rc) return rc;
   hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, c->stream, c->d_key.as<int2>(), n, cell,

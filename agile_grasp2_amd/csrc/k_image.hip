@@ -511,6 +511,14 @@ __global__ void __launch_bounds__(NT) k_render_sorted(const double* __restrict__
 
 // max_p: an upper bound of the images' point counts (the sweep's statistics have it): renderers
 // none of whose images can occur are not launched.
+// largest point count the renderers launched for an upper bound of max_p can take
+int render_capacity_for(int max_p) {
+  if (max_p <= kSparseMax) return kSparseMax;
+  if (max_p <= kSortedMax) return kSortedMax;
+  if (max_p <= kSortedMaxBig) return kSortedMaxBig;
+  return 0x7fffffff;
+}
+
 // d_n (frame mode): n_img is the capacity of the list, its length is read from *d_n on the device.
 int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, const int* d_cnt,
                   size_t n_img, uint8_t* d_out, int max_p, const unsigned* d_n) {

@@ -343,21 +343,27 @@ __global__ void __launch_bounds__(256, 2)
 k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restrict__ d_n, int n_pad,
                const uint4* __restrict__ w3x, int chunks_per_split, float* __restrict__ part) {
   __shared__ FxShared S;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;  // image tile, column group, K split
   if (d_n) {
-    // frame mode: the launch covers the list's capacity and the finest split; the batch size is read
-    // here and the split chosen by the SAME rule the host applies to a known batch size, so the
-    // partial sums (and with them every logit) are bit-identical to those of an exact-size launch
+    // frame mode: a 1-D launch as large as any batch up to the list's capacity can need; the batch
+    // size is read here and the split chosen by the SAME rule the host applies to a known batch
+    // size, so the partial sums (and with them every logit) are bit-identical to those of an
+    // exact-size launch
     n_img = min(n_img, (int)*d_n);
     const int mtiles = (n_img + kFxBM - 1) / kFxBM;
     const int ks = fc1_x3_ksplit(mtiles);
-    if ((int)blockIdx.x >= mtiles || (int)blockIdx.z >= ks) return;  // uniform
+    const int w = blockIdx.x;
+    if (w >= mtiles * 4 * ks) return;  // uniform
+    bx = w % mtiles;
+    by = (w / mtiles) & 3;
+    bz = w / (mtiles * 4);
     chunks_per_split = 150 / ks;
   }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
-  const int img0 = blockIdx.x * kFxBM;
-  const int nt = blockIdx.y * 4 + wid;  // 32-column tile of this wave
-  const int chunk0 = blockIdx.z * chunks_per_split;
+  const int img0 = bx * kFxBM;
+  const int nt = by * 4 + wid;  // 32-column tile of this wave
+  const int chunk0 = bz * chunks_per_split;
   v16f acc[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -430,7 +436,7 @@ k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restric
       }
     }
   }
-  float* dst = part + ((size_t)blockIdx.z * n_pad + img0) * kFxN + nt * 32 + r;
+  float* dst = part + ((size_t)bz * n_pad + img0) * kFxN + nt * 32 + r;
 #pragma unroll
   for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -469,7 +475,13 @@ int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out, c
   const int n_pad = mtiles * kFxBM;
   const int ksplit = d_n ? kFc1X3MaxSplit : fc1_x3_ksplit(mtiles);
   AG2_HIP(c, c->d_fcpart.reserve((size_t)ksplit * n_pad * kFxN * 4));
-  hipLaunchKernelGGL(k_lenet_fc1_x3, dim3(mtiles, 4, ksplit), dim3(256), 0, c->stream,
+  dim3 grid(mtiles, 4, ksplit);
+  if (d_n) {  // the largest number of work items any batch of 1 .. mtiles tiles needs
+    int items = 0;
+    for (int m = 1; m <= mtiles; m++) items = std::max(items, m * 4 * fc1_x3_ksplit(m));
+    grid = dim3(items, 1, 1);
+  }
+  hipLaunchKernelGGL(k_lenet_fc1_x3, grid, dim3(256), 0, c->stream,
                      c->d_act1.as<float>(), (int)n, d_n, n_pad, d.w3x.as<uint4>(), 150 / ksplit,
                      c->d_fcpart.as<float>());
   AG2_HIP(c, hipGetLastError());

@@ -142,7 +142,10 @@ def bench_stream(args):
         return d
 
     legs, results = {}, {}
+    only = os.environ.get("AG2_STREAM_LEG")   # profiling aid: run one leg only
     for name in ("graph", "plain", "stepwise"):
+        if only and name != only:
+            continue
         d = make()
         if name != "stepwise":
             d.stream_configure(0, 0, name == "graph")
@@ -172,6 +175,9 @@ def bench_stream(args):
         c = d.counters()
         legs[name]["hypotheses_last_frame"] = int(c.n_hypotheses)
         d.close()
+    if only:
+        print(json.dumps({"leg": only, **legs[only]}), flush=True)
+        return
     same = results["graph"] == results["stepwise"] and results["plain"] == results["stepwise"]
     # frames handed over in HOST memory (the PCIe-inclusive figure, never `value`)
     d = make()

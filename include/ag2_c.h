@@ -116,7 +116,7 @@ typedef struct ag2_frame_info {
   int64_t captures;         /* graphs captured and instantiated */
   int64_t capture_failed, capture_refused;  /* refused: the legacy default stream cannot be captured */
   int64_t fallbacks;        /* fixed-shape frames repeated step by step (a buffer or table was too small) */
-  int64_t max_points, max_samples, max_cells;  /* the fixed shapes in force */
+  int64_t max_points, max_samples, max_cells, max_images;  /* the fixed shapes in force */
   int64_t graph_ready;
 } ag2_frame_info;
 
