@@ -727,8 +727,10 @@ k_sweep(SweepArgs A) {
         const bool ok = pc < n_pieces;
         pb[u] = ok ? S.piece_start[pc] : 0;
         pl[u] = ok ? (int)(LITE ? (S.piece_lc[pc] & 0xFFFFu) : S.piece_lc[pc]) : 0;
-        pv[u] = make_float4(0, 0, 0, 0);
-        if (lg < pl[u]) pv[u] = A.pts[pb[u] + lg];
+        // unconditional load from a clamped position (lanes beyond the piece re-read its last point,
+        // an empty slot reads point 0): no branch around the load, so the four loads of this loop are
+        // issued back to back and waited for once -- the pass is latency-bound
+        pv[u] = A.pts[pb[u] + max(min(lg, pl[u] - 1), 0)];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -851,8 +853,7 @@ k_sweep(SweepArgs A) {
         pb[u] = ok ? S.piece_start[pc] : 0;
         pl[u] = ok ? (int)S.piece_lc[pc] : 0;
         po[u] = ok ? (int)S.piece_mask[pc] : 0;
-        pv[u] = make_float4(0, 0, 0, 0);
-        if (lg < pl[u]) pv[u] = A.pts[pb[u] + lg];
+        pv[u] = A.pts[pb[u] + max(min(lg, pl[u] - 1), 0)];  // (clamped, unconditional: as in pass 1)
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -961,13 +962,18 @@ k_sweep(SweepArgs A) {
       // work; the set is shared across the workgroup through S.dead (an optimisation only: a late
       // reader just does redundant work).
       unsigned alive = (R >= 32) ? 0xFFFFFFFFu : ((1u << R) - 1u);
+      // The point of the NEXT iteration is requested before this iteration's arithmetic (the list
+      // position comes from LDS, the point from L2: two dependent latencies that would otherwise be
+      // exposed once per iteration); lanes beyond the list re-read its last point and are masked.
+      float qx, qy, qz;
+      ldp(min(tid, K - 1), qx, qy, qz);
       for (int j0 = 0; j0 < K; j0 += NT) {
         alive = (unsigned)__builtin_amdgcn_readfirstlane((int)(alive & ~S.dead));
         if (alive == 0u) break;
         const int j = j0 + tid;
         const bool valid = j < K;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (valid) ldp(j, px, py, pz);
+        const float px = qx, py = qy, pz = qz;
+        ldp(min(j + NT, K - 1), qx, qy, qz);
         const float u = (n0 * px + n1 * py) + n2 * pz;
         const float v = (b0 * px + b1 * py) + b2 * pz;
         unsigned need_exact = 0;  // orientations whose estimate is too close to a threshold
@@ -1089,19 +1095,26 @@ k_sweep(SweepArgs A) {
       // (the same pass yields surface = min y over ALL rotated points, finger_hand.cpp:158)
       int kfail = n_depths;
       double miny = __builtin_inf();
-      for (int j = tid; j < K; j += NT) {
-        float fx_, fy_, fz_;
-        ldp(j, fx_, fy_, fz_);
-        const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
-        const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
-        const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
-        miny = (y < miny) ? y : miny;
-        const bool zone = (x > fl0 && x < fl1) || (x > fr0 && x < fr1);
-        for (int di = 0; di < kfail; di++) {
-          const double d = S.depths[di];
-          if (y < d && (zone || y < d - hand_depth)) {
-            kfail = di;
-            break;
+      {
+        float qx, qy, qz;  // next iteration's point, requested one iteration ahead (as in pass A)
+        ldp(min(tid, K - 1), qx, qy, qz);
+        for (int j0 = 0; j0 < K; j0 += NT) {
+          const int j = j0 + tid;
+          const float fx_ = qx, fy_ = qy, fz_ = qz;
+          ldp(min(j + NT, K - 1), qx, qy, qz);
+          if (j < K) {
+            const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
+            const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
+            const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
+            miny = (y < miny) ? y : miny;
+            const bool zone = (x > fl0 && x < fl1) || (x > fr0 && x < fr1);
+            for (int di = 0; di < kfail; di++) {
+              const double d = S.depths[di];
+              if (y < d && (zone || y < d - hand_depth)) {
+                kfail = di;
+                break;
+              }
+            }
           }
         }
       }
@@ -1136,22 +1149,33 @@ k_sweep(SweepArgs A) {
       const int jb = min(wid * segk, K), je = min(jb + segk, K);
       int cnt = 0;
       double mnx = __builtin_inf(), mxx = -__builtin_inf();
-      for (int j0 = jb; j0 < je; j0 += 64) {
-        const int j = j0 + lane;
-        bool in = false;
-        if (j < je) {
-          float fx_, fy_, fz_;
-          ldp(j, fx_, fy_, fz_);
-          const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
-          const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
-          const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
-          in = (y < top && x > left && x < right);
-          if (in) {
-            mnx = (x < mnx) ? x : mnx;
-            mxx = (x > mxx) ? x : mxx;
+      // The membership masks of this pass are kept (one 64-bit ballot per step, in the piece-mask
+      // area the crop no longer needs) so that the writing pass below expands them instead of
+      // rotating every point a second time; a segment with more steps than fit recomputes.
+      unsigned long long* inmask = reinterpret_cast<unsigned long long*>(S.piece_mask) + wid * (kMaxPieces / 2 / NW);
+      const bool keep_masks = segk / 64 <= kMaxPieces / 2 / NW;
+      {
+        float qx, qy, qz;  // next step's point, requested one step ahead
+        ldp(min(jb + lane, K - 1), qx, qy, qz);
+        for (int j0 = jb; j0 < je; j0 += 64) {
+          const int j = j0 + lane;
+          bool in = false;
+          const float fx_ = qx, fy_ = qy, fz_ = qz;
+          ldp(min(j + 64, K - 1), qx, qy, qz);
+          if (j < je) {
+            const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
+            const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
+            const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
+            in = (y < top && x > left && x < right);
+            if (in) {
+              mnx = (x < mnx) ? x : mnx;
+              mxx = (x > mxx) ? x : mxx;
+            }
           }
+          const unsigned long long mask = __ballot(in);
+          if (keep_masks && lane == 0) inmask[(j0 - jb) >> 6] = mask;
+          cnt += __popcll(mask);
         }
-        cnt += __popcll(__ballot(in));
       }
       mnx = wave_min_d(mnx);
       mxx = wave_max_d(mxx);
@@ -1180,15 +1204,21 @@ k_sweep(SweepArgs A) {
         for (int j0 = jb; j0 < je; j0 += 64) {
           const int j = j0 + lane;
           bool in = false;
-          if (j < je) {
-            float fx_, fy_, fz_;
-            ldp(j, fx_, fy_, fz_);
-            const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
-            const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
-            const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
-            in = (y < top && x > left && x < right);
+          unsigned long long mask;
+          if (keep_masks) {  // (uniform) the masks of the counting pass: written and read by this wave only
+            mask = inmask[(j0 - jb) >> 6];
+            in = (mask >> lane) & 1ull;
+          } else {
+            if (j < je) {
+              float fx_, fy_, fz_;
+              ldp(j, fx_, fy_, fz_);
+              const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
+              const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
+              const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
+              in = (y < top && x > left && x < right);
+            }
+            mask = __ballot(in);
           }
-          const unsigned long long mask = __ballot(in);
           if (in) {
             const int dst = run + __popcll(mask & lt_mask);
             if (LITE && gmode) gbox[dst] = (unsigned short)j;
