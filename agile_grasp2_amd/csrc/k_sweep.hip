@@ -14,6 +14,7 @@
 // reductions (finger-slot occupancy mask, back-of-hand collision, deepen step, closing-region
 // extents, antipodal extents).  All geometry is f64 with the op order of ag2_device.h.
 #include "ag2_internal.h"
+#include "k_sweep_common.h"
 
 namespace ag2 {
 
@@ -49,24 +50,6 @@ __global__ void k_sample_queries_idx(const int* __restrict__ idx, int s,
     if (finite3(p.x, p.y, p.z)) o = make_float4(p.x, p.y, p.z, 1.f);
   }
   q[i] = o;
-}
-
-struct QueryRange {
-  int lo[3], hi[3];
-  bool empty;
-};
-__device__ __forceinline__ QueryRange query_range(const GridDesc& g, float qx, float qy, float qz,
-                                                  float rq) {
-  QueryRange r;
-  const float qq[3] = {qx, qy, qz};
-  r.empty = (g.n_valid == 0);
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    r.lo[a] = max(cell_of(qq[a] - rq, g.o[a], g.inv), 0);
-    r.hi[a] = min(cell_of(qq[a] + rq, g.o[a], g.inv), g.dims[a] - 1);
-    if (r.lo[a] > r.hi[a]) r.empty = true;
-  }
-  return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -342,36 +325,6 @@ __global__ void __launch_bounds__(64) k_frames_finish(const HandConst* __restric
 // ---------------------------------------------------------------------------------------------
 // K3: hand sweep
 // ---------------------------------------------------------------------------------------------
-struct SweepArgs {
-  const float4* pts;
-  const float4* nrm;
-  const unsigned* cell;
-  GridDesc g;
-  const GridDesc* gp;        // frame mode: g and min_z are read from here
-  const FrameArgs* fa;       // frame mode: slot_base is read from here
-  const HandConst* hc;
-  const float4* sample_q;
-  const double* frames;
-  const int* frame_ok;
-  int n_samples;
-  int slot_base;
-  ag2_hypothesis* table;     // [n_samples * R]
-  long long* tab_off;        // arena offset per slot (-1: no list)
-  unsigned char* tab_keep;   // prune flag per slot
-  double* arena;             // 6 doubles per in-box point
-  long long arena_cap;       // points
-  int emit_lists;
-  DevStats* st;
-  int* overflow;             // stage 0 appends, stage 1 works through it (length: st->n_overflow)
-  float* gscratch;           // global variant: 6 * gcap floats per block
-  int gcap;
-  int* gpos;                 // stage 0: kGposCap positions per workgroup, then kGposCap u16 in-box
-                             // indices per workgroup (lists a little longer than the LDS stage)
-  float min_z;
-  int flags;                 // bit0: no row tightening (exact K2 accounting, diagnostic)
-  unsigned long long* prof;  // optional per-phase cycle sums (AG2_SWEEP_PROF=1), else nullptr
-};
-
 // phase stamps for the diagnostic build of the launch (thread 0 of each workgroup)
 #define AG2_PROF(i)                                                    \
   do {                                                                 \
@@ -565,48 +518,7 @@ k_sweep(SweepArgs A) {
     for (int r = tid; r < nrows; r += NT) {
       const int cz = qr.lo[2] + r / ny, cy = qr.lo[1] + r % ny;
       int cxa = qr.lo[0], cxb = qr.hi[0];
-      if (tighten) {
-        // Shrink the row's x-cell range to what the sphere |p - q| < r and the crop slab
-        // |curv . (p - q)| < hand_height can reach.  Purely conservative (mg = 0.3 mm of slack on
-        // every bound, three orders above the float rounding of these few operations): the exact
-        // per-point tests below still decide, so the surviving set and its order are unchanged.
-        const float mg = 3.0e-4f;
-        const float h = 1.0f / G.inv;
-        const float dyl = (G.o[1] + (float)cy * h) - q.y - mg, dyh = dyl + h + 2.0f * mg;
-        const float dzl = (G.o[2] + (float)cz * h) - q.z - mg, dzh = dzl + h + 2.0f * mg;
-        const float dym = dyl > 0.f ? dyl : (dyh < 0.f ? -dyh : 0.f);
-        const float dzm = dzl > 0.f ? dzl : (dzh < 0.f ? -dzh : 0.f);
-        const float rm = hc.rq_hands + mg;
-        const float rho2 = rm * rm - dym * dym - dzm * dzm;
-        bool empty = !(rho2 > 0.f);
-        float xa = 0.f, xb = 0.f;
-        if (!empty) {
-          const float rho = __builtin_sqrtf(rho2);
-          xa = -rho;
-          xb = rho;
-          const float cxn = (float)F[0][2], cyn = (float)F[1][2], czn = (float)F[2][2];
-          const float hm = (float)hh + mg;
-          const float slo = cyn * (cyn >= 0.f ? dyl : dyh) + czn * (czn >= 0.f ? dzl : dzh);
-          const float shi = cyn * (cyn >= 0.f ? dyh : dyl) + czn * (czn >= 0.f ? dzh : dzl);
-          const float ulo = -hm - shi - mg, uhi = hm - slo + mg;  // cxn * dx must lie in (ulo, uhi)
-          const float acx = __builtin_fabsf(cxn);
-          if (uhi < -acx * rho || ulo > acx * rho) {
-            empty = true;
-          } else if (acx > 1.0e-4f) {
-            const float a = ulo / cxn, b2 = uhi / cxn;
-            const float sa = (a < b2 ? a : b2) - mg, sb = (a < b2 ? b2 : a) + mg;
-            xa = sa > xa ? sa : xa;
-            xb = sb < xb ? sb : xb;
-            if (xa > xb) empty = true;
-          }
-        }
-        if (empty) {
-          cxb = cxa - 1;
-        } else {
-          cxa = max(cxa, cell_of(q.x + xa - mg, G.o[0], G.inv));
-          cxb = min(cxb, cell_of(q.x + xb + mg, G.o[0], G.inv));
-        }
-      }
+      if (tighten) tighten_row(G, hc, q, F, hh, cy, cz, cxa, cxb);
       const int rowbase = (cz * G.dims[1] + cy) * G.dims[0];
       int b = 0, e = 0;
       if (cxa <= cxb) {
@@ -701,10 +613,17 @@ k_sweep(SweepArgs A) {
     AG2_PROF(0);
 
     // ---- crop to the +-hand_height slab, ordered compaction --------------------------------
+    const float cropn[3] = {(float)F[0][2], (float)F[1][2], (float)F[2][2]};
+    const float crop_hh = (float)hh;
     auto classify = [&](const float4& p, float4& d) -> int {  // 0 miss, 1 in radius, 3 + in slab
       d = make_float4(p.x - q.x, p.y - q.y, p.z - q.z, 0.f);
       const float d2 = (d.x * d.x + d.y * d.y) + d.z * d.z;
       if (!(d2 < r2_hands)) return 0;
+      {  // decided from an f32 estimate unless it is within 2e-6 m of the slab faces (error < 1e-7 m)
+        const float ze = __builtin_fabsf((cropn[0] * d.x + cropn[1] * d.y) + cropn[2] * d.z);
+        if (ze < crop_hh - 2.0e-6f) return 3;
+        if (ze > crop_hh + 2.0e-6f) return 1;
+      }
       // hand_search.cpp:209-210 centred in float then widened; :329-339 crop on row 2 of frame^T p
       const double p0 = (double)d.x, p1 = (double)d.y, p2 = (double)d.z;
       const double zf = (F[0][2] * p0 + F[1][2] * p1) + F[2][2] * p2;
@@ -982,9 +901,15 @@ k_sweep(SweepArgs A) {
         for (int i = 0; i < RMAX; i++) {
           if (i < R && ((alive >> i) & 1u)) {  // wave-uniform
             const float cf = S.cosf_t[i], sf = S.sinf_t[i];
-            const float xa = __builtin_fmaf(cf, u, sf * v), ya = __builtin_fmaf(cf, v, -(sf * u));
+            const float ya = __builtin_fmaf(cf, v, -(sf * u));
             // distance of the estimates to the nearest threshold, in y and in slot spacings
             const float dy = __builtin_fminf(__builtin_fabsf(ya - top0f), __builtin_fabsf(ya - bot0f));
+            // Points in front of the fingertips (y >= top) take part in nothing (finger_hand.cpp:27:
+            // only points with y < top are looked at).  The list is in cell order, so the 64 points of
+            // a wave are neighbours in space and often ALL lie in front: the slot arithmetic of this
+            // orientation is then skipped for the whole wave.
+            if (fast_ok && __ballot(valid && (ya < top0f || dy < mY)) == 0ull) continue;
+            const float xa = __builtin_fmaf(cf, u, sf * v);
             const float rel = xa * invs;
             const float kff = __builtin_floorf(rel);
             const float frac = rel - kff;
@@ -1497,10 +1422,20 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   const SweepFn fn_lds = (R <= 8) ? k_sweep<0, 8> : (R <= 16 ? k_sweep<0, 16> : k_sweep<0, 32>);
   const SweepFn fn_glb = (R <= 8) ? k_sweep<1, 8> : (R <= 16 ? k_sweep<1, 16> : k_sweep<1, 32>);
   const int grid = (int)std::min<size_t>(s, 256 * kStage0WgPerCu);
-  AG2_HIP(c, c->d_gpos.reserve((size_t)256 * kStage0WgPerCu * kGposCap * 6));
-  A.gpos = c->d_gpos.as<int>();
-  hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads0), lds, c->stream, A);
-  AG2_HIP(c, hipGetLastError());
+  // first stage: one workgroup per sample, or -- AG2_SWEEP_WAVE=1 -- one wave per sample
+  // (k_sweep_wave.hip: the same results; measured slower at configuration 2)
+  static const bool use_wave = getenv("AG2_SWEEP_WAVE") != nullptr;
+  if (use_wave) {
+    AG2_HIP(c, c->d_gpos.reserve(sweep_wave_gpos_ints(1024) * 4));
+    A.gpos = c->d_gpos.as<int>();
+    const int rc = launch_sweep_wave(c, A, s, R);
+    if (rc) return rc;
+  } else {
+    AG2_HIP(c, c->d_gpos.reserve((size_t)256 * kStage0WgPerCu * kGposCap * 6));
+    A.gpos = c->d_gpos.as<int>();
+    hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads0), lds, c->stream, A);
+    AG2_HIP(c, hipGetLastError());
+  }
   AG2_HIP(c, stage_event(c, 2));
   if (want_prof) {
     unsigned long long h[8];
