@@ -80,6 +80,7 @@ struct LeNetDev {
   DevBuf w1p, b1, w2p, b2, w3p, b3, w4, b4;  // packed for the MFMA lane layout (k_lenet.hip)
   DevBuf w1x, w2x, w3x;                      // conv / ip1 weights split into 3 bf16 terms (k_lenet_x3.hip)
   bool use_x3 = true;                        // false: the f32-input MFMA convolutions (AG2_LENET_F32=1)
+  bool use_bands = true;                     // false: k_lenet_conv_x3, one workgroup per image (AG2_LENET_WHOLE=1)
 };
 
 }  // namespace ag2

@@ -332,6 +332,7 @@ int lenet_pack_weights(ag2_ctx* c, const float* c1w, const float* c1b, const flo
   rc = lenet_pack_fc_x3(c, w3p.data());
   if (rc) return rc;
   d.use_x3 = getenv("AG2_LENET_F32") == nullptr;
+  d.use_bands = getenv("AG2_LENET_WHOLE") == nullptr;
   d.loaded = true;
   return 0;
 }

@@ -72,8 +72,9 @@ __host__ __device__ __forceinline__ void split3(float v, unsigned short t[3]) {
 __device__ __forceinline__ bf16x8 as_frag(const uint4& u) { return __builtin_bit_cast(bf16x8, u); }
 
 // conv2 + bias + max-pool for the NT tiles mgrp, mgrp + 4, ... of this wave, one channel half
-template <int NT>
-__device__ __forceinline__ void x3_conv2(const X3Shared& S, const uint4* __restrict__ w2x,
+// SH: the shared-memory layout (whole map or one band of it); TS: tile stride between a wave's tiles
+template <class SH, int NT, int TS>
+__device__ __forceinline__ void x3_conv2(const SH& S, const uint4* __restrict__ w2x,
                                          float* __restrict__ dst, float bias2, int nh, int mgrp,
                                          int lane) {
   const int h = lane >> 5, r = lane & 31;
@@ -83,7 +84,7 @@ __device__ __forceinline__ void x3_conv2(const X3Shared& S, const uint4* __restr
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int w = 8 * (mgrp + 4 * t) + g;
+    const int w = 8 * (mgrp + TS * t) + g;
     const int wy = w / 12, wx = w - wy * 12;
     const int y = 2 * wy + (q >> 1), x = 2 * wx + (q & 1);
     pa0[t] = y * kXPA + x;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void x3_conv2(const X3Shared& S, const uint4* __restr
       for (int j = 0; j < 4; j++) {
         const float m = fmaxf(fmaxf(acc[t][4 * j], acc[t][4 * j + 1]),
                               fmaxf(acc[t][4 * j + 2], acc[t][4 * j + 3]));
-        const int wdw = 8 * (mgrp + 4 * t) + 2 * j + h;
+        const int wdw = 8 * (mgrp + TS * t) + 2 * j + h;
         dst[wdw * 50 + oc] = m + bias2;  // K' order of ip1: window-major, channel-minor
       }
     }
@@ -163,9 +164,11 @@ __device__ __forceinline__ void x3_conv2(const X3Shared& S, const uint4* __restr
 
 // conv1 + bias + max-pool for NT tiles (T0, T0 + 8, ...): 8 windows x 32 channels each; the pooled
 // values are split into three bf16 terms on the way into LDS
-template <int NT>
-__device__ __forceinline__ void x3_conv1(X3Shared& S, const uint4* __restrict__ w1x, float bias1,
-                                         int T0, int lane) {
+// TS: tile stride between a wave's tiles (= waves per workgroup); PLANE: pixels of one image channel.
+// BF: the staged image already holds bf16 values (S.imgb), else u8 (S.img) converted per fragment.
+template <class SH, int NT, int TS, int PLANE, bool BF = false>
+__device__ __forceinline__ void x3_conv1(SH& S, const uint4* __restrict__ w1x, float bias1,
+                                         int T0, int lane, const unsigned short* imgb = nullptr) {
   const int h = lane >> 5, r = lane & 31;
   const int g = r >> 2, q = r & 3;
   v16f acc[NT];
@@ -173,7 +176,7 @@ __device__ __forceinline__ void x3_conv1(X3Shared& S, const uint4* __restrict__ 
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int w = 8 * (T0 + t * kXWaves) + g;
+    const int w = 8 * (T0 + t * TS) + g;
     const int wy = w / 28, wx = w - wy * 28;
     a0[t] = (2 * wy + (q >> 1)) * kXImgRow + 2 * wx + (q & 1);
   }
@@ -190,20 +193,33 @@ __device__ __forceinline__ void x3_conv1(X3Shared& S, const uint4* __restrict__ 
     // image offset of this lane's (channel, ky) row; row 15 is the zero row under channel 2
     const int rr = 2 * b + h;
     const int cc = (rr * 13) >> 6;  // rr / 5 for rr < 16
-    const int c1off = (rr < 15) ? cc * kXImgPlane + (rr - 5 * cc) * kXImgRow
-                                : 2 * kXImgPlane + 5 * kXImgRow;
+    const int c1off = (rr < 15) ? cc * PLANE + (rr - 5 * cc) * kXImgRow
+                                : 2 * PLANE + 5 * kXImgRow;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      const unsigned char* px = &S.img[a0[t] + c1off];
-      // u8 -> float -> bf16 (exact): the high half of the float is the bf16
-      const unsigned f0 = __float_as_uint((float)px[0]), f1 = __float_as_uint((float)px[1]),
-                     f2 = __float_as_uint((float)px[2]), f3 = __float_as_uint((float)px[3]),
-                     f4 = __float_as_uint((float)px[4]);
       uint4 au;
-      au.x = (f1 & 0xFFFF0000u) | (f0 >> 16);
-      au.y = (f3 & 0xFFFF0000u) | (f2 >> 16);
-      au.z = f4 >> 16;
-      au.w = 0u;
+      if constexpr (BF) {
+        // five consecutive bf16 pixels from three aligned dwords: the fragment starts at an even
+        // pixel for q & 1 == 0 and at an odd one otherwise (PLANE, the row pitch and so c1off are
+        // even), so the lane shifts by a constant 0 or 16 bits
+        const unsigned* pw = reinterpret_cast<const unsigned*>(imgb) + ((a0[t] + c1off) >> 1);
+        const unsigned d0 = pw[0], d1 = pw[1], d2 = pw[2];
+        const unsigned sh = (unsigned)(q & 1) * 16u;
+        au.x = __builtin_amdgcn_alignbit(d1, d0, sh);
+        au.y = __builtin_amdgcn_alignbit(d2, d1, sh);
+        au.z = (d2 >> sh) & 0xFFFFu;
+        au.w = 0u;
+      } else {
+        const unsigned char* px = &S.img[a0[t] + c1off];
+        // u8 -> float -> bf16 (exact): the high half of the float is the bf16
+        const unsigned f0 = __float_as_uint((float)px[0]), f1 = __float_as_uint((float)px[1]),
+                       f2 = __float_as_uint((float)px[2]), f3 = __float_as_uint((float)px[3]),
+                       f4 = __float_as_uint((float)px[4]);
+        au.x = (f1 & 0xFFFF0000u) | (f0 >> 16);
+        au.y = (f3 & 0xFFFF0000u) | (f2 >> 16);
+        au.z = f4 >> 16;
+        au.w = 0u;
+      }
       const bf16x8 Af = as_frag(au);
       v16f a = acc[t];
       a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af, Bl, a, 0, 0, 0);
@@ -215,7 +231,7 @@ __device__ __forceinline__ void x3_conv1(X3Shared& S, const uint4* __restrict__ 
   if (r < 20) {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      const int T = T0 + t * kXWaves;
+      const int T = T0 + t * TS;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const float m = fmaxf(fmaxf(acc[t][4 * j], acc[t][4 * j + 1]),
@@ -269,15 +285,91 @@ k_lenet_conv_x3(const unsigned char* __restrict__ images, int n_img, const unsig
     }
     __syncthreads();
     // conv1: 98 tiles; wave w takes tiles w, w + 8, ... (12 each, waves 0 and 1 a 13th)
-    for (int k0 = 0; k0 < 12; k0 += 4) x3_conv1<4>(S, w1x, bias1, wid + 8 * k0, lane);
-    if (wid < 2) x3_conv1<1>(S, w1x, bias1, wid + 96, lane);
+    for (int k0 = 0; k0 < 12; k0 += 4) x3_conv1<X3Shared, 4, kXWaves, kXImgPlane>(S, w1x, bias1, wid + 8 * k0, lane);
+    if (wid < 2) x3_conv1<X3Shared, 1, kXWaves, kXImgPlane>(S, w1x, bias1, wid + 96, lane);
     __syncthreads();
     // conv2: 18 tiles x 2 channel halves over 8 waves
     {
       float* dst = pooled2 + (size_t)im * 7200;
-      if (mgrp < 2) x3_conv2<5>(S, w2x, dst, bias2, nh, mgrp, lane);   // tiles mgrp, +4, .., +16
-      else x3_conv2<4>(S, w2x, dst, bias2, nh, mgrp, lane);            // tiles mgrp, +4, .., +12
+      if (mgrp < 2) x3_conv2<X3Shared, 5, 4>(S, w2x, dst, bias2, nh, mgrp, lane);   // tiles mgrp, +4, .., +16
+      else x3_conv2<X3Shared, 4, 4>(S, w2x, dst, bias2, nh, mgrp, lane);            // tiles mgrp, +4, .., +12
     }
+  }
+}
+
+// ---- the same layers, one BAND of an image per workgroup ------------------------------------------
+// k_lenet_conv_x3 keeps the whole three-term pooled conv1 map of an image in LDS (148 KB): one
+// workgroup per CU, whose staging, conv1 (issue-bound: the u8 -> bf16 A path), the two barriers and
+// the pooling / store epilogue all leave the matrix pipes idle (MFMA busy 0.54).  Here the unit of work
+// is a third of an image: the conv2 output rows 8k .. 8k+7 (pooled-output rows 4k .. 4k+3, 48 of the
+// 144 windows) need the pooled conv1 rows 8k .. 8k+11, i.e. image rows 16k .. 16k+27.  A band's map is
+// 12 rows (64 KB with the band of the image), so TWO 256-thread workgroups share a CU and one's
+// staging / conv1 / epilogue overlaps the other's conv2; 3 x n units instead of n also cut the last,
+// partly empty round of workgroups to a third.  Cost: the four pooled rows two neighbouring bands share
+// are computed twice (conv1 + 29 %, 7 % of all MFMA work).  The band of the image is staged as bf16 (a
+// u8 value is exact), so a conv1 A fragment is three aligned dword reads and a funnel shift instead of
+// five byte reads, five conversions and the packing.  Every output is the same chain of MFMAs in
+// the same k order as in the whole-image kernel: bit-identical results.  Measured (934 images): whole
+// image 0.276 ms, bands 0.245 ms.  Ablation: conv1 alone 0.085 ms, conv2 alone 0.127 ms, staging 0.015 ms
+// -- the phases ADD even with two workgroups per CU, and also when conv1 of the next unit runs in the
+// same workgroup beside conv2 of the current one (tried: 0.244 ms): at the clock this kernel sustains
+// (~1.8 GHz) conv2 is matrix-pipe-bound (~0.9 busy) and the pipes are the shared resource.
+constexpr int kBThreads = 256;
+constexpr int kBWaves = kBThreads / 64;
+constexpr int kBRows = 12;                   // pooled conv1 rows of a band
+constexpr int kBImgRows = 28;                // image rows of a band (+ one zero row per channel)
+constexpr int kBImgPlane = (kBImgRows + 1) * 60;
+
+struct X3Band {
+  unsigned short pa[3][2][kBRows * kXPA][8];
+  unsigned short pc[3][kBRows * kXPC][4];
+  unsigned short imgb[3 * kBImgPlane + 16];  // the band of the image as bf16 (u8 values are exact)
+};
+static_assert(2 * sizeof(X3Band) <= 160 * 1024, "k_lenet_conv_x3b: two workgroups per CU");
+
+__global__ void __launch_bounds__(kBThreads, 2)
+k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsigned* __restrict__ d_n,
+                 const uint4* __restrict__ w1x, const float* __restrict__ b1,
+                 const uint4* __restrict__ w2x, const float* __restrict__ b2,
+                 float* __restrict__ pooled2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  X3Band& S = *reinterpret_cast<X3Band*>(smem_raw);
+  if (d_n) n_img = min(n_img, (int)*d_n);  // frame mode: the list length is read on the device
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31;
+  const float bias1 = b1[r];
+  const int nh = wid & 1;     // conv2: which 32 output channels
+  const int mgrp = wid >> 1;  // conv2: tiles mgrp, mgrp + 2, mgrp + 4
+  const float bias2 = b2[nh * 32 + r];
+  const int units = 3 * n_img;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int im = u / 3, band = u - 3 * im;
+    __syncthreads();  // previous unit's conv2 readers of the pooled map are done
+    {  // stage image rows 16 band .. 16 band + 27: HWC u8 -> planar u8 (+ one zero row per channel)
+      const unsigned* src = reinterpret_cast<const unsigned*>(images + (size_t)im * 10800 + band * (16 * 180));
+      for (int i = tid; i < kBImgRows * 45; i += kBThreads) {  // 28 rows x 180 bytes
+        const unsigned v = src[i];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const int e = i * 4 + b;  // byte index = pixel * 3 + ch
+          const int pix = e / 3, ch = e - pix * 3;
+          // u8 -> float -> bf16 (exact): the high half of the float is the bf16
+          S.imgb[ch * kBImgPlane + pix] = (unsigned short)(__float_as_uint((float)((v >> (8 * b)) & 255u)) >> 16);
+        }
+      }
+      if (tid < 180) S.imgb[(tid / 60) * kBImgPlane + kBImgRows * 60 + (tid % 60)] = 0;
+      if (tid < 16) S.imgb[3 * kBImgPlane + tid] = 0;
+    }
+    __syncthreads();
+    // conv1: 42 tiles; wave w takes tiles w, w + 4, ... (10 each, waves 0 and 1 an 11th)
+    x3_conv1<X3Band, 4, kBWaves, kBImgPlane, true>(S, w1x, bias1, wid, lane, S.imgb);
+    x3_conv1<X3Band, 4, kBWaves, kBImgPlane, true>(S, w1x, bias1, wid + 16, lane, S.imgb);
+    x3_conv1<X3Band, 2, kBWaves, kBImgPlane, true>(S, w1x, bias1, wid + 32, lane, S.imgb);
+    if (wid < 2) x3_conv1<X3Band, 1, kBWaves, kBImgPlane, true>(S, w1x, bias1, wid + 40, lane, S.imgb);
+    __syncthreads();
+    // conv2: 6 tiles x 2 channel halves over 4 waves; the band's 48 windows follow the 48 band
+    // windows before them in the K' order of ip1
+    x3_conv2<X3Band, 3, 2>(S, w2x, pooled2 + (size_t)im * 7200 + band * (48 * 50), bias2, nh, mgrp, lane);
   }
 }
 
@@ -499,6 +591,20 @@ int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d
     AG2_HIP(c, hipFuncSetAttribute((const void*)k_lenet_conv_x3,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
+  }
+  if (d.use_bands) {  // (AG2_LENET_WHOLE=1 at weight load: one workgroup per image, for A/B)
+    static bool battr = false;
+    if (!battr) {
+      AG2_HIP(c, hipFuncSetAttribute((const void*)k_lenet_conv_x3b,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(X3Band)));
+      battr = true;
+    }
+    const int gridb = (int)std::min<size_t>(3 * n, 512);
+    hipLaunchKernelGGL(k_lenet_conv_x3b, dim3(gridb), dim3(kBThreads), sizeof(X3Band), c->stream, d_images,
+                       (int)n, d_n, d.w1x.as<uint4>(), d.b1.as<float>(), d.w2x.as<uint4>(), d.b2.as<float>(),
+                       d_pooled2);
+    AG2_HIP(c, hipGetLastError());
+    return 0;
   }
   const int grid = (int)std::min<size_t>(n, 256);
   hipLaunchKernelGGL(k_lenet_conv_x3, dim3(grid), dim3(kXThreads), lds, c->stream, d_images, (int)n,

@@ -157,6 +157,29 @@ def test_detect_on_the_null_stream_with_growing_lists(small_scene):
     d.close()
 
 
+def test_banded_convolutions_equal_the_whole_image_kernel_bit_for_bit(monkeypatch):
+    """k_lenet_conv_x3b (default: a third of an image per workgroup, two workgroups per CU) runs every
+    output through the same chain of MFMAs in the same k order as k_lenet_conv_x3 (AG2_LENET_WHOLE=1:
+    one workgroup per image)."""
+    from agile_grasp2_amd import capi
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, size=(1000, 60, 60, 3), dtype=np.uint8)
+    imgs[::7] = 0
+    imgs[3::11, :, :, 1] = 255
+    w = make_lenet_weights(11)
+    out = {}
+    for mode in ("bands", "whole"):
+        monkeypatch.delenv("AG2_LENET_WHOLE", raising=False)
+        if mode == "whole":
+            monkeypatch.setenv("AG2_LENET_WHOLE", "1")
+        d = capi.Detector()
+        d.lenet_load(w)
+        out[mode] = [d.lenet_forward(imgs[:n]) for n in (1, 2, 85, 86, 170, 171, 1000)]
+        d.close()
+    for a, b in zip(out["bands"], out["whole"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_detect_no_hypotheses():
     """A bare plane yields no hand placements: every stage must cope with zero work."""
     from agile_grasp2_amd import capi
