@@ -25,6 +25,7 @@ SYMBOLS = [
     "ag2_find_clusters", "ag2_set_min_inliers", "ag2_set_grid_origin", "ag2_set_stage_timing",
     "ag2_export_candidates_compact_device", "ag2_hand_constants",
     "ag2_stream_configure", "ag2_detect_frame", "ag2_get_frame_info",
+    "ag2_export_selected_compact_device", "ag2_merge_selected_device",
 ]
 
 
@@ -324,8 +325,14 @@ class Detector:
         return out
 
     def detect(self, sample_idx=None, sample_xyz=None, slot_base=0, seed=0, do_prune=True,
-               want_all=True, n_resident=None):
+               want_all=True, n_resident=None, local_select=True):
         si, sx, s = self._samples(sample_idx, sample_xyz, n_resident)
+        if not local_select:   # a multi-GPU rank: the merge (merge_selected_device) does the top-k
+            ns, na = C.c_size_t(0), C.c_size_t(0)
+            self._ck(self.L.ag2_detect(self.h, _ptr(si), _ptr(sx), C.c_size_t(s), C.c_uint64(slot_base),
+                                       C.c_uint64(seed), C.c_int(1 if do_prune else 0), None, C.c_size_t(0),
+                                       C.byref(ns), None, C.c_size_t(0), C.byref(na)))
+            return np.zeros(0, dtype=HYP_DTYPE), na.value
         cap = max(1, s * int(self.params.num_orientations))
         sel = np.zeros(cap, dtype=HYP_DTYPE)
         allh = np.zeros(cap if want_all else 1, dtype=HYP_DTYPE)
@@ -395,6 +402,21 @@ class Detector:
     def export_candidates_compact_device(self, dptr: int, nbytes: int, cap_records: int):
         self._ck(self.L.ag2_export_candidates_compact_device(self.h, C.c_void_p(dptr), C.c_size_t(nbytes),
                                                              C.c_size_t(cap_records)))
+
+    def export_selected_compact_device(self, dptr: int, nbytes: int, cap_records: int):
+        self._ck(self.L.ag2_export_selected_compact_device(self.h, C.c_void_p(dptr), C.c_size_t(nbytes),
+                                                           C.c_size_t(cap_records)))
+
+    def merge_selected_device(self, dptr: int, world: int, cap_records: int):
+        """(top num_selected of the gathered selected lists, number of records that took part)"""
+        k = int(self.params.num_selected)
+        cap = world * cap_records if k < 0 else min(k, world * cap_records)
+        sel = np.zeros(max(1, cap), dtype=HYP_DTYPE)
+        ns, nt = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self.L.ag2_merge_selected_device(self.h, C.c_void_p(dptr), C.c_size_t(world),
+                                                  C.c_size_t(cap_records), _ptr(sel), C.c_size_t(len(sel)),
+                                                  C.byref(ns), C.byref(nt)))
+        return sel[: ns.value].copy(), nt.value
 
     def counters(self) -> Counters:
         c = Counters()

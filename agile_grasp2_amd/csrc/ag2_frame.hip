@@ -139,7 +139,7 @@ unsigned long long frame_signature(const ag2_ctx* c, const ag2_frame_state* f) {
                         c->d_sorted.p, c->d_nrm.p, c->d_stats.p, c->d_hc.p, c->d_sample_q.p, c->d_frames.p,
                         c->d_frame_ok.p, c->d_table.p, c->d_tab_off.p, c->d_tab_keep.p, c->d_arena.p,
                         c->d_overflow.p, c->d_gscratch.p, c->d_gpos.p, c->d_list2.p, c->d_images.p,
-                        c->d_logits.p, c->d_act1.p, c->d_fcpart.p, c->d_tmp.p, c->d_flags.p, c->d_desc.p,
+                        c->d_logits.p, c->d_act1.p, c->d_fcpart.p, c->d_sel.p, c->d_flags.p, c->d_desc.p,
                         c->d_scan.p, f->h_pin, c->net.w1x.p, c->net.w2x.p, c->net.w3x.p,
                         c->net.b1.p, c->net.b2.p, c->net.b3.p, c->net.w4.p, c->net.b4.p, (const void*)c->stream};
   const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points, f->cap_img,
@@ -228,7 +228,7 @@ int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
   ag2_hypothesis* d_rec = (ag2_hypothesis*)((char*)c->fm_args_dev + f->off_rec);
   FrameOut* d_fo = (FrameOut*)((char*)c->fm_args_dev + f->off_out);
   hipLaunchKernelGGL(k_topk, dim3((unsigned)((cap_img + kTopkThreads - 1) / kTopkThreads)), dim3(kTopkThreads), 0,
-                     c->stream, c->d_tmp.as<ag2_hypothesis>(), &st->n_sel, (int)cap_img, c->p.num_selected,
+                     c->stream, c->d_sel.as<ag2_hypothesis>(), &st->n_sel, (int)cap_img, c->p.num_selected,
                      (int)f->k_cap, d_rec, d_fo, st, gp);
   AG2_HIP(c, hipGetLastError());
   return 0;

@@ -155,6 +155,10 @@ struct ag2_ctx {
   ag2::DevBuf d_act1;      // LeNet intermediates (pooled2: n x 7200 float)
   ag2::DevBuf d_fcpart;    // ip1 split-K partial sums [ksplit][n_pad][512]
   ag2::DevBuf d_tmp;       // misc staging
+  ag2::DevBuf d_sel;       // ag2_hypothesis: scored records with score >= min_score_diff, list order (+ count trailer)
+  ag2::DevBuf d_merge;     // ag2_hypothesis: the gathered selected lists of all ranks, flattened (ag2_merge_selected_device)
+  const void* d_last_sel = nullptr;    // what the last ag2_detect selected from (d_sel or d_cluster) ...
+  const unsigned* d_last_nsel = nullptr;  // ... and its count on the device
   ag2::DevBuf d_flags;     // uint32 flags / prefix for slot compaction
   ag2::DevBuf d_desc;      // image descriptors: int64 arena offset[n] then int32 count[n]
   ag2::DevBuf d_cluster;   // ag2_hypothesis: clustered hands, compacted (k_cluster.hip)
@@ -258,6 +262,9 @@ int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned
 int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypothesis>& recs,
                    std::vector<int64_t>* offs, std::vector<uint8_t>* keep);
 int export_candidates_compact(ag2_ctx* c, void* d_dst, size_t cap_records);
+int export_selected_compact(ag2_ctx* c, void* d_dst, size_t cap_records);
+int merge_selected(ag2_ctx* c, const void* d_gathered, size_t world, size_t cap_records, ag2_hypothesis* selected,
+                   size_t cap, size_t* n_selected, size_t* n_total);
 int make_image_descs(ag2_ctx* c, const int* d_list, size_t n);
 // k_lenet_x3.hip
 int lenet_pack_weights_x3(ag2_ctx* c, const float* conv1_w, const float* conv2_w);

@@ -339,16 +339,28 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   rc = score_and_select_async(c, c->d_list2.as<int>(), n_img, d_nsel);
   if (rc) return rc;
   // 4b. grasp clusters (grasp_detector.cpp:228-236), only when HandleSearch::setMinInliers > 0
-  const void* d_res = c->d_tmp.p;
+  const void* d_res = c->d_sel.p;
   const unsigned* d_nres = d_nsel;
   if (c->min_inliers > 0) {
     unsigned* d_nclu = &c->d_stats.as<DevStats>()->n_clu;
-    rc = cluster_async(c, c->d_tmp.as<ag2_hypothesis>(), n_img, d_nsel, c->min_inliers, d_nclu);
+    rc = cluster_async(c, c->d_sel.as<ag2_hypothesis>(), n_img, d_nsel, c->min_inliers, d_nclu);
     if (rc) return rc;
     d_res = c->d_cluster.p;
     d_nres = d_nclu;
   }
+  c->d_last_sel = d_res;    // for ag2_export_selected_compact_device
+  c->d_last_nsel = d_nres;
   AG2_HIP(c, stage_event(c, 7));
+  if (!selected && cap == 0 && !(scored_all && cap_all)) {
+    // Multi-GPU use: the caller exports the selected list (ag2_export_selected_compact_device) and the
+    // top-k happens in ag2_merge_selected_device over all ranks' lists -- no local read-back, no local
+    // top-k, and this call returns with the tail of the pipeline still queued on the stream.
+    *n_selected = 0;
+    c->cnt.n_scored = (int64_t)n_img;
+    c->cnt.n_selected = 0;
+    if (n_scored) *n_scored = n_img;
+    return 0;
+  }
   std::vector<ag2_hypothesis> anti;
   const ag2_hypothesis* recs = nullptr;  // the selected records, in list order
   unsigned n_anti = 0;
@@ -422,6 +434,30 @@ int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes) {
     AG2_HIP(c, hipGetLastError());
   }
   return 0;
+}
+
+int ag2_export_selected_compact_device(ag2_ctx* c, void* d_dst, size_t bytes, size_t cap_records) {
+  if (!c || !d_dst) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (cap_records > ((size_t)1 << 30)) return set_err(c, AG2_ERR_ARG, "export: cap too large");
+  if (bytes < 16 + cap_records * sizeof(ag2_hypothesis))
+    return set_err(c, AG2_ERR_CAPACITY, "export: destination too small");
+  if (!c->d_last_nsel) return set_err(c, AG2_ERR_STATE, "export: no ag2_detect result to export");
+  if (!c->d_last_sel || cap_records == 0) {  // a detect over no images: an empty list
+    const unsigned hdr[4] = {0u, (unsigned)cap_records, 0u, 0u};
+    AG2_HIP(c, hipMemcpyAsync(d_dst, hdr, 16, hipMemcpyHostToDevice, c->stream));
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  return export_selected_compact(c, d_dst, cap_records);
+}
+
+int ag2_merge_selected_device(ag2_ctx* c, const void* d_gathered, size_t world, size_t cap_records,
+                              ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_total) {
+  if (!c || !d_gathered || !n_selected || world == 0) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (world > 4096 || cap_records > ((size_t)1 << 24)) return set_err(c, AG2_ERR_ARG, "merge: sizes");
+  return merge_selected(c, d_gathered, world, cap_records, selected, cap, n_selected, n_total);
 }
 
 int ag2_export_candidates_compact_device(ag2_ctx* c, void* d_dst, size_t bytes, size_t cap_records) {

@@ -33,6 +33,9 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
       hi[a] = min(cell_of(qq[a] + rq, g.o[a], g.inv), g.dims[a] - 1);
     }
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 A01 = {0.f, 0.f}, A23 = {0.f, 0.f}, A45 = {0.f, 0.f}, A67 = {0.f, 0.f};  // the row walk below
+    const f2 qxy = {q.x, q.y};
     // The kernel is bound by the latency of each thread's chain of dependent loads (one wave per
     // SIMD slot, every wave runs once), so the chain is kept short: the span bounds of ALL stencil
     // rows (<= 4 x 4: q +- 1.001 r reaches 3, rarely 4, cells per axis) are requested first, and a
@@ -112,17 +115,19 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const float4 p = p4[k];
-            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            // two-wide packed f32 operations (v_pk_mul_f32 / v_pk_add_f32): every component is the
+            // same IEEE multiply or add as before -- nothing is contracted or reassociated -- at half
+            // the instruction count
+            const f2 pxy = {p.x, p.y}, dxy = pxy - qxy;
+            const float dz = p.z - q.z;
+            const f2 dd = dxy * dxy;
+            const float d2 = (dd.x + dd.y) + dz * dz;
             if (j + k < e && d2 < r2f) {
-              a0 = a0 + p.x * p.x;
-              a1 = a1 + p.x * p.y;
-              a2 = a2 + p.x * p.z;
-              a3 = a3 + p.y * p.y;
-              a4 = a4 + p.y * p.z;
-              a5 = a5 + p.z * p.z;
-              a6 = a6 + p.x;
-              a7 = a7 + p.y;
+              const f2 pxx = {p.x, p.x}, pzy = {p.z, p.y}, pyz = {p.y, p.z}, pzz = {p.z, p.z};
+              A01 = A01 + pxx * pxy;   // xx, xy
+              A23 = A23 + pxy * pzy;   // xz, yy
+              A45 = A45 + pyz * pzz;   // yz, zz
+              A67 = A67 + pxy;         // x, y
               a8 = a8 + p.z;
               cnt++;
             }
@@ -130,6 +135,8 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
         }
       }
     }
+    a0 = a0 + A01.x; a1 = a1 + A01.y; a2 = a2 + A23.x; a3 = a3 + A23.y;  // (one of the two sets is zero:
+    a4 = a4 + A45.x; a5 = a5 + A45.y; a6 = a6 + A67.x; a7 = a7 + A67.y;  //  x + 0 is exact)
     float4 out;
     if (cnt < 3) {
       const float nanv = __builtin_nanf("");

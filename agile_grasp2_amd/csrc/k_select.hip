@@ -6,6 +6,8 @@
 // (grasp_detector.cpp:363-395; the predicate itself is evaluated inside k_sweep) and the
 // score >= min_score_diff filter (grasp_detector.cpp:198-207).  Slot order (sample, orientation)
 // IS the reference's output order, so a flag + exclusive scan + scatter keeps it.
+#include <string.h>
+
 #include "ag2_internal.h"
 
 namespace ag2 {
@@ -248,7 +250,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_small(
   }
 }
 
-// Leaves the selected records (score >= threshold, list order) in d_tmp and their count in *d_count.
+// Leaves the selected records (score >= threshold, list order) in d_sel and their count in *d_count.
 // d_n (frame mode): n_img is the capacity of the list, its length is read from *d_n on the device.
 int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned* d_count,
                            const unsigned* d_n) {
@@ -256,12 +258,12 @@ int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned
     AG2_HIP(c, hipMemsetAsync(d_count, 0, 4, c->stream));
     return 0;
   }
-  AG2_HIP(c, c->d_tmp.reserve(n_img * sizeof(ag2_hypothesis) + 16));  // + the count trailer
+  AG2_HIP(c, c->d_sel.reserve(n_img * sizeof(ag2_hypothesis) + 16));  // + the count trailer
   if (n_img <= (size_t)kSelSmall) {
     hipLaunchKernelGGL(k_select_small, dim3(1), dim3(kSelThreads), 0, c->stream, c->d_logits.as<float>(),
                        d_list, (int)n_img, d_n, c->d_table.as<ag2_hypothesis>(),
                        c->d_tab_keep.as<unsigned char>(), c->p.min_score_diff,
-                       c->d_tmp.as<ag2_hypothesis>(), d_count);
+                       c->d_sel.as<ag2_hypothesis>(), d_count);
     AG2_HIP(c, hipGetLastError());
     return 0;
   }
@@ -274,7 +276,7 @@ int score_and_select_async(ag2_ctx* c, const int* d_list, size_t n_img, unsigned
   const int rc = scan_exclusive_u32(c, fl, (int)n_img + 1);
   if (rc) return rc;
   hipLaunchKernelGGL(k_gather_selected, dim3(nb), dim3(256), 0, c->stream, fl, d_list, (int)n_img,
-                     c->d_table.as<ag2_hypothesis>(), c->d_tmp.as<ag2_hypothesis>(), d_count);
+                     c->d_table.as<ag2_hypothesis>(), c->d_sel.as<ag2_hypothesis>(), d_count);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
@@ -363,6 +365,104 @@ int export_candidates_compact(ag2_ctx* c, void* d_dst, size_t cap_records) {
   hipLaunchKernelGGL(k_export_compact, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
                      c->d_table.as<uint4>(), c->d_export_list.as<int>(), (unsigned)cap_records, (uint4*)d_dst);
   AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+// ---- multi-GPU merge: every rank's selected list travels (compact form), every rank ranks them all ----
+// header (16 B): {count, cap, 0, 0}; then min(count, cap) records in list order
+__global__ void k_export_selected(const uint4* __restrict__ recs, const unsigned* __restrict__ d_count,
+                                  unsigned cap, uint4* __restrict__ dst) {
+  constexpr unsigned kPer = (unsigned)(sizeof(ag2_hypothesis) / 16);
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned count = *d_count;
+  const unsigned n = count < cap ? count : cap;
+  if (i == 0) dst[0] = make_uint4(count, cap, 0u, 0u);
+  if (i / kPer < n) dst[1 + i] = recs[i];
+}
+
+int export_selected_compact(ag2_ctx* c, void* d_dst, size_t cap_records) {
+  const size_t threads = std::max<size_t>(cap_records, 1) * (sizeof(ag2_hypothesis) / 16);
+  hipLaunchKernelGGL(k_export_selected, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
+                     (const uint4*)c->d_last_sel, c->d_last_nsel, (unsigned)cap_records, (uint4*)d_dst);
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+// The gathered buffers (world x (16 B header + cap records)) flattened in (rank, list position) order --
+// rank order is sample order, so this is the order the unsplit run's list has -- then the top
+// num_selected by score, ties by position (grasp_detector.cpp:239-252), by rank counting as in the frame
+// path.  One workgroup per 256 records; out[0 .. k) in rank order, the counts behind them.
+__global__ void __launch_bounds__(256) k_merge_flatten(const unsigned char* __restrict__ g, int world, unsigned cap,
+                                                      ag2_hypothesis* __restrict__ flat, unsigned* __restrict__ total) {
+  const size_t per = 16 + (size_t)cap * sizeof(ag2_hypothesis);
+  const int r = blockIdx.y;
+  unsigned off = 0, mine = 0;
+  for (int k = 0; k <= r; k++) {  // (a few ranks: every thread adds up the counts before its rank)
+    const unsigned cnt = min(*reinterpret_cast<const unsigned*>(g + (size_t)k * per), cap);
+    if (k < r) off += cnt; else mine = cnt;
+  }
+  if (r == world - 1 && blockIdx.x == 0 && threadIdx.x == 0) *total = off + mine;
+  constexpr unsigned kPer = (unsigned)(sizeof(ag2_hypothesis) / 16);
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i / kPer < mine)
+    reinterpret_cast<uint4*>(flat + off)[i] = reinterpret_cast<const uint4*>(g + (size_t)r * per + 16)[i];
+}
+
+__global__ void __launch_bounds__(256) k_merge_topk(const ag2_hypothesis* __restrict__ recs,
+                                                   const unsigned* __restrict__ d_n, int k_want, int k_cap,
+                                                   ag2_hypothesis* __restrict__ out, unsigned* __restrict__ out_counts) {
+  __shared__ double sc[256];
+  const int n = (int)*d_n;
+  int k = (k_want >= 0 && k_want < n) ? k_want : n;
+  k = min(k, k_cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out_counts[0] = (unsigned)k;
+    out_counts[1] = (unsigned)n;
+  }
+  const int base = blockIdx.x * 256;
+  if (base >= n) return;  // uniform
+  const int i = base + threadIdx.x;
+  const double si = (i < n) ? recs[i].score : 0.0;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    __syncthreads();
+    if (j0 + (int)threadIdx.x < n) sc[threadIdx.x] = recs[j0 + threadIdx.x].score;
+    __syncthreads();
+    const int m = min(256, n - j0);
+    for (int t = 0; t < m; t++) {
+      const double sj = sc[t];
+      rank += (sj > si || (sj == si && j0 + t < i)) ? 1 : 0;
+    }
+  }
+  if (i < n && rank < k) out[rank] = recs[i];
+}
+
+int merge_selected(ag2_ctx* c, const void* d_gathered, size_t world, size_t cap_records, ag2_hypothesis* selected,
+                   size_t cap, size_t* n_selected, size_t* n_total) {
+  const size_t n_max = world * cap_records;
+  const size_t k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, n_max) : n_max;
+  AG2_HIP(c, c->d_merge.reserve((n_max + k_cap + 1) * sizeof(ag2_hypothesis) + 64));
+  ag2_hypothesis* flat = c->d_merge.as<ag2_hypothesis>();
+  ag2_hypothesis* out = flat + n_max;
+  unsigned* counts = reinterpret_cast<unsigned*>(out + k_cap);  // {k, n}, then the flat total
+  const size_t threads = std::max<size_t>(cap_records, 1) * (sizeof(ag2_hypothesis) / 16);
+  hipLaunchKernelGGL(k_merge_flatten, dim3((unsigned)((threads + 255) / 256), (unsigned)world), dim3(256), 0, c->stream,
+                     (const unsigned char*)d_gathered, (int)world, (unsigned)cap_records, flat, counts + 2);
+  hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, c->stream, flat, counts + 2,
+                     c->p.num_selected, (int)k_cap, out, counts);
+  AG2_HIP(c, hipGetLastError());
+  // one copy brings the top-k records and the counts behind them
+  const size_t bytes = k_cap * sizeof(ag2_hypothesis) + 16;
+  int rc = pin_reserve(c, bytes);
+  if (rc) return rc;
+  AG2_HIP(c, hipMemcpyAsync(pin_bulk(c), out, bytes, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  unsigned kn[2];
+  __builtin_memcpy(kn, pin_bulk(c) + k_cap * sizeof(ag2_hypothesis), 8);
+  *n_selected = kn[0];
+  if (n_total) *n_total = kn[1];
+  if (kn[0] > cap) return set_err(c, AG2_ERR_CAPACITY, "merge: output capacity too small");
+  if (kn[0] && selected) __builtin_memcpy(selected, pin_bulk(c), (size_t)kn[0] * sizeof(ag2_hypothesis));
   return 0;
 }
 

@@ -97,8 +97,34 @@ def tile_halo(nn_radius_hands: float, nn_radius_taubin: float, normals_radius: f
     return max(nn_radius_hands, nn_radius_taubin) + normals_radius + 1e-5
 
 
+def sample_costs(xyz: np.ndarray, ordered_sample_idx: np.ndarray, radius: float, axis: int = 0) -> np.ndarray:
+    """Proxy of a sample's sweep cost: the number of cloud points whose coordinate along `axis` lies within
+    `radius` of the sample's -- the 1-D marginal of K2, the neighbour count that drives the hand sweep
+    (balance tiles on sum K2, not on the sample count).  Same on every rank."""
+    x = np.asarray(xyz)[:, axis].astype(np.float64)
+    xs = np.sort(x[np.isfinite(x)])
+    sx = x[np.asarray(ordered_sample_idx, dtype=np.int64)]
+    return (np.searchsorted(xs, sx + radius) - np.searchsorted(xs, sx - radius)).astype(np.float64)
+
+
+def balanced_bounds(costs: np.ndarray, world: int) -> np.ndarray:
+    """world + 1 boundaries of contiguous ranges of the ordered sample list with (nearly) equal summed
+    cost; every rank gets at least one sample while there are enough."""
+    n = len(costs)
+    if n == 0:
+        return np.zeros(world + 1, dtype=np.int64)
+    if n <= world:                      # fewer samples than ranks: one each, the last ranks idle
+        return np.minimum(np.arange(world + 1), n).astype(np.int64)
+    cum = np.cumsum(np.maximum(np.asarray(costs, dtype=np.float64), 1.0))
+    targets = cum[-1] * np.arange(1, world) / world
+    b = np.concatenate([[0], np.searchsorted(cum, targets, side="left") + 1, [n]]).astype(np.int64)
+    for r in range(1, world):           # at least one sample per rank
+        b[r] = min(max(b[r], b[r - 1] + 1), n - (world - r))
+    return b
+
+
 def tile_points(xyz: np.ndarray, ordered_sample_idx: np.ndarray, rank: int, world: int,
-                halo: float, axis: int = 0):
+                halo: float, axis: int = 0, bounds: np.ndarray | None = None):
     """Tile of `rank` along `axis` (the one the samples were ordered by): (keep, local_sample_idx,
     slot_base).
 
@@ -108,7 +134,10 @@ def tile_points(xyz: np.ndarray, ordered_sample_idx: np.ndarray, rank: int, worl
     slot_base         position of the rank's first sample in ordered_sample_idx (RNG key and table
                       slot, as with replicated clouds)."""
     xyz = np.asarray(xyz)
-    b, e = shard_range(len(ordered_sample_idx), rank, world)
+    if bounds is None:
+        b, e = shard_range(len(ordered_sample_idx), rank, world)
+    else:               # cost-balanced ranges (balanced_bounds): same contract, other cut points
+        b, e = int(bounds[rank]), int(bounds[rank + 1])
     mine = np.asarray(ordered_sample_idx[b:e], dtype=np.int64)
     if len(mine) == 0:
         return np.zeros(0, np.int64), np.zeros(0, np.int32), b

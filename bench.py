@@ -64,11 +64,14 @@ FC_X3_ISSUED_FLOP = 16 * 450 * 6 * 32768.0 / 32
 
 
 def launch_params(ws, R):
-    """launch/file_detect_grasps.launch:16-48 values."""
+    """launch/file_detect_grasps.launch:16-48 values -- except min_score_diff: the launch files' 300 .. 800
+    presume the trained network, which the reference does not ship (.MISSING_LARGE_BLOBS); with the seeded
+    Xavier weights scores are O(10) around zero, so the threshold is 0 (about half of the scored
+    hypotheses pass and reach the clustering / top-k / multi-GPU merge)."""
     from agile_grasp2_amd import scene
     return dict(finger_width=0.01, hand_outer_diameter=0.09, hand_depth=0.06, hand_height=0.02,
                 init_bite=0.01, nn_radius_taubin=0.01, nn_radius_hands=0.1, num_orientations=R,
-                filter_half_grasps=0, min_aperture=0.03, max_aperture=0.08, min_score_diff=300.0,
+                filter_half_grasps=0, min_aperture=0.03, max_aperture=0.08, min_score_diff=0.0,
                 num_selected=30, cam_origin=[scene.CAMERA, scene.CAMERA], workspace=list(ws))
 
 
@@ -224,6 +227,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL exchange path even with one rank (rehearsal on a 1-GPU box)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="N > 1: weak = num_samples per GPU fixed (default, what the driver's scaling run uses), "
+                         "strong = the configuration's num_samples in total, split over the GPUs")
     args = ap.parse_args()
     if args.config == "cfg5":
         if args.steps == 10:
@@ -280,9 +286,12 @@ def main():
     if dist_on:
         # spatial tiles: same scene and same N x S samples on every rank, cut by x
         axis = sharding.longest_axis(xyz)
-        ordered = sharding.order_samples_by_x(xyz, scene.draw_samples(args.seed, n_cloud, S * world), axis)
+        s_total = S * world if args.scaling == "weak" else S
+        ordered = sharding.order_samples_by_x(xyz, scene.draw_samples(args.seed, n_cloud, s_total), axis)
         halo = sharding.tile_halo(prm["nn_radius_hands"], prm["nn_radius_taubin"], 0.01)
-        keep, idx, slot_base = sharding.tile_points(xyz, ordered, rank, world, halo, axis)
+        # tiles balanced on the samples' neighbour counts, not on their number
+        bounds = sharding.balanced_bounds(sharding.sample_costs(xyz, ordered, prm["nn_radius_hands"], axis), world)
+        keep, idx, slot_base = sharding.tile_points(xyz, ordered, rank, world, halo, axis, bounds)
         origin = sharding.cloud_origin(xyz)
         xyz = np.ascontiguousarray(xyz[keep])
         tile_note = f"{xyz.shape[0]} of {n_cloud} points on rank 0"
@@ -298,30 +307,40 @@ def main():
     torch.cuda.synchronize()
     # exchange buffer: the candidates in compact form (header + occupied slots, sharding.py); its
     # capacity is fixed after the warm-up from the largest list any rank produced
-    xch = {"cap": S * R, "buf": None}
+    s_rank = len(idx)                                # this rank's samples
+    # exchange capacity: the same on every rank (the largest tile's slots) -- all-gather needs equal sizes
+    s_max_rank = int(np.diff(bounds).max()) if dist_on else s_rank
+    xch = {"cap": max(1, s_max_rank * R), "buf": None}
 
     def size_exchange(cap):
         xch["cap"] = int(cap)
         xch["buf"] = torch.empty(sharding.compact_bytes(xch["cap"]), dtype=torch.uint8, device="cuda")
 
     if dist_on:
-        size_exchange(S * R)
+        size_exchange(xch["cap"])
 
     acc = {}
 
-    def local_step():  # this rank's part of a step: no collective
+    def local_step(local_select=True):  # this rank's part of a step: no collective
         d.set_cloud_device(xyz_dev.data_ptr(), xyz.shape[0], 12)
         d.compute_normals()
+        # (a rank of a multi-GPU run leaves the top-k to the merge: no local read-back)
         sel, n_scored = d.detect(sample_idx=idx, slot_base=slot_base, seed=args.seed, do_prune=True,
-                                 want_all=False)
+                                 want_all=False, local_select=local_select)
         return n_scored
 
     def step():
-        n_scored = local_step()
+        n_scored = local_step(local_select=not dist_on)
         if dist_on:
-            # the path's one exchange step: candidates of every rank, RCCL all-gather over xGMI
-            d.export_candidates_compact_device(xch["buf"].data_ptr(), xch["buf"].numel(), xch["cap"])
-            xch["out"] = sharding.all_gather_tables(xch["buf"].cpu() if rehearsal else xch["buf"], world)
+            # the path's one exchange step: every rank's scored candidates above the threshold (compact
+            # form), RCCL all-gather over xGMI; then every rank merges -- the lists concatenated in rank
+            # (= sample) order, top num_selected by score (grasp_detector.cpp:239-252) -- on the device
+            d.export_selected_compact_device(xch["buf"].data_ptr(), xch["buf"].numel(), xch["cap"])
+            if rehearsal:
+                xch["out"] = sharding.all_gather_tables(xch["buf"].cpu(), world).cuda()
+            else:
+                xch["out"] = sharding.all_gather_tables(xch["buf"], world)
+            xch["merged"], xch["n_total"] = d.merge_selected_device(xch["out"].data_ptr(), world, xch["cap"])
         return n_scored
 
     def sync():
@@ -336,10 +355,11 @@ def main():
     for _ in range(max(1, args.warmup) if dist_on else args.warmup):
         step()
     if dist_on:
-        # every rank sizes the exchange for twice the largest candidate list seen (same on all ranks)
-        nh = torch.tensor([float(d.counters().n_hypotheses)], dtype=torch.float64, device=coll_dev)
+        # every rank sizes the exchange for twice the largest selected list seen (same on all ranks)
+        hdr0 = xch["buf"][:4].cpu().numpy().view(np.uint32)[0]
+        nh = torch.tensor([float(hdr0)], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(nh, op=dist.ReduceOp.MAX)
-        size_exchange(min(S * R, max(1024, 2 * int(nh.item()))))
+        size_exchange(min(s_max_rank * R, max(1024, 2 * int(nh.item()))))
         step()
     sync()
     t0 = time.perf_counter()
@@ -357,12 +377,22 @@ def main():
         hdr = xch["out"].view(world, -1)[:, :8].cpu().numpy().view(np.uint32)
         if (hdr[:, 0] > hdr[:, 1]).any():
             raise SystemExit(f"exchange capacity {xch['cap']} too small: {hdr[:, 0].tolist()}")
-    tt = torch.tensor([elapsed, float(scored), float(c.n_hypotheses)], dtype=torch.float64, device=coll_dev)
+    sweep_rank_ms = (acc.get("sweep_ms", 0.0) + acc.get("sweep_overflow_ms", 0.0)) / max(1, args.steps)
+    tt = torch.tensor([elapsed, float(scored), float(c.n_hypotheses), float(xyz.shape[0]), float(s_rank),
+                       sweep_rank_ms], dtype=torch.float64, device=coll_dev)
+    per_rank = None
     if dist_on:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = tt.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
+        per_rank = {"points_max": int(tmax[3]), "points_min": int(tmin[3]), "points_sum": int(tt[3]),
+                    "halo_duplication": float(tt[3]) / n_cloud,   # sum of the tiles' points / cloud points
+                    "samples_max": int(tmax[4]), "samples_min": int(tmin[4]),
+                    "sweep_ms_max": float(tmax[5]), "sweep_ms_mean": float(tt[5]) / world,
+                    "merged_records": int(xch.get("n_total", 0)), "merged_selected": int(len(xch.get("merged", [])))}
     total_scored = float(tt[1])
     if rank != 0:
         dist.destroy_process_group()
@@ -432,7 +462,7 @@ def main():
     # with the gfx950 factor-2 correction of MI355X_MICROARCH.md).  Counters cannot be read from
     # inside this process, so the committed summary of the last profiled run is quoted; null if the
     # kernel is not in it.
-    traffic = None
+    traffic, traffic_source, write_amp = None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
@@ -447,11 +477,22 @@ def main():
             traffic = per_kernel.get(dom)
             if dom == "k_sweep" and traffic is not None:  # both instantiations, like the duration
                 traffic += per_kernel.get("k_sweep_overflow", 0)
+            if traffic is not None:
+                traffic_source = (f"profiles/{pmc.get('_profile', {}).get(args.config, '?')} via profiles/pmc_traffic.json: "
+                                  "committed rocprofv3 counter passes of this command (FETCH_SIZE and WRITE_SIZE "
+                                  "in separate runs), NOT measured by this run")
+            # bytes the dominant kernel HAS to write (records + point lists for the sweep) against the
+            # WRITE_SIZE counter: register spills and scratch traffic show up as the excess
+            wr = pmc.get("_writes", {}).get(args.config, {})
+            if dom == "k_sweep" and "k_sweep" in wr:
+                must = c.n_hypotheses * 176 + c.sum_p * 48 + c.n_hypotheses * 9
+                write_amp = (wr["k_sweep"] + wr.get("k_sweep_overflow", 0)) / max(1, must)
         except Exception:
             traffic = None
     roofline = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
                 "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
-                "traffic": traffic, "launch_ms": kernels[dom]["ms"],
+                "traffic": traffic, "traffic_source": traffic_source, "write_amplification": write_amp,
+                "launch_ms": kernels[dom]["ms"],
                 "algorithmic_work_per_launch": kernels[dom]["work"],
                 "all_kernels": {n: dict({"ms": round(k["ms"], 4), "achieved": round(k["achieved"], 3),
                                          "unit": k["unit"], "peak": k["peak"], "frac": round(k["frac"], 4)},
@@ -463,27 +504,32 @@ def main():
         "metric": "grasp hypotheses scored/sec on 300k-pt cloud; end-to-end detect latency",
         "value": total_scored / elapsed, "unit": "hypotheses/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup,
-        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": ("f64 geometry + f32 LeNet (fp32 MFMA)" if os.environ.get("AG2_LENET_F32") else
                   "f64 geometry + f32 LeNet (conv1, conv2, ip1: every fp32 operand as the exact sum of 3 bf16 "
                   "terms on bf16 MFMA, fp32 accumulate; ip2 in fp32)"),
         "data": "synthetic",
+        "span": ("hbm-resident: the cloud is in HBM when the timed region starts, the selected grasps are in host memory "
+                 "when it ends (pcie_inclusive.value: the same step with the cloud handed over in host memory)"),
         "config": {
             "workload": (f"{args.config}: {n_cloud}-pt {'voxelised (3 mm)' if voxelised else 'un-voxelised'} "
                          f"synthetic tabletop cloud, num_samples={S}/GPU, {R} orientations, launch-file hand "
                          f"geometry, seeded LeNet weights"),
-            "n_points": int(n_cloud), "num_samples_per_gpu": S, "num_orientations": R,
+            "n_points": int(n_cloud), "num_samples_per_gpu": (S if args.scaling == "weak" or not dist_on else S // world),
+            "num_orientations": R, "per_rank": per_rank,
             "hypotheses_per_step_per_gpu": int(c.n_hypotheses), "scored_per_step_per_gpu": int(n_img),
             "slots_swept_per_s": S * R * world / (elapsed / K),
             "mean_K1": c.sum_k1 / max(1, c.n_valid_points), "mean_K2": sum_k2 / max(1, c.n_frames),
             "mean_Kcrop": c.sum_kcrop / max(1, c.n_frames), "mean_P": c.sum_p / max(1, c.n_hypotheses),
             "overflow_samples": int(c.n_overflow_samples),
             "parallelism": ("single GPU" if not dist_on else
-                            f"{world} spatial tiles along the cloud's longest axis (interval of the rank's {S} "
-                            f"samples + 0.11 m halo, "
-                            f"{tile_note}), one RCCL all-gather of the candidates in compact form "
-                            f"(16 B header + up to {xch['cap']} records x 176 B per rank)"),
+                            f"{world} spatial tiles along the cloud's longest axis, cut so that the summed "
+                            f"neighbour counts of their samples are equal (interval of the rank's samples + 0.11 m "
+                            f"halo, {tile_note}); one RCCL all-gather of every rank's scored candidates above the "
+                            f"threshold in compact form (16 B header + up to {xch['cap']} records x 176 B per "
+                            f"rank), then the global top-{prm['num_selected']} by score on every rank, inside the "
+                            f"timed step"),
         },
         "stage_ms": {k: round(v, 4) for k, v in ms.items()},
         "stage_ms_note": ("sweep_ms and sweep_overflow_ms: HIP events inside the timed region; the other stages: "
@@ -579,7 +625,43 @@ def main():
                               "note": "two clouds in flight on two HIP streams; never `value`"}
         for dk in pair:
             dk.close()
+        # (4) the launch-file variant with grasp clustering (launch/file_detect_grasps.launch:45
+        # min_inliers = 5: HandleSearch::findClusters between the threshold and the top-k)
+        d.set_min_inliers(5)
+
+        def cluster_step():
+            d.set_cloud_device(xyz_dev.data_ptr(), xyz.shape[0], 12)
+            d.compute_normals()
+            return d.detect(sample_idx=idx, seed=args.seed, do_prune=True, want_all=False)[1]
+
+        dt, sc = timed(cluster_step)
+        d.set_min_inliers(0)
+        out["with_min_inliers_5"] = {"value": sc / dt, "unit": "hypotheses/s", "ms_per_step": dt * 1e3,
+                                     "note": "launch-file min_inliers=5: k_cluster between threshold and top-k; never `value`"}
+        out["value_pcie_inclusive"] = out["pcie_inclusive"]["value"]
         out["cpu_baseline"] = cpu_baseline(xyz, ws, idx, R, weights)
+        # BASELINE.json configs[0] ("PR1 ref"): the launch file's own case -- num_samples = 500, ONE thread
+        # (launch/file_detect_grasps.launch:18-19) -- on a 50 k-point scene (the reference bundles no .pcd)
+        n1, s1, r1, _, k1 = CONFIGS["cfg1"]
+        xyz1, ws1 = scene.make_scene(args.seed, n1, kind=k1)
+        idx1 = scene.draw_samples(args.seed, xyz1.shape[0], s1)
+        cb1 = cpu_baseline(xyz1, ws1, idx1, r1, weights, budget_s=6.0, threads=1)
+        cb1["workload"] = f"cfg1: {xyz1.shape[0]}-pt voxelised tabletop cloud, num_samples={s1}, {r1} orientations, num_threads=1"
+        d1 = capi.Detector(device=local_rank, **launch_params(ws1, r1))
+        d1.set_stream(torch.cuda.current_stream().cuda_stream)
+        d1.lenet_load(weights)
+        d1.set_stage_timing(1)
+
+        def cfg1_step():
+            d1.set_cloud(xyz1)
+            d1.compute_normals()
+            return d1.detect(sample_idx=idx1, seed=1, do_prune=True, want_all=False)[1]
+
+        dt, sc = timed(cfg1_step)
+        d1.close()
+        cb1["gpu_same_workload"] = {"value": sc / dt, "unit": "hypotheses/s", "ms_per_step": dt * 1e3,
+                                    "note": "this library on the same cfg1 workload, cloud handed over in host memory"}
+        out["cpu_baseline_1thread"] = cb1
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)

@@ -210,6 +210,19 @@ int ag2_detect_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, s
 int ag2_get_frame_info(ag2_ctx* c, ag2_frame_info* out);
 
 int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes);
+/* Multi-GPU merge of the detect results (no counterpart in the single-process reference; this is the
+ * step grasp_detector.cpp:239-252 -- top num_selected by score -- becomes when the samples are sharded):
+ * ag2_export_selected_compact_device leaves what the last ag2_detect selected FROM (scored records
+ * with score >= min_score_diff, after the clustering if it is on; list order) in d_dst as a 16-byte
+ * header {count, cap, 0, 0} + min(count, cap) records; the ranks all-gather these buffers (RCCL) and
+ * every rank calls ag2_merge_selected_device on the gathered world x (16 + cap x 176) bytes: the
+ * lists concatenated in rank order (= sample order) and the top num_selected by score, ties by
+ * position.  n_total (may be NULL): records that took part. */
+int ag2_export_selected_compact_device(ag2_ctx* c, void* d_dst, size_t bytes, size_t cap_records);
+/* (ag2_detect with selected == NULL and cap == 0 skips the local read-back and top-k and returns with the
+ * tail of the pipeline still queued: what a rank calls when the merge follows.) */
+int ag2_merge_selected_device(ag2_ctx* c, const void* d_gathered, size_t world, size_t cap_records,
+                              ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_total);
 /* The same candidates in compact form (what a multi-GPU job should put on the wire: the table is
  * mostly empty): a 16-byte header {uint32 count, uint32 cap_records, 0, 0} followed by
  * min(count, cap_records) records in slot order -- the occupied slots of the table above, so the

@@ -113,9 +113,15 @@ def main():
         traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
         traffic[config] = {s: sum(r[4] for r in rows if rx.search(r[0])) for s, rx in SHORT.items()
                            if any(rx.search(r[0]) for r in rows)}
-        traffic["_source"] = (f"profiles/{os.path.basename(dst)} (rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
-                              "WRITE_SIZE, separate passes of python3 bench.py --steps 3 --warmup 1 --no-cpu); "
-                              "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch")
+        # HBM write bytes per launch (WRITE_SIZE x 1024) on their own: bench.py divides them by the
+        # bytes the kernel has to write (roofline.write_amplification: register spills show up here)
+        traffic.setdefault("_writes", {})[config] = {
+            s: int(sum(r[3] for r in rows if rx.search(r[0])) * 1024) for s, rx in SHORT.items()
+            if any(rx.search(r[0]) for r in rows)}
+        traffic.setdefault("_profile", {})[config] = os.path.basename(dst)
+        traffic["_source"] = ("per config: profiles/<_profile[config]> (rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
+                              "WRITE_SIZE, separate passes of python3 bench.py --config <config> --steps 3 --warmup 1 "
+                              "--no-cpu); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch")
         json.dump(traffic, open(tpath, "w"), indent=1)
         print("wrote", dst, "and", tpath)
         return
@@ -124,6 +130,7 @@ def main():
         # defines the units: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs of the busy
         # CUs, SQ_BUSY_CU_CYCLES counts cycles summed over busy CUs (4 SIMDs each)
         src, dst = sys.argv[2], sys.argv[3]
+        config = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
         names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU",
                  "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"]
         cols = {n: counter_means(src, n) for n in names}
@@ -149,8 +156,9 @@ def main():
                 if SHORT[short].search(k):
                     b = cols["SQ_BUSY_CU_CYCLES"][k][1] or 1.0
                     busy[short] = round(cols["SQ_VALU_MFMA_BUSY_CYCLES"].get(k, (0, 0.0))[1] / (4.0 * b), 4)
-        tr["mfma_busy"] = busy
-        tr["_mfma_source"] = f"profiles/{os.path.basename(dst)}: SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)"
+        tr["mfma_busy" if config == "cfg2" else "mfma_busy_" + config] = busy
+        if config == "cfg2":
+            tr["_mfma_source"] = f"profiles/{os.path.basename(dst)}: SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)"
         json.dump(tr, open(mpath, "w"), indent=1)
         print("wrote", dst, "and", mpath)
         return

@@ -73,7 +73,7 @@ def test_cfg2_full_size_detect_matches_oracle(seed):
     tol = 2e-4 * np.abs(oa["score"]).max() + 2e-3
     assert np.abs(ga["score"] - oa["score"]).max() <= tol
     # selection: same set unless a score sits within the tolerance of the threshold / of the cut
-    thr = 300.0
+    thr = float(_bench_params(ws, R)["min_score_diff"])
     near_thr = np.abs(oa["score"] - thr).min() <= 2 * tol
     srt = np.sort(oa["score"][oa["score"] >= thr])[::-1]
     near_cut = len(srt) > 30 and abs(srt[29] - srt[30]) <= 2 * tol

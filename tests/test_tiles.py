@@ -172,3 +172,86 @@ def test_gpu_origin_above_a_point_is_an_error():
     d.set_cloud(xyz)
     d.compute_normals()
     d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 3])
+def test_merge_of_the_ranks_selected_lists_on_the_gpu(world):
+    """The multi-GPU merge (ag2_export_selected_compact_device on every rank, all-gather,
+    ag2_merge_selected_device): the ranks' selected lists concatenated in rank order and the top
+    num_selected by score, ties by position -- checked against the same merge done in numpy on the
+    exported bytes, and against the unsplit run (same hypotheses; the scores of a tile can differ from
+    the unsplit run's in the last bits because ip1's split-K depends on the batch size)."""
+    import ctypes as C
+    from agile_grasp2_amd import capi
+    from agile_grasp2_amd.weights import make_lenet_weights
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    xyz, ws, ordered = _case(7, 12000, 150)
+    w = make_lenet_weights(7)
+    # threshold = the median score of the unsplit run: about half of the records take part in the merge
+    d0 = capi.Detector(**scene_params(ws, min_score_diff=-1e30, num_selected=-1))
+    d0.lenet_load(w)
+    d0.set_cloud(xyz)
+    d0.compute_normals()
+    _, all0 = d0.detect(sample_idx=ordered, seed=3, do_prune=False)
+    d0.close()
+    thr = float(np.median(all0["score"]))
+    prm = scene_params(ws, min_score_diff=thr, num_selected=17)
+    R, cap = 8, 150 * 8
+    per = sharding.compact_bytes(cap)
+    dbuf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dbuf), per * world) == 0
+    halo = None
+    costs = sharding.sample_costs(xyz, ordered, 0.1, AXIS)
+    bounds = sharding.balanced_bounds(costs, world)
+    assert bounds[0] == 0 and bounds[-1] == len(ordered) and np.all(np.diff(bounds) > 0)
+    dets = []
+    for rank in range(world):
+        d = capi.Detector(**prm)
+        d.lenet_load(w)
+        halo = halo or _halo(d)
+        keep, local, base = sharding.tile_points(xyz, ordered, rank, world, halo, AXIS, bounds)
+        d.set_grid_origin(sharding.cloud_origin(xyz))
+        d.set_cloud(xyz[keep])
+        d.compute_normals()
+        d.detect(sample_idx=local, slot_base=base, seed=3, do_prune=False, want_all=False)
+        d.export_selected_compact_device(dbuf.value + rank * per, per, cap)
+        dets.append(d)
+    raw = np.zeros(per * world, dtype=np.uint8)
+    assert hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), dbuf, per * world, 2) == 0
+    flat, cut = sharding.unpack_compact(raw, world, cap, capi.HYP_DTYPE)
+    assert not cut and len(flat) > 17
+    order = sorted(range(len(flat)), key=lambda i: (-flat["score"][i], i))[:17]
+    want = flat[order]
+    got, n_total = dets[0].merge_selected_device(dbuf.value, world, cap)
+    assert n_total == len(flat) and got.tobytes() == want.tobytes()
+    # the unsplit run selects from the same hypotheses
+    d0 = capi.Detector(**prm)
+    d0.lenet_load(w)
+    d0.set_cloud(xyz)
+    d0.compute_normals()
+    sel0, all0 = d0.detect(sample_idx=ordered, seed=3, do_prune=False)
+    thr_margin = np.abs(all0["score"] - thr).min()
+    if thr_margin > 1e-2:
+        keys = sorted(zip(flat["sample_slot"], flat["orientation"]))
+        assert keys == sorted((s, o) for s, o, sc in zip(all0["sample_slot"], all0["orientation"], all0["score"]) if sc >= thr)
+    if world == 1:
+        assert got.tobytes() == sel0.tobytes()
+    for d in dets + [d0]:
+        d.close()
+    hip.hipFree(dbuf)
+
+
+def test_cost_balanced_bounds():
+    rng = np.random.default_rng(0)
+    costs = rng.integers(1, 100, size=1000).astype(np.float64)
+    for world in (1, 2, 3, 8):
+        b = sharding.balanced_bounds(costs, world)
+        assert b[0] == 0 and b[-1] == 1000 and np.all(np.diff(b) > 0)
+        sums = [costs[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(sums) <= costs.sum() / world + 100
+    assert list(sharding.balanced_bounds(np.ones(3), 8))[:4] == [0, 1, 2, 3]
+    assert list(sharding.balanced_bounds(np.zeros(0), 4)) == [0, 0, 0, 0, 0]
