@@ -188,15 +188,24 @@ __global__ void __launch_bounds__(kImgThreads) k_render(const double* __restrict
   }
 }
 
+// The accumulators (one f64 triple per leader point) are dead once the leaders have quantised their
+// cell, and the pixel map + the staged output image are needed only from then on: the two share one
+// area, which brings a workgroup to 27 KB -- five to six per CU (80 VGPRs), 1 280+ images in flight, so the ~900 images of
+// a configuration-2 step run in one round instead of two (the kernel is bound by the latency of one
+// image: ~15 barriers and a dependent read of its point list).
 struct SparseShared {
-  double acc[kSparseMax * 3];     // per leader point; the staged output image aliases it afterwards
-  unsigned pix[kCells];
+  union {
+    double acc[kSparseMax * 3];
+    struct {
+      unsigned pix[kCells];
+      unsigned char obuf[kCells * 3];
+    } img;
+  } u;
   short cid[kSparseMax];
   double red[kImgThreads / kWave];
   int max_rank;
 };
-static_assert(sizeof(SparseShared) * 3 <= 160 * 1024, "k_render_sparse: three workgroups per CU");
-static_assert(kSparseMax * 3 * 8 >= kCells * 3, "output staging must fit the accumulator area");
+static_assert(sizeof(SparseShared) * 5 <= 160 * 1024, "k_render_sparse: five workgroups per CU");
 
 __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __restrict__ arena,
                                                                const long long* __restrict__ desc_off,
@@ -227,7 +236,6 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
       }
       S.cid[b] = c;
     }
-    for (int i = tid; i < kCells; i += kImgThreads) S.pix[i] = 0u;  // image.setTo(0)
     if (tid == 0) S.max_rank = 0;
     __syncthreads();
     // rank of every point among the earlier points of its cell, and the cell's first point
@@ -263,9 +271,9 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
         my_rank[k] = -1;
       }
       if (b < kSparseMax) {  // every leader starts from 0.0 like the reference's running sum
-        S.acc[3 * b] = 0.0;
-        S.acc[3 * b + 1] = 0.0;
-        S.acc[3 * b + 2] = 0.0;
+        S.u.acc[3 * b] = 0.0;
+        S.u.acc[3 * b + 1] = 0.0;
+        S.u.acc[3 * b + 2] = 0.0;
       }
     }
     if (mx > 0) atomicMax(&S.max_rank, mx);
@@ -276,22 +284,33 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
       for (int k = 0; k < kPer; k++)
         if (my_rank[k] == r) {
           const int l = my_lead[k];
-          S.acc[3 * l] = S.acc[3 * l] + yv[k][0];
-          S.acc[3 * l + 1] = S.acc[3 * l + 1] + yv[k][1];
-          S.acc[3 * l + 2] = S.acc[3 * l + 2] + yv[k][2];
+          S.u.acc[3 * l] = S.u.acc[3 * l] + yv[k][0];
+          S.u.acc[3 * l + 1] = S.u.acc[3 * l + 1] + yv[k][1];
+          S.u.acc[3 * l + 2] = S.u.acc[3 * l + 2] + yv[k][2];
         }
       __syncthreads();
     }
+    // leaders quantise their cell into a register; only when every accumulator has been read is the
+    // area reused for the pixel map
+    unsigned qv[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int b = tid + k * kImgThreads;
+      qv[k] = (my_rank[k] == 0) ? quantise(S.u.acc[3 * b], S.u.acc[3 * b + 1], S.u.acc[3 * b + 2]) : 0u;
+    }
+    __syncthreads();
+    for (int i = tid; i < kCells; i += kImgThreads) S.u.img.pix[i] = 0u;  // image.setTo(0)
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < kPer; k++)
-      if (my_rank[k] == 0) {  // leaders: written at (59 - row, col)
+      if (my_rank[k] == 0) {  // written at (59 - row, col)
         const int b = tid + k * kImgThreads;
         const int cell = S.cid[b];
         const int row = kImg - 1 - cell / kImg, col = cell % kImg;
-        S.pix[row * kImg + col] = quantise(S.acc[3 * b], S.acc[3 * b + 1], S.acc[3 * b + 2]);
+        S.u.img.pix[row * kImg + col] = qv[k];
       }
     __syncthreads();
-    dilate_store(S.pix, reinterpret_cast<unsigned char*>(S.acc), out + (size_t)im * (kCells * 3), tid);
+    dilate_store(S.u.img.pix, S.u.img.obuf, out + (size_t)im * (kCells * 3), tid);
   }
 }
 
@@ -534,7 +553,7 @@ int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, con
     attr_set = true;
   }
   // images with at most kSparseMax points (nearly all) ...
-  hipLaunchKernelGGL(k_render_sparse, dim3((int)std::min<size_t>(n_img, 256 * 12)), dim3(kImgThreads), 0,
+  hipLaunchKernelGGL(k_render_sparse, dim3((int)std::min<size_t>(n_img, 256 * 6)), dim3(kImgThreads), 0,
                      c->stream, d_arena, d_off, d_cnt, (int)n_img, d_n, d_out);
   // ... the rest; each kernel skips the others' images by the point count alone
   if (max_p > kSparseMax)

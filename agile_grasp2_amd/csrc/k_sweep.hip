@@ -885,14 +885,16 @@ k_sweep(SweepArgs A) {
       // position comes from LDS, the point from L2: two dependent latencies that would otherwise be
       // exposed once per iteration); lanes beyond the list re-read its last point and are masked.
       float qx, qy, qz;
-      ldp(min(tid, K - 1), qx, qy, qz);
-      for (int j0 = 0; j0 < K; j0 += NT) {
+      const int n_it = (K + NT - 1) / NT;
+      auto jof = [&](int sidx) { return sidx * NT + tid; };
+      ldp(min(jof(0), K - 1), qx, qy, qz);
+      for (int sidx = 0; sidx < n_it; sidx++) {
         alive = (unsigned)__builtin_amdgcn_readfirstlane((int)(alive & ~S.dead));
         if (alive == 0u) break;
-        const int j = j0 + tid;
+        const int j = jof(sidx);
         const bool valid = j < K;
         const float px = qx, py = qy, pz = qz;
-        ldp(min(j + NT, K - 1), qx, qy, qz);
+        ldp(min(jof(sidx + 1), K - 1), qx, qy, qz);
         const float u = (n0 * px + n1 * py) + n2 * pz;
         const float v = (b0 * px + b1 * py) + b2 * pz;
         unsigned need_exact = 0;  // orientations whose estimate is too close to a threshold

@@ -130,6 +130,7 @@ def bench_stream(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     n_points, S, R, _, _ = CONFIGS["cfg5"]
+    S = int(os.environ.get("AG2_STREAM_S", S))   # experiment aid: other sample counts on the same stream
     n_frames, n_warm = args.steps, max(3, args.warmup)   # warm-up: step-by-step, plain run + capture, first replay
     clouds, ws = scene.make_stream(args.seed, n_points, n_frames + n_warm)
     samples = [scene.draw_samples(args.seed + k, c.shape[0], S) for k, c in enumerate(clouds)]
