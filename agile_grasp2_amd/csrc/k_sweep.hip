@@ -390,7 +390,7 @@ static_assert(kLdsCap >= 2048, "unexpected LDS stage size");
 // A list that is longer than stage 0's LDS but not by much keeps its positions in a per-workgroup
 // global slice instead (L2-resident, same code): the few such samples of a tabletop cloud would
 // otherwise cost a whole extra launch whose duration is one sample's latency.
-constexpr int kGposCap = 2 * kLdsCap;
+constexpr int kGposCap = 2 * kLdsCap;  // (A/B at cfg3: 10 k, 24 k and 32 k are all slower than ~7.4 k)
 static_assert(kGposCap <= 65536, "in-box indices are 16 bits");
 
 // Two instantiations run back to back; the second reads its queue length on the device (no host
