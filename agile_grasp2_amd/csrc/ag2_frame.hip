@@ -138,11 +138,11 @@ unsigned long long frame_signature(const ag2_ctx* c, const ag2_frame_state* f) {
   const void* ptrs[] = {c->d_xyz_in.p, c->d_bounds.p, c->d_griddesc.p, c->d_key.p, c->d_cell.p, c->d_perm.p,
                         c->d_sorted.p, c->d_nrm.p, c->d_stats.p, c->d_hc.p, c->d_sample_q.p, c->d_frames.p,
                         c->d_frame_ok.p, c->d_table.p, c->d_tab_off.p, c->d_tab_keep.p, c->d_arena.p,
-                        c->d_overflow.p, c->d_gscratch.p, c->d_gpos.p, c->d_list2.p, c->d_images.p,
+                        c->d_overflow.p, c->d_gscratch.p, c->d_gpos.p, c->d_lists.p, c->d_pairs.p, c->d_list2.p, c->d_images.p,
                         c->d_logits.p, c->d_act1.p, c->d_fcpart.p, c->d_sel.p, c->d_flags.p, c->d_desc.p,
                         c->d_scan.p, f->h_pin, c->net.w1x.p, c->net.w2x.p, c->net.w3x.p,
                         c->net.b1.p, c->net.b2.p, c->net.b3.p, c->net.w4.p, c->net.b4.p, (const void*)c->stream};
-  const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points, f->cap_img,
+  const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points, c->list_ints, f->cap_img,
                                      (unsigned long long)c->sweep_gcap, (unsigned long long)c->sweep_g2,
                                      (unsigned long long)c->p.num_selected, f->k_cap, (unsigned long long)f->cap_p,
                                      (unsigned long long)c->origin_set};
@@ -339,7 +339,7 @@ int ag2_detect_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, s
     AG2_HIP(c, hipStreamSynchronize(c->stream));
     const FrameOut* fo = (const FrameOut*)(f->h_pin + f->off_out);
     const unsigned flags = fo->st.err_flags;
-    const bool bad = (flags & (1u | 8u)) != 0 || fo->g.ncells < 0 || fo->topk_overflow != 0 ||
+    const bool bad = (flags & (1u | 2u | 8u)) != 0 || fo->g.ncells < 0 || fo->topk_overflow != 0 ||
                      (size_t)fo->st.n_list > std::min(f->cap_img, c->fm_s_max * (size_t)R) ||
                      (int)fo->st.max_p > render_capacity_for(f->cap_p);
     if (bad) {

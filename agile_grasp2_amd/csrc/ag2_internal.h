@@ -39,14 +39,16 @@ struct DevStats {
   unsigned long long sum_k2, sum_kcrop, sum_p;
   unsigned long long arena_top;      // in-box points reserved in the arena
   unsigned int n_frames, n_hyp, n_overflow, n_pruned_keep;
-  unsigned int err_flags;            // bit0 arena overflow, bit3 global sweep scratch overflow
+  unsigned int err_flags;            // bit0 arena overflow, bit1 list arena overflow (split sweep), bit3 global sweep scratch overflow
   unsigned int n_list;               // hypotheses that go on to be scored (after the prune)
   unsigned int n_sel;                // scored hypotheses with score >= min_score_diff
   unsigned int n_clu;                // selected hypotheses that survive the clustering
   unsigned int max_p;                // largest in-box list of the run (picks the image renderers)
   unsigned int work_next[3];         // k_sweep work queues, one per stage (items beyond the first grid)
   unsigned int max_k_over;           // longest cropped list that did not fit the sweep's global scratch
-  unsigned int pad0[3];
+  unsigned int n_pairs;              // split sweep: (sample, orientation) pairs queued for k_sweep_orient
+  unsigned int pad0[2];
+  unsigned long long list_top;       // split sweep: ints reserved in the list arena
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
   unsigned int pad1;
@@ -146,6 +148,10 @@ struct ag2_ctx {
   size_t arena_points = 0;
   ag2::DevBuf d_overflow;  // int sample ids that need the global-memory sweep
   ag2::DevBuf d_gscratch;  // global cropped-list scratch for the overflow path
+  ag2::DevBuf d_lists;     // split sweep: cropped lists (float4: centred xyz, sorted position) of the samples with a passing orientation
+  ag2::DevBuf d_pairs;     // split sweep: SweepPair queue
+  ag2::DevBuf d_obox;      // split sweep: per-workgroup closing-region index lists beyond the LDS part
+  size_t list_ints = 0;    // capacity of d_lists in points; grown on demand like the arena
   int sweep_gcap = 1 << 16;  // points per workgroup of that scratch; grows to the longest list met
   int sweep_g2 = 1024;       // workgroups of the stage that uses it
   ag2::DevBuf d_list;      // int compacted slot ids (hypotheses in order)

@@ -104,6 +104,10 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
       c->sweep_g2 = (int)g2;
       continue;
     }
+    if (hs.err_flags & 2u) {  // list arena of the split sweep too small: grow to what this run asked for, retry
+      c->list_ints = std::max<size_t>((size_t)hs.list_top + ((size_t)hs.list_top >> 3), c->list_ints * 2);
+      continue;
+    }
     if (hs.err_flags & 1u) {  // arena too small: grow to what this run asked for, retry
       c->arena_points = std::max<size_t>((size_t)hs.arena_top + ((size_t)hs.arena_top >> 3), c->arena_points * 2);
       continue;

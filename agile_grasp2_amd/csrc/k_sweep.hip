@@ -335,13 +335,6 @@ __global__ void __launch_bounds__(64) k_frames_finish(const HandConst* __restric
     }                                                                  \
   } while (0)
 
-template <int NW>
-struct Red {
-  double d[2][NW][12];
-  unsigned u[2][NW][4];
-  int i[2][NW][2];
-};
-
 constexpr int kMaxPieces = 1024;
 #ifndef AG2_SWEEP_GROUP
 #define AG2_SWEEP_GROUP 8
@@ -400,7 +393,9 @@ static_assert(kGposCap <= 65536, "in-box indices are 16 bits");
 //   STAGE 1: the samples stage 0 handed on (dense clouds); centred coordinates + positions of the
 //            cropped list in a per-workgroup global scratch (four 256-thread workgroups per CU)
 // RMAX: compile-time bound on num_orientations (8, 16 or 32) for the per-orientation registers
-template <int STAGE, int RMAX>
+// SPLIT: stop at the gates -- the sample's list goes to the list arena, its passing orientations to
+// the pair queue of k_sweep_orient (k_sweep_orient.hip); !SPLIT: the per-orientation passes run here
+template <int STAGE, int RMAX, bool SPLIT>
 __global__ void __launch_bounds__(sweep_threads(STAGE),
                                   (STAGE == 0 ? kStage0WgPerCu : 4) * sweep_threads(STAGE) / 256)
 k_sweep(SweepArgs A) {
@@ -990,6 +985,42 @@ k_sweep(SweepArgs A) {
       hand_l = open ? (free_ & (free_ >> 10) & 0x3FFu) : 0u;        // finger_hand.cpp:313-325
     }
     unsigned long long todo = __ballot(hand_l != 0u);               // hand_search.cpp:370
+    if constexpr (SPLIT) {
+      if (todo) {  // (uniform: every wave holds the same gates)
+        if (tid == 0) {
+          long long loff = (long long)atomicAdd(&A.st->list_top, (unsigned long long)K);
+          if (loff + K > A.list_cap) {
+            atomicOr(&A.st->err_flags, 2u);  // the host grows the list arena and repeats the run
+            loff = -1;
+          }
+          S.arena_off = loff;
+        }
+        __syncthreads();
+        const long long loff = S.arena_off;
+        if (loff >= 0) {
+          for (int j = tid; j < K; j += NT) {
+            float x, y, z;
+            ldp(j, x, y, z);
+            A.lists[loff + j] = make_float4(x, y, z, __int_as_float(pos_at(j)));
+          }
+          if (wid == 0) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&A.st->n_pairs, (unsigned)__popcll(todo));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (hand_l != 0u) {
+              SweepPair pr;
+              pr.t = t;
+              pr.oi = lane;
+              pr.hand = hand_l;
+              pr.K = K;
+              pr.list_off = loff;
+              A.pairs[base + (unsigned)__popcll(todo & lt_mask)] = pr;
+            }
+          }
+        }
+      }
+    }
+    if constexpr (!SPLIT)
     while (todo) {
       AG2_PROF(7);
       const int oi = __ffsll((long long)todo) - 1;
@@ -1421,8 +1452,20 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   }
   const size_t lds = sweep_lds_bytes(0);
   typedef void (*SweepFn)(SweepArgs);
-  const SweepFn fn_lds = (R <= 8) ? k_sweep<0, 8> : (R <= 16 ? k_sweep<0, 16> : k_sweep<0, 32>);
-  const SweepFn fn_glb = (R <= 8) ? k_sweep<1, 8> : (R <= 16 ? k_sweep<1, 16> : k_sweep<1, 32>);
+  // one-kernel sweep (AG2_SWEEP_MONO=1, A/B) or split at the gates (default)
+  static const bool split = getenv("AG2_SWEEP_MONO") == nullptr;
+  const SweepFn fn_lds = split ? ((R <= 8) ? k_sweep<0, 8, true> : (R <= 16 ? k_sweep<0, 16, true> : k_sweep<0, 32, true>))
+                               : ((R <= 8) ? k_sweep<0, 8, false> : (R <= 16 ? k_sweep<0, 16, false> : k_sweep<0, 32, false>));
+  const SweepFn fn_glb = split ? ((R <= 8) ? k_sweep<1, 8, true> : (R <= 16 ? k_sweep<1, 16, true> : k_sweep<1, 32, true>))
+                               : ((R <= 8) ? k_sweep<1, 8, false> : (R <= 16 ? k_sweep<1, 16, false> : k_sweep<1, 32, false>));
+  if (split) {
+    if (c->list_ints == 0) c->list_ints = (size_t)16 << 20;  // 16 Mi points = 256 MiB; grown on demand
+    AG2_HIP(c, c->d_lists.reserve(c->list_ints * 16));
+    AG2_HIP(c, c->d_pairs.reserve(std::max<size_t>(n_slots, 1) * sizeof(SweepPair)));
+    A.lists = c->d_lists.as<float4>();
+    A.list_cap = (long long)c->list_ints;
+    A.pairs = c->d_pairs.as<SweepPair>();
+  }
   const int grid = (int)std::min<size_t>(s, 256 * kStage0WgPerCu);
   // first stage: one workgroup per sample, or -- AG2_SWEEP_WAVE=1 -- one wave per sample
   // (k_sweep_wave.hip: the same results; measured slower at configuration 2)
@@ -1459,6 +1502,10 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   A.gcap = gcap;
   hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads1), sweep_lds_bytes(1), c->stream, A);
   AG2_HIP(c, hipGetLastError());
+  if (split) {
+    const int rc = launch_sweep_orient(c, A, n_slots);
+    if (rc) return rc;
+  }
   AG2_HIP(c, stage_event(c, 11));
   if (want_prof) {
     unsigned long long h[8];

@@ -51,6 +51,26 @@ struct SweepArgs {
   float min_z;
   int flags;                 // bit0: no row tightening (exact K2 accounting, diagnostic)
   unsigned long long* prof;  // optional per-phase cycle sums (AG2_SWEEP_PROF=1), else nullptr
+  // split sweep: the first kernels stop at the gates and queue (sample, orientation) pairs for
+  // k_sweep_orient, with the sample's cropped list in the list arena: one float4 per point, the
+  // centred coordinates p - q (float, the value the crop computed) and the sorted position as bits
+  float4* lists;
+  long long list_cap;        // points
+  struct SweepPair* pairs;   // [n_samples * R]
+};
+
+struct SweepPair {
+  int t, oi;                 // sample (position in this run's list), orientation
+  unsigned hand;             // the 10 hand bits of the orientation (finger_hand.cpp:313-325)
+  int K;                     // length of the sample's cropped list
+  long long list_off;        // its first entry in the list arena
+};
+
+template <int NW>
+struct Red {
+  double d[2][NW][12];
+  unsigned u[2][NW][4];
+  int i[2][NW][2];
 };
 
 // Shrink the x-cell range [cxa, cxb] of stencil row (cy, cz) to what the sphere |p - q| < r and the
@@ -99,6 +119,8 @@ __device__ __forceinline__ void tighten_row(const GridDesc& G, const HandConst& 
   }
 }
 
+// k_sweep_orient.hip
+int launch_sweep_orient(ag2_ctx* c, const SweepArgs& A, size_t n_slots);
 // k_sweep_wave.hip
 size_t sweep_wave_gpos_ints(int grid);
 int launch_sweep_wave(ag2_ctx* c, const SweepArgs& A, size_t s, int R);

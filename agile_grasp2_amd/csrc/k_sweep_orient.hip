@@ -1,0 +1,466 @@
+// k_sweep_orient.hip -- K3, second half: the per-orientation passes of the hand sweep, one workgroup
+// per (sample, orientation) pair that passed the gates.
+//
+// calculateHand's tail (hand_search.cpp:366-426) for one orientation: deepenHand
+// (finger_hand.cpp:96-134), computePointsInClosingRegion (:137-180), calculateGraspParameters
+// (:183-214), the unit-box scaling (hand_search.cpp:399-409), Antipodal::evaluateGrasp
+// (antipodal.cpp:8-84), the prune predicate (grasp_detector.cpp:363-395) and the record.
+//
+// k_sweep used to run these passes inside the sample's workgroup, one passing orientation after the
+// other.  They are the part of the sweep with the most live state (rotated frame, eight f64 extents, scaling
+// constants: the spills of the one-kernel sweep were here) and the least parallelism (0.5 passing
+// orientations per sample at configuration 2, 1.4 at configuration 3, a few thousand points each).
+// Split off, every pair is its own workgroup: the first kernels (k_sweep<.., SPLIT>) stop at the gates,
+// leave the sample's cropped list in a list arena -- one float4 per point: the centred coordinates
+// p - q (float: the very value the crop computed) and the sorted position -- and queue the pair; this
+// kernel streams the list without any indirection.  Same arithmetic, same results.
+#include "ag2_internal.h"
+#include "k_sweep_common.h"
+
+namespace ag2 {
+
+constexpr int kOThreads = 256;
+constexpr int kONW = kOThreads / kWave;
+constexpr int kOMaskWords = 16;    // 64-bit membership ballots of one wave's quarter of a chunk
+// lists are staged in LDS in chunks of this many points (the usual list is one chunk)
+constexpr int kOStage = 2432;
+static_assert((((kOStage + 3) / 4 + 63) & ~63) / 64 <= 16, "mask words per wave");
+
+struct OrientShared {
+  double fs[20], fsr[20];
+  double depths[kMaxDepths];
+  Red<kONW> red;
+  unsigned long long inmask[kONW][kOMaskWords];
+  int next_w[2];
+  long long arena_off;
+  struct {
+    struct {
+      float px[kOStage], py[kOStage], pz[kOStage];  // the staged chunk: centred coordinates ...
+      unsigned short box16[kOStage];               // ... and, for a one-chunk list, its members' indices
+    } st;
+  } u;
+};
+static_assert(sizeof(OrientShared) * 4 <= 160 * 1024, "k_sweep_orient: four workgroups per CU");
+
+__global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
+  __shared__ OrientShared S;
+  constexpr int NT = kOThreads, NW = kONW;
+  const HandConst& hc = *A.hc;
+  const float cloud_min_z = A.gp ? A.gp->min_z : A.min_z;
+  const int slot_base = A.fa ? (int)A.fa->slot_base : A.slot_base;
+  const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int R = hc.R;
+  const double hh = hc.hand_height;
+  const int n_work = (int)A.st->n_pairs;
+  if (n_work == 0) return;
+  if (tid < 20) {
+    S.fs[tid] = hc.fs[tid];
+    S.fsr[tid] = hc.fsr[tid];
+  }
+  if (tid < kMaxDepths) S.depths[tid] = hc.depths[tid];
+  __syncthreads();
+  const int n_depths = hc.n_depths;
+  const double hand_depth = hc.hand_depth;
+  const double top0 = hc.init_bite, bottom0 = hc.init_bite - hc.hand_depth;
+  int red_sel = 0;
+  unsigned nxt = 0;
+  int it = 0;
+  auto next_work = [&]() -> int {
+    if (tid == 0) S.next_w[it & 1] = (int)nxt;
+    __syncthreads();  // also: every reader of S of this iteration is done
+    const int w = __builtin_amdgcn_readfirstlane(S.next_w[it & 1]);
+    it++;
+    return w;
+  };
+  for (int w = blockIdx.x; w < n_work; w = next_work()) {
+    if (tid == 0) nxt = gridDim.x + atomicAdd(&A.st->work_next[2], 1u);
+    const SweepPair pr = A.pairs[w];
+    const int t = pr.t, oi = pr.oi, K = pr.K;
+    const unsigned hand = pr.hand;
+    const float4* plist = A.lists + pr.list_off;
+    // The list is worked through in chunks of kOStage points staged in LDS: every thread has five loads
+    // of the (contiguous) list in flight, and the arithmetic of a pass reads LDS.  The usual list is
+    // ONE chunk, staged once for all passes; a long one is re-staged by each pass.
+    const int nchunks = (K + kOStage - 1) / kOStage;
+    auto stage = [&](int c) -> int {
+      const int c0 = c * kOStage, clen = min(kOStage, K - c0);
+      constexpr int kPer = (kOStage + NT - 1) / NT, kHalf = (kPer + 1) / 2;
+      __syncthreads();  // the readers of the chunk that is being replaced are done
+#pragma unroll
+      for (int h = 0; h < 2; h++) {  // five loads in flight per thread, twice
+        float4 v[kHalf];
+#pragma unroll
+        for (int k = 0; k < kHalf; k++) v[k] = plist[c0 + min(tid + (h * kHalf + k) * NT, clen - 1)];
+#pragma unroll
+        for (int k = 0; k < kHalf; k++) {
+          const int j = tid + (h * kHalf + k) * NT;
+          if (j < clen) {
+            S.u.st.px[j] = v[k].x;
+            S.u.st.py[j] = v[k].y;
+            S.u.st.pz[j] = v[k].z;
+          }
+        }
+      }
+      __syncthreads();
+      return clen;
+    };
+    const double* fr = A.frames + (size_t)t * 12;
+    const double smp[3] = {fr[0], fr[1], fr[2]};
+    // frame = [normal binormal curvature_axis] as columns, hand_search.cpp:325-326
+    const double F[3][3] = {{fr[3], fr[6], fr[9]}, {fr[4], fr[7], fr[10]}, {fr[5], fr[8], fr[11]}};
+    const int nvalid = __popc(hand);
+    // rot = [c -s 0; s c 0; 0 0 1], frame_rot = frame * rot, hand_search.cpp:356-357
+    const double cs = hc.cos_t[oi], sn = hc.sin_t[oi];
+    double Fr[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      Fr[a][0] = (F[a][0] * cs + F[a][1] * sn) + F[a][2] * 0.0;
+      Fr[a][1] = (F[a][0] * (-1.0 * sn) + F[a][1] * cs) + F[a][2] * 0.0;
+      Fr[a][2] = (F[a][0] * 0.0 + F[a][1] * 0.0) + F[a][2] * 1.0;
+    }
+    // deepenHand, finger_hand.cpp:96-134: middle valid hand = valid[ceil(n/2) - 1]
+    int idx = 0;
+    {
+      const int want = (nvalid + 1) / 2 - 1;
+      int seen = 0;
+      for (int k = 0; k < 10; k++)
+        if (hand & (1u << k)) {
+          if (seen == want) idx = k;
+          seen++;
+        }
+    }
+    const double fl0 = S.fs[idx], fl1 = S.fsr[idx], fr0 = S.fs[10 + idx], fr1 = S.fsr[10 + idx];
+    auto rot_xy = [&](int j, double& x, double& y) {  // staged point j in the rotated frame
+      const double p0 = (double)S.u.st.px[j], p1 = (double)S.u.st.py[j], p2 = (double)S.u.st.pz[j];
+      x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
+      y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
+    };
+    // pass B: first depth step that fails (some point under the finger pads or behind the hand)
+    // (the same pass yields surface = min y over ALL rotated points, finger_hand.cpp:158)
+    int kfail = n_depths;
+    double miny = __builtin_inf();
+    for (int c = 0; c < nchunks; c++) {
+      const int clen = stage(c);
+      for (int j = tid; j < clen; j += NT) {
+        double x, y;
+        rot_xy(j, x, y);
+        miny = (y < miny) ? y : miny;
+        const bool zone = (x > fl0 && x < fl1) || (x > fr0 && x < fr1);
+        for (int di = 0; di < kfail; di++) {
+          const double d = S.depths[di];
+          if (y < d && (zone || y < d - hand_depth)) {
+            kfail = di;
+            break;
+          }
+        }
+      }
+    }
+    kfail = wave_min_i(kfail);
+    miny = wave_min_d(miny);
+    red_sel ^= 1;
+    if (lane == 0) {
+      S.red.i[red_sel][wid][0] = kfail;
+      S.red.d[red_sel][wid][0] = miny;
+    }
+    __syncthreads();
+    kfail = n_depths;
+    double surface = __builtin_inf();
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      kfail = min(kfail, S.red.i[red_sel][k][0]);
+      const double v = S.red.d[red_sel][k][0];
+      surface = (v < surface) ? v : surface;
+    }
+    double top = top0, bottom = bottom0;
+    if (kfail > 0) {  // last successful step, finger_hand.cpp:128-129
+      top = S.depths[kfail - 1];
+      bottom = top - hand_depth;
+    }
+    // closing region, finger_hand.cpp:137-180
+    const double left = fl0 + hc.finger_width;
+    const double right = fr0;
+    const double center = 0.5 * (left + right);
+    // pass C: members of the closing region.  Inside a chunk every wave takes a contiguous quarter, so
+    // that (chunk, wave, lane) order is list order; the membership ballots of a chunk are kept in LDS.
+    auto seg_of = [&](int clen, int& jb, int& je) {
+      const int seg = (((clen + NW - 1) / NW) + 63) & ~63;
+      jb = min(wid * seg, clen);
+      je = min(jb + seg, clen);
+    };
+    auto members = [&](int clen, double& mn, double& mx) -> int {  // this wave's count in the chunk
+      int jb, je, cnt = 0;
+      seg_of(clen, jb, je);
+      for (int j0 = jb; j0 < je; j0 += 64) {
+        const int j = j0 + lane;
+        bool in = false;
+        if (j < je) {
+          double x, y;
+          rot_xy(j, x, y);
+          in = (y < top && x > left && x < right);
+          if (in) {
+            mn = (x < mn) ? x : mn;
+            mx = (x > mx) ? x : mx;
+          }
+        }
+        const unsigned long long mask = __ballot(in);
+        if (lane == 0) S.inmask[wid][(j0 - jb) >> 6] = mask;
+        cnt += __popcll(mask);
+      }
+      return cnt;
+    };
+    int cnt = 0;
+    double mnx = __builtin_inf(), mxx = -__builtin_inf();
+    for (int c = 0; c < nchunks; c++) {
+      const int clen = (nchunks > 1) ? stage(c) : K;  // (a single chunk is still staged from pass B)
+      cnt += members(clen, mnx, mxx);
+    }
+    mnx = wave_min_d(mnx);
+    mxx = wave_max_d(mxx);
+    red_sel ^= 1;
+    if (lane == 0) {
+      S.red.i[red_sel][wid][0] = cnt;
+      S.red.d[red_sel][wid][0] = mnx;
+      S.red.d[red_sel][wid][1] = mxx;
+    }
+    __syncthreads();
+    int P = 0, pbase_w = 0;
+    mnx = __builtin_inf();
+    mxx = -__builtin_inf();
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      const int ck = S.red.i[red_sel][k][0];
+      if (k < wid) pbase_w += ck;
+      P += ck;
+      const double a = S.red.d[red_sel][k][0], b = S.red.d[red_sel][k][1];
+      mnx = (a < mnx) ? a : mnx;
+      mxx = (b > mxx) ? b : mxx;
+    }
+    if (P == 0) continue;                                         // hand_search.cpp:377-381
+    const int slot = t * R + oi;
+    if (tid == 0) {
+      long long off = -1;
+      if (A.emit_lists) {
+        off = (long long)atomicAdd(&A.st->arena_top, (unsigned long long)P);
+        if (off + P > A.arena_cap) {
+          atomicOr(&A.st->err_flags, 1u);
+          off = -1;
+        }
+      }
+      S.arena_off = off;
+    }
+    __syncthreads();
+    const long long off = S.arena_off;
+    // pass D: unit-box scaling (hand_search.cpp:399-409), list emission, antipodal extents
+    const double baseline = 0.1;
+    const double left_const = left - 0.5 * (baseline - (right - left));
+    const double lower[3] = {left_const, bottom, -1.0 * hh};
+    const double scales[3] = {1.0 / baseline, 1.0 / (top - bottom), 1.0 / (2.0 * hh)};
+    const double lt = scales[0] * (mnx - lower[0]) + 0.003;       // antipodal.cpp:16
+    const double rt = scales[0] * (mxx - lower[0]) - 0.003;       // antipodal.cpp:17
+    int nl = 0, nr = 0;
+    double e[8] = {-__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf(),
+                   -__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf()};
+    // e: lmaxy lminy lmaxz lminz rmaxy rminy rmaxz rminz
+    auto emit = [&](int bpos, int jl, int jg) {  // member jl of the staged chunk = list entry jg
+      const double p0 = (double)S.u.st.px[jl], p1 = (double)S.u.st.py[jl], p2 = (double)S.u.st.pz[jl];
+      const float4 nn = A.nrm[__float_as_int(plist[jg].w)];  // hand_search.cpp:211, :394: the point's normal
+      const double q0 = (double)nn.x, q1 = (double)nn.y, q2 = (double)nn.z;
+      double X[3], Y[3], U[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        X[a] = (Fr[0][a] * p0 + Fr[1][a] * p1) + Fr[2][a] * p2;
+        Y[a] = (Fr[0][a] * q0 + Fr[1][a] * q1) + Fr[2][a] * q2;
+        U[a] = scales[a] * (X[a] - lower[a]);
+      }
+      if (off >= 0) {
+        double* dst = A.arena + (size_t)(off + bpos) * 6;
+        dst[0] = U[0]; dst[1] = U[1]; dst[2] = U[2];
+        dst[3] = Y[0]; dst[4] = Y[1]; dst[5] = Y[2];
+      }
+      const double ldot = (-1.0 * Y[0] + 0.0 * Y[1]) + 0.0 * Y[2];  // antipodal.cpp:20-25
+      const double rdot = (1.0 * Y[0] + 0.0 * Y[1]) + 0.0 * Y[2];
+      if (ldot > hc.cos_fc && U[0] < lt) {
+        nl++;
+        e[0] = (U[1] > e[0]) ? U[1] : e[0]; e[1] = (U[1] < e[1]) ? U[1] : e[1];
+        e[2] = (U[2] > e[2]) ? U[2] : e[2]; e[3] = (U[2] < e[3]) ? U[2] : e[3];
+      }
+      if (rdot > hc.cos_fc && U[0] > rt) {
+        nr++;
+        e[4] = (U[1] > e[4]) ? U[1] : e[4]; e[5] = (U[1] < e[5]) ? U[1] : e[5];
+        e[6] = (U[2] > e[6]) ? U[2] : e[6]; e[7] = (U[2] < e[7]) ? U[2] : e[7];
+      }
+    };
+    if (nchunks == 1) {
+      // the usual case: the masks of pass C give every member its ordered position; the members are
+      // listed (16-bit indices) so that ALL threads share the arithmetic of the emission
+      int jb, je;
+      seg_of(K, jb, je);
+      int run = pbase_w;
+      for (int j0 = jb; j0 < je; j0 += 64) {
+        const unsigned long long mask = S.inmask[wid][(j0 - jb) >> 6];  // written by this wave
+        if ((mask >> lane) & 1ull) S.u.st.box16[run + __popcll(mask & lt_mask)] = (unsigned short)(j0 + lane);
+        run += __popcll(mask);
+      }
+      __syncthreads();
+      for (int b = tid; b < P; b += NT) {
+        const int j = (int)S.u.st.box16[b];
+        emit(b, j, j);
+      }
+    } else {
+      // a long list: chunk by chunk, every wave emits the members of its quarter at their ordered
+      // positions (count per wave -> one LDS hop -> offsets)
+      int done = 0;  // members of the chunks before this one
+      for (int c = 0; c < nchunks; c++) {
+        const int clen = stage(c);
+        double d0 = 0.0, d1 = 0.0;
+        const int mine = members(clen, d0, d1);
+        red_sel ^= 1;
+        if (lane == 0) S.red.i[red_sel][wid][0] = mine;
+        __syncthreads();
+        int run = done;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+          const int ck = S.red.i[red_sel][k][0];
+          if (k < wid) run += ck;
+          done += ck;
+        }
+        int jb, je;
+        seg_of(clen, jb, je);
+        for (int j0 = jb; j0 < je; j0 += 64) {
+          const unsigned long long mask = S.inmask[wid][(j0 - jb) >> 6];
+          if ((mask >> lane) & 1ull) emit(run + __popcll(mask & lt_mask), j0 + lane, c * kOStage + j0 + lane);
+          run += __popcll(mask);
+        }
+      }
+    }
+    nl = wave_sum_i(nl);
+    nr = wave_sum_i(nr);
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      e[k] = wave_max_d(e[k]);
+      e[k + 1] = wave_min_d(e[k + 1]);
+    }
+    red_sel ^= 1;
+    if (lane == 0) {
+      S.red.i[red_sel][wid][0] = nl;
+      S.red.i[red_sel][wid][1] = nr;
+#pragma unroll
+      for (int k = 0; k < 8; k++) S.red.d[red_sel][wid][k] = e[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      nl = nr = 0;
+      for (int k = 0; k < 8; k += 2) {
+        e[k] = -__builtin_inf();
+        e[k + 1] = __builtin_inf();
+      }
+      for (int wv = 0; wv < NW; wv++) {
+        nl += S.red.i[red_sel][wv][0];
+        nr += S.red.i[red_sel][wv][1];
+        for (int k = 0; k < 8; k += 2) {
+          const double a = S.red.d[red_sel][wv][k], b = S.red.d[red_sel][wv][k + 1];
+          e[k] = (a > e[k]) ? a : e[k];
+          e[k + 1] = (b < e[k + 1]) ? b : e[k + 1];
+        }
+      }
+      int label = 0;
+      if (nl > 0 || nr > 0) label = 1;                              // antipodal.cpp:48-51
+      if (nl > 0 && nr > 0) {                                       // :54-81
+        const double top_y = (e[0] < e[4]) ? e[0] : e[4], bot_y = (e[1] > e[5]) ? e[1] : e[5];
+        const double top_z = (e[2] < e[6]) ? e[2] : e[6], bot_z = (e[3] > e[7]) ? e[3] : e[7];
+        if (top_y > bot_y && top_z > bot_z) label = 2;
+      }
+      ag2_hypothesis h;
+      const double ys[3] = {surface, bottom, top};
+      double* dstv[3] = {h.surface, h.bottom, h.top};
+      for (int k = 0; k < 3; k++)                                   // finger_hand.cpp:189-199
+        for (int a = 0; a < 3; a++)
+          dstv[k][a] = ((Fr[a][0] * center + Fr[a][1] * ys[k]) + Fr[a][2] * 0.0) + smp[a];
+      for (int a = 0; a < 3; a++) {                                 // hand_search.cpp:383-385
+        h.binormal[a] = Fr[a][0];
+        h.approach[a] = Fr[a][1];
+        h.axis[a] = Fr[a][2];
+      }
+      h.width = mxx - mnx;                                          // hand_search.cpp:397
+      h.score = 0.0;
+      h.sample_slot = slot_base + t;
+      h.orientation = oi;
+      h.half_antipodal = (label >= 1) ? 1 : 0;                      // hand_search.cpp:417-418
+      h.full_antipodal = (label == 2) ? 1 : 0;
+      h.reserved = 0;
+      h.n_points = P;
+      // pruneGraspsOnHandParameters, grasp_detector.cpp:363-395
+      bool keep = !(hc.filter_half && !h.half_antipodal);
+      if (keep) {
+        const double hw = 0.5 * hc.hand_outer_diameter;
+        double mn[3], mx[3];
+        for (int a = 0; a < 3; a++) {
+          const double c5[5] = {h.bottom[a] + hw * h.binormal[a], h.bottom[a] - hw * h.binormal[a],
+                                h.top[a] + hw * h.binormal[a], h.top[a] - hw * h.binormal[a],
+                                h.bottom[a] - 0.10 * h.approach[a]};
+          mn[a] = mx[a] = c5[0];
+          for (int k = 1; k < 5; k++) {
+            mn[a] = (c5[k] < mn[a]) ? c5[k] : mn[a];
+            mx[a] = (c5[k] > mx[a]) ? c5[k] : mx[a];
+          }
+        }
+        keep = h.width >= hc.min_aperture && h.width <= hc.max_aperture &&
+               mn[2] >= (double)cloud_min_z && mn[1] >= (double)hc.ws_min_y &&
+               mx[1] <= (double)hc.ws_max_y && mn[0] >= (double)hc.ws_min_x &&
+               mx[0] <= (double)hc.ws_max_x;
+      }
+      A.table[slot] = h;
+      A.tab_off[slot] = off;
+      A.tab_keep[slot] = keep ? 1 : 4;  // slot state: 0 empty, 1 survives the prune, 4 pruned away
+      // (the run's statistics -- hypotheses, their points, the largest list -- are gathered from the slot
+      // table by k_hyp_stats afterwards: three atomics per pair on one cache line, issued by thousands
+      // of workgroups at once, cost this kernel a third of its time)
+    }
+  }
+}
+
+// n_hyp, sum_p, max_p of a run from its slot table: 16 slot states per thread and load; the point
+// counts of the occupied slots are read from the records.  A few atomics per workgroup.
+__global__ void __launch_bounds__(256) k_hyp_stats(const unsigned char* __restrict__ keep,
+                                                   const ag2_hypothesis* __restrict__ table, int n_slots,
+                                                   DevStats* st) {
+  const int s0 = (blockIdx.x * 256 + threadIdx.x) * 16;
+  unsigned cnt = 0, mx = 0;
+  unsigned long long sum = 0;
+  if (s0 < n_slots) {  // (the state buffer is padded past n_slots: DevBuf slack)
+    const uint4 v = *reinterpret_cast<const uint4*>(keep + s0);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const unsigned b = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+      if (b != 0u && s0 + k < n_slots) {
+        const unsigned p = (unsigned)table[s0 + k].n_points;
+        cnt++;
+        sum += p;
+        mx = max(mx, p);
+      }
+    }
+  }
+  cnt = (unsigned)wave_sum_i((int)cnt);
+  const unsigned slo = (unsigned)wave_sum_i((int)(unsigned)(sum & 0xFFFFFFu));  // < 2^24 per lane: no overflow
+  const unsigned shi = (unsigned)wave_sum_i((int)(unsigned)(sum >> 24));
+  mx = (unsigned)(-wave_min_i(-(int)mx));
+  if (lane_id() == 0 && cnt) {
+    atomicAdd(&st->n_hyp, cnt);
+    atomicAdd(&st->sum_p, (unsigned long long)slo + ((unsigned long long)shi << 24));
+    atomicMax(&st->max_p, mx);
+  }
+}
+
+int launch_sweep_orient(ag2_ctx* c, const SweepArgs& A, size_t n_slots) {
+  // the queue length is read on the device: a fixed launch, the surplus workgroups leave at once
+  const int grid = (int)std::min<size_t>(std::max<size_t>(n_slots, 1), 256 * 8);
+  hipLaunchKernelGGL(k_sweep_orient, dim3(grid), dim3(kOThreads), 0, c->stream, A);
+  hipLaunchKernelGGL(k_hyp_stats, dim3((unsigned)((n_slots + 4095) / 4096)), dim3(256), 0, c->stream, A.tab_keep,
+                     A.table, (int)n_slots, A.st);
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+}  // namespace ag2
