@@ -49,7 +49,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_points", "n_valid_points", "n_samples", "n_frames", "n_hypotheses", "n_pruned",
         "n_scored", "n_selected", "sum_k1", "sum_k2", "sum_kcrop", "sum_p", "n_overflow_samples",
-        "reserved")]
+        "list_points")]
 
 
 class FrameInfo(C.Structure):

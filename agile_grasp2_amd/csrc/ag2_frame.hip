@@ -402,6 +402,7 @@ int ag2_detect_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, s
       c->cnt.sum_kcrop = (int64_t)fo->st.sum_kcrop;
       c->cnt.sum_p = (int64_t)fo->st.sum_p;
       c->cnt.n_overflow_samples = fo->st.n_overflow;
+      c->cnt.list_points = (int64_t)fo->st.list_top;
       const size_t k = fo->n_out;
       c->cnt.n_selected = (int64_t)k;
       *n_selected = k;

@@ -119,6 +119,7 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     c->cnt.sum_kcrop = (int64_t)hs.sum_kcrop;
     c->cnt.sum_p = (int64_t)hs.sum_p;
     c->cnt.n_overflow_samples = hs.n_overflow;  // handed to the sweep's global-scratch stage
+    c->cnt.list_points = (int64_t)hs.list_top;
     if (compact_mode >= 0) c->n_img = hs.n_list;
     c->max_p = (int)hs.max_p;
     stage_elapsed(c, &c->times.frames_ms, 0, 1);

@@ -407,7 +407,12 @@ k_sweep(SweepArgs A) {
   constexpr int kCapL = kLdsCap;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SweepShared<NT>& S = *reinterpret_cast<SweepShared<NT>*>(smem_raw);
-  const int CAP = LITE ? kGposCap : (LDS_STORE ? kCapL : A.gcap);
+  // Split sweep, stage 1: the cropped list is written ONCE, in the form k_sweep_orient reads (one
+  // float4 per point in the list arena), and pass A streams it from there -- no per-workgroup scratch,
+  // no copy at the gates, and no bound on the list length other than the arena's (which grows).
+  constexpr bool ARENA = SPLIT && STAGE == 1;
+  const int CAP = LITE ? kGposCap : (LDS_STORE ? kCapL : (ARENA ? 0x7fffffff : A.gcap));
+  float4* L = nullptr;  // ARENA: this sample's list
   float* pbase;
   unsigned short* box16 = nullptr;
   int* box32 = nullptr;
@@ -417,8 +422,8 @@ k_sweep(SweepArgs A) {
     pbase = reinterpret_cast<float*>(smem_raw + sweep_ctl_bytes(STAGE));
     box16 = reinterpret_cast<unsigned short*>(pbase + (LITE ? 1 : 4) * kCapL);
   } else {
-    pbase = A.gscratch + (size_t)blockIdx.x * 5 * (size_t)A.gcap;
-    box32 = reinterpret_cast<int*>(pbase + 4 * (size_t)A.gcap);
+    pbase = ARENA ? nullptr : A.gscratch + (size_t)blockIdx.x * 5 * (size_t)A.gcap;
+    box32 = ARENA ? nullptr : reinterpret_cast<int*>(pbase + 4 * (size_t)A.gcap);
   }
   float* PX = pbase;
   float* PY = pbase + CAP;
@@ -486,7 +491,10 @@ k_sweep(SweepArgs A) {
     if (!A.frame_ok[t]) continue;  // uniform
     const float4 q = A.sample_q[t];
     bool gmode = false;  // stage 0: this sample's list lives in the global slice (set once K is known)
-    auto pos_at = [&](int j) -> int { return (LITE && gmode) ? gpos[j] : POS[j]; };
+    auto pos_at = [&](int j) -> int {
+      if (ARENA) return __float_as_int(L[j].w);
+      return (LITE && gmode) ? gpos[j] : POS[j];
+    };
     auto ldp = [&](int j, float& x, float& y, float& z) {  // cropped point j, centred on the sample
       if (LITE) {
         const float4 p = A.pts[pos_at(j)];
@@ -494,9 +502,16 @@ k_sweep(SweepArgs A) {
         y = p.y - q.y;
         z = p.z - q.z;
       } else {
-        x = PX[j];
-        y = PY[j];
-        z = PZ[j];
+        if (ARENA) {
+          const float4 v = L[j];
+          x = v.x;
+          y = v.y;
+          z = v.z;
+        } else {
+          x = PX[j];
+          y = PY[j];
+          z = PZ[j];
+        }
       }
     };
     const double* fr = A.frames + (size_t)t * 12;
@@ -739,6 +754,20 @@ k_sweep(SweepArgs A) {
       S.dead = 0u;  // read in pass A, two barriers further down
     }
     if (K == 0) continue;  // hand_search.cpp:201 (no neighbours) / no cropped points => no fingers
+    if (ARENA) {  // room for the list in the arena (kept only if an orientation passes the gates; the
+                  // arena is a bump allocator, so the others' room is simply not used again this run)
+      if (tid == 0) {
+        long long loff = (long long)atomicAdd(&A.st->list_top, (unsigned long long)K);
+        if (loff + K > A.list_cap) {
+          atomicOr(&A.st->err_flags, 2u);  // the host grows the list arena and repeats the run
+          loff = -1;
+        }
+        S.arena_off = loff;
+      }
+      __syncthreads();
+      if (S.arena_off < 0) continue;  // uniform
+      L = A.lists + S.arena_off;
+    }
     __syncthreads();
     // pass 2: write the survivors of each piece at its offset (order within a piece preserved).
     // Stage 0 stores positions only, and pass 1 left every piece's survivors as a bit mask: the list
@@ -779,8 +808,12 @@ k_sweep(SweepArgs A) {
           const unsigned long long mask = __ballot(cls == 3);
           if (cls == 3) {
             const int dst = dst0 + __popcll(mask & lt_grp);
-            PX[dst] = d.x; PY[dst] = d.y; PZ[dst] = d.z;
-            POS[dst] = pb[u] + j;
+            if (ARENA) {
+              L[dst] = make_float4(d.x, d.y, d.z, __int_as_float(pb[u] + j));
+            } else {
+              PX[dst] = d.x; PY[dst] = d.y; PZ[dst] = d.z;
+              POS[dst] = pb[u] + j;
+            }
           }
           dst0 += __popcll(mask & grp_mask);
           o += kGrp;
@@ -987,18 +1020,20 @@ k_sweep(SweepArgs A) {
     unsigned long long todo = __ballot(hand_l != 0u);               // hand_search.cpp:370
     if constexpr (SPLIT) {
       if (todo) {  // (uniform: every wave holds the same gates)
-        if (tid == 0) {
-          long long loff = (long long)atomicAdd(&A.st->list_top, (unsigned long long)K);
-          if (loff + K > A.list_cap) {
-            atomicOr(&A.st->err_flags, 2u);  // the host grows the list arena and repeats the run
-            loff = -1;
+        if (!ARENA) {
+          if (tid == 0) {
+            long long loff = (long long)atomicAdd(&A.st->list_top, (unsigned long long)K);
+            if (loff + K > A.list_cap) {
+              atomicOr(&A.st->err_flags, 2u);  // the host grows the list arena and repeats the run
+              loff = -1;
+            }
+            S.arena_off = loff;
           }
-          S.arena_off = loff;
+          __syncthreads();
         }
-        __syncthreads();
-        const long long loff = S.arena_off;
+        const long long loff = S.arena_off;  // (ARENA: where the crop put the list)
         if (loff >= 0) {
-          for (int j = tid; j < K; j += NT) {
+          for (int j = tid; !ARENA && j < K; j += NT) {
             float x, y, z;
             ldp(j, x, y, z);
             A.lists[loff + j] = make_float4(x, y, z, __int_as_float(pos_at(j)));
@@ -1459,7 +1494,8 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   const SweepFn fn_glb = split ? ((R <= 8) ? k_sweep<1, 8, true> : (R <= 16 ? k_sweep<1, 16, true> : k_sweep<1, 32, true>))
                                : ((R <= 8) ? k_sweep<1, 8, false> : (R <= 16 ? k_sweep<1, 16, false> : k_sweep<1, 32, false>));
   if (split) {
-    if (c->list_ints == 0) c->list_ints = (size_t)16 << 20;  // 16 Mi points = 256 MiB; grown on demand
+    if (c->list_ints == 0)  // 16 Mi points = 256 MiB, grown on demand (debug_flags bit 1: start tiny, to exercise that)
+      c->list_ints = (c->p.debug_flags & 2) ? (size_t)4096 : (size_t)16 << 20;
     AG2_HIP(c, c->d_lists.reserve(c->list_ints * 16));
     AG2_HIP(c, c->d_pairs.reserve(std::max<size_t>(n_slots, 1) * sizeof(SweepPair)));
     A.lists = c->d_lists.as<float4>();
@@ -1497,7 +1533,7 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   // (default: four workgroups per CU x 5 x 64 Ki words = 1.3 GB of scratch; run_hypotheses resizes
   // it when a list of the run is longer)
   const int gcap = c->sweep_gcap, g2 = c->sweep_g2;
-  AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 5 * (size_t)gcap * 4));
+  if (!split) AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 5 * (size_t)gcap * 4));  // (split: lists go to the arena)
   A.gscratch = c->d_gscratch.as<float>();
   A.gcap = gcap;
   hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads1), sweep_lds_bytes(1), c->stream, A);

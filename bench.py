@@ -476,8 +476,8 @@ def main():
                         kernels[name]["mfma_busy"] = frac
             per_kernel = pmc.get(args.config, {})
             traffic = per_kernel.get(dom)
-            if dom == "k_sweep" and traffic is not None:  # both instantiations, like the duration
-                traffic += per_kernel.get("k_sweep_overflow", 0)
+            if dom == "k_sweep" and traffic is not None:  # all of the sweep's kernels, like the duration
+                traffic += per_kernel.get("k_sweep_overflow", 0) + per_kernel.get("k_sweep_orient", 0)
             if traffic is not None:
                 traffic_source = (f"profiles/{pmc.get('_profile', {}).get(args.config, '?')} via profiles/pmc_traffic.json: "
                                   "committed rocprofv3 counter passes of this command (FETCH_SIZE and WRITE_SIZE "
@@ -485,9 +485,14 @@ def main():
             # bytes the dominant kernel HAS to write (records + point lists for the sweep) against the
             # WRITE_SIZE counter: register spills and scratch traffic show up as the excess
             wr = pmc.get("_writes", {}).get(args.config, {})
-            if dom == "k_sweep" and "k_sweep" in wr:
-                must = c.n_hypotheses * 176 + c.sum_p * 48 + c.n_hypotheses * 9
-                write_amp = (wr["k_sweep"] + wr.get("k_sweep_overflow", 0)) / max(1, must)
+            if "k_sweep" in wr:   # records + point lists + (split sweep) the cropped lists of the passing samples
+                must = c.n_hypotheses * 176 + c.sum_p * 48 + c.n_hypotheses * 9 + c.list_points * 16
+                sweep_wa = (wr["k_sweep"] + wr.get("k_sweep_overflow", 0) + wr.get("k_sweep_orient", 0)) / max(1, must)
+                kernels["k_sweep"]["write_amplification"] = round(sweep_wa, 3)
+                kernels["k_sweep"]["traffic"] = (per_kernel.get("k_sweep", 0) + per_kernel.get("k_sweep_overflow", 0) +
+                                                 per_kernel.get("k_sweep_orient", 0))
+                if dom == "k_sweep":
+                    write_amp = sweep_wa
         except Exception:
             traffic = None
     roofline = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
@@ -499,7 +504,9 @@ def main():
                                          "unit": k["unit"], "peak": k["peak"], "frac": round(k["frac"], 4)},
                                         **({"fp32_equivalent_tflops": round(k["fp32_equivalent_tflops"], 2)}
                                            if "fp32_equivalent_tflops" in k else {}),
-                                        **({"mfma_busy": k["mfma_busy"]} if "mfma_busy" in k else {}))
+                                        **({"mfma_busy": k["mfma_busy"]} if "mfma_busy" in k else {}),
+                                        **({"write_amplification": k["write_amplification"], "traffic": k["traffic"]}
+                                           if "write_amplification" in k else {}))
                                 for n, k in kernels.items()}}
     out = {
         "metric": "grasp hypotheses scored/sec on 300k-pt cloud; end-to-end detect latency",

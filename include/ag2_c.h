@@ -62,9 +62,10 @@ typedef struct ag2_params {
   int32_t num_selected;       /* 50   */
   int32_t debug_flags;        /* 0. bit0: visit every radius neighbour in the hand sweep (no
                                  sphere/slab row culling) so counters.sum_k2 is exact; results
-                                 are identical either way.  bit1: start the sweep's global scratch
-                                 at 1 024 points per workgroup instead of 65 536 (exercises the
-                                 grow-and-repeat path on small clouds; results identical) */
+                                 are identical either way.  bit1: start the sweep's list arena at
+                                 4 096 points instead of 16 Mi (and, with AG2_SWEEP_MONO=1, its global
+                                 scratch at 1 024 points per workgroup instead of 65 536): exercises
+                                 the grow-and-repeat paths on small clouds; results identical */
 } ag2_params;
 
 /* One grasp hypothesis = the fixed part of GraspHypothesis
@@ -86,7 +87,7 @@ typedef struct ag2_counters {
   int64_t n_points, n_valid_points, n_samples, n_frames, n_hypotheses, n_pruned, n_scored, n_selected;
   int64_t sum_k1, sum_k2, sum_kcrop, sum_p;  /* measured neighbourhood sizes (roofline bytes) */
   int64_t n_overflow_samples;                /* samples whose cropped list did not fit the first sweep stage */
-  int64_t reserved;
+  int64_t list_points;                       /* split sweep: points written to the list arena (16 B each) */
 } ag2_counters;
 
 /* Device time of the last call per stage, milliseconds (HIP events on the context's stream).

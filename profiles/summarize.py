@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 SHORT = {
     "k_sweep": re.compile(r"k_sweep<(true|0)"),
     "k_sweep_overflow": re.compile(r"k_sweep<(false|1|2)"),
+    "k_sweep_orient": re.compile(r"k_sweep_orient|k_hyp_stats"),
     "k_normals": re.compile(r"k_normals"),
     "k_frames": re.compile(r"k_frames"),
     "k_render": re.compile(r"k_render"),
