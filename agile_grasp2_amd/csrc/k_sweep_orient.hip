@@ -42,6 +42,8 @@ struct OrientShared {
 };
 static_assert(sizeof(OrientShared) * 4 <= 160 * 1024, "k_sweep_orient: four workgroups per CU");
 
+// (four workgroups per CU: 128 VGPRs, 52 B of scratch per lane around pass D; three per CU -- 150 VGPRs,
+// no scratch -- is equal at configuration 2 and 7 % slower at configuration 3)
 __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
   __shared__ OrientShared S;
   constexpr int NT = kOThreads, NW = kONW;
@@ -105,8 +107,8 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
       __syncthreads();
       return clen;
     };
+    stage(0);  // (here, before the frame and the rotation occupy registers)
     const double* fr = A.frames + (size_t)t * 12;
-    const double smp[3] = {fr[0], fr[1], fr[2]};
     // frame = [normal binormal curvature_axis] as columns, hand_search.cpp:325-326
     const double F[3][3] = {{fr[3], fr[6], fr[9]}, {fr[4], fr[7], fr[10]}, {fr[5], fr[8], fr[11]}};
     const int nvalid = __popc(hand);
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     int kfail = n_depths;
     double miny = __builtin_inf();
     for (int c = 0; c < nchunks; c++) {
-      const int clen = stage(c);
+      const int clen = (c == 0) ? min(kOStage, K) : stage(c);
       for (int j = tid; j < clen; j += NT) {
         double x, y;
         rot_xy(j, x, y);
@@ -372,6 +374,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
         if (top_y > bot_y && top_z > bot_z) label = 2;
       }
       ag2_hypothesis h;
+      const double smp[3] = {fr[0], fr[1], fr[2]};  // (read here, by the one thread that needs it)
       const double ys[3] = {surface, bottom, top};
       double* dstv[3] = {h.surface, h.bottom, h.top};
       for (int k = 0; k < 3; k++)                                   // finger_hand.cpp:189-199
