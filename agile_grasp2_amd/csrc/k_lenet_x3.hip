@@ -34,18 +34,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kXThreads = 512;
 constexpr int kXWaves = kXThreads / 64;
-constexpr int kXImgRow = 60;
-constexpr int kXImgPlane = 61 * 60;  // one zero row appended per channel
+constexpr int kXImgRow = 180;        // bf16 elements per staged image row (60 pixels x 3 channels, HWC)
 constexpr int kXPA = 40;             // row pitch of pa
 constexpr int kXPC = 48;             // row pitch of pc
-constexpr int kXC1Blocks = 8;        // 15 (channel, ky) rows two per block, kx 0..4 (+3 zero taps)
+constexpr int kXC1Blocks = 5;        // one ky row per block: its 5 x 3 (kx, channel) values are 15 consecutive HWC elements (+1 zero tap)
 constexpr int kXC2Main = 25;
 constexpr int kXC2Blocks = kXC2Main + 7;
 
 struct X3Shared {
   unsigned short pa[3][2][28 * kXPA][8];
   unsigned short pc[3][28 * kXPC][4];
-  unsigned char img[3 * kXImgPlane + 16];
+  unsigned short imgb[60 * kXImgRow + 16];  // the image as bf16 (u8 values are exact), HWC as handed over
 };
 static_assert(sizeof(X3Shared) <= 160 * 1024, "k_lenet_conv_x3: LDS");
 
@@ -69,7 +68,22 @@ __host__ __device__ __forceinline__ void split3(float v, unsigned short t[3]) {
   t[2] = (unsigned short)(b2 >> 16);
 }
 
+// requests in front of it stay in front, MFMAs behind it stay behind: a compiler-level memory fence
+// (the loads are plain reads the instruction selector may otherwise place anywhere) plus a
+// scheduling barrier for the machine scheduler
+__device__ __forceinline__ void x3_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ bf16x8 as_frag(const uint4& u) { return __builtin_bit_cast(bf16x8, u); }
+
+// four u8 pixels values (one dword of the HWC image) -> four bf16 at elements 4 i .. 4 i + 3
+__device__ __forceinline__ void x3_stage4(unsigned short* imgb, int i, unsigned v) {
+  const unsigned f0 = __float_as_uint((float)(v & 255u)), f1 = __float_as_uint((float)((v >> 8) & 255u)),
+                 f2 = __float_as_uint((float)((v >> 16) & 255u)), f3 = __float_as_uint((float)(v >> 24));
+  reinterpret_cast<uint2*>(imgb)[i] = make_uint2((f1 & 0xFFFF0000u) | (f0 >> 16), (f3 & 0xFFFF0000u) | (f2 >> 16));
+}
 
 // conv2 + bias + max-pool for the NT tiles mgrp, mgrp + 4, ... of this wave, one channel half
 // SH: the shared-memory layout (whole map or one band of it); TS: tile stride between a wave's tiles
@@ -91,61 +105,72 @@ __device__ __forceinline__ void x3_conv2(const SH& S, const uint4* __restrict__ 
     pc0[t] = y * kXPC + x;
   }
   const uint4* wl = w2x + (size_t)nh * 3 * 64 + lane;
-  // B fragments of block b + 1 are requested from L2 before the MFMAs of block b are issued
-  uint4 nb0 = wl[0], nb1 = wl[64], nb2 = wl[128];
-  auto mfma6 = [&](v16f a, const bf16x8& Ah, const bf16x8& Am, const bf16x8& Al, const bf16x8& Bh,
-                   const bf16x8& Bm, const bf16x8& Bl) {
-    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, a, 0, 0, 0);
-    return a;
+  // Two sets of operand fragments: while the 6 NT MFMAs of block b run, the B fragments of block
+  // b + 1 are on their way from L2 and its A fragments from LDS.  The scheduling barriers keep the
+  // requests in front of the MFMAs: left alone the compiler gives both blocks the same registers and
+  // so sinks every request behind the last use of the current block, i.e. in front of its own first
+  // use -- an L2 round trip and NT LDS round trips exposed per block.
+  struct Frags {
+    uint4 a[NT][3];
+    uint4 b[3];
   };
+  // (the whole-image kernel's 4 or 5 tiles per wave leave no room for two sets of A fragments: there
+  // only the B fragments are requested a block ahead)
+  constexpr bool kAhead = NT <= 3;
+  auto load = [&](int b, Frags& f, bool want_a, bool want_b) {
+    if (want_b) {
+      const uint4* wn = wl + (size_t)b * (2 * 3 * 64);
+      f.b[0] = wn[0];
+      f.b[1] = wn[64];
+      f.b[2] = wn[128];
+    }
+    if (!want_a) return;
+    if (b < kXC2Main) {  // one tap, channels 8 h .. 8 h + 7
+      const int ky = b / 5, kx = b - 5 * ky;
+      const int off = ky * kXPA + kx;
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int s = 0; s < 3; s++) f.a[t][s] = *reinterpret_cast<const uint4*>(&S.pa[s][h][pa0[t] + off][0]);
+    } else {  // taps 4i + 2h and 4i + 2h + 1, channels 16-19; a tap past the 25th carries zero weights and re-reads tap 24
+      const int i = b - kXC2Main;
+      const int ta = min(4 * i + 2 * h, 24), tb = min(4 * i + 2 * h + 1, 24);
+      const int offa = (ta / 5) * kXPC + ta % 5, offb = (tb / 5) * kXPC + tb % 5;
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+          const uint2 lo = *reinterpret_cast<const uint2*>(&S.pc[s][pc0[t] + offa][0]);
+          const uint2 hi = *reinterpret_cast<const uint2*>(&S.pc[s][pc0[t] + offb][0]);
+          f.a[t][s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
+  };
+  // per accumulator the six terms in the order hl, lh, mm, hm, mh, hh (smallest first); the tiles
+  // interleaved so that consecutive MFMAs are independent
+  auto mma = [&](const Frags& f) {
+    constexpr int ia[6] = {0, 2, 1, 0, 1, 0}, ib[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(f.a[t][ia[k]]), as_frag(f.b[ib[k]]), acc[t], 0, 0, 0);
+  };
+  static_assert(kXC2Blocks % 2 == 0, "x3_conv2: blocks are taken in pairs");
+  Frags f0, f1;
+  load(0, f0, kAhead, true);
 #pragma unroll 1
-  for (int b = 0; b < kXC2Main; b++) {  // rolled: one k-block's B fragments in flight at a time
-    const bf16x8 Bh = as_frag(nb0), Bm = as_frag(nb1), Bl = as_frag(nb2);
-    {
-      const uint4* wn = wl + (size_t)(b + 1) * (2 * 3 * 64);
-      nb0 = wn[0];
-      nb1 = wn[64];
-      nb2 = wn[128];
-    }
-    const int ky = b / 5, kx = b - 5 * ky;
-    const int off = ky * kXPA + kx;
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      const int p = pa0[t] + off;
-      const bf16x8 Ah = as_frag(*reinterpret_cast<const uint4*>(&S.pa[0][h][p][0]));
-      const bf16x8 Am = as_frag(*reinterpret_cast<const uint4*>(&S.pa[1][h][p][0]));
-      const bf16x8 Al = as_frag(*reinterpret_cast<const uint4*>(&S.pa[2][h][p][0]));
-      acc[t] = mfma6(acc[t], Ah, Am, Al, Bh, Bm, Bl);
-    }
-  }
-#pragma unroll 1
-  for (int i = 0; i < kXC2Blocks - kXC2Main; i++) {
-    const bf16x8 Bh = as_frag(nb0), Bm = as_frag(nb1), Bl = as_frag(nb2);
-    {
-      const uint4* wn = wl + (size_t)min(kXC2Main + i + 1, kXC2Blocks - 1) * (2 * 3 * 64);
-      nb0 = wn[0];
-      nb1 = wn[64];
-      nb2 = wn[128];
-    }
-    // taps 4i + 2h and 4i + 2h + 1; a tap past the 25th carries zero weights and re-reads tap 24
-    const int ta = min(4 * i + 2 * h, 24), tb = min(4 * i + 2 * h + 1, 24);
-    const int offa = (ta / 5) * kXPC + ta % 5, offb = (tb / 5) * kXPC + tb % 5;
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      uint4 u[3];
-#pragma unroll
-      for (int s = 0; s < 3; s++) {
-        const uint2 lo = *reinterpret_cast<const uint2*>(&S.pc[s][pc0[t] + offa][0]);
-        const uint2 hi = *reinterpret_cast<const uint2*>(&S.pc[s][pc0[t] + offb][0]);
-        u[s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      }
-      acc[t] = mfma6(acc[t], as_frag(u[0]), as_frag(u[1]), as_frag(u[2]), Bh, Bm, Bl);
-    }
+  for (int b = 0; b < kXC2Blocks; b += 2) {
+    load(b + 1, f1, kAhead, true);
+    if (!kAhead) load(b, f0, true, false);
+    x3_fence();
+    mma(f0);
+    x3_fence();
+    load(min(b + 2, kXC2Blocks - 1), f0, kAhead, true);  // (the last request is a repeat nobody uses)
+    if (!kAhead) load(b + 1, f1, true, false);
+    x3_fence();
+    mma(f1);
+    x3_fence();
   }
   const int oc = nh * 32 + r;
   if (oc < 50) {
@@ -162,13 +187,15 @@ __device__ __forceinline__ void x3_conv2(const SH& S, const uint4* __restrict__ 
   }
 }
 
-// conv1 + bias + max-pool for NT tiles (T0, T0 + 8, ...): 8 windows x 32 channels each; the pooled
-// values are split into three bf16 terms on the way into LDS
-// TS: tile stride between a wave's tiles (= waves per workgroup); PLANE: pixels of one image channel.
-// BF: the staged image already holds bf16 values (S.imgb), else u8 (S.img) converted per fragment.
-template <class SH, int NT, int TS, int PLANE, bool BF = false>
-__device__ __forceinline__ void x3_conv1(SH& S, const uint4* __restrict__ w1x, float bias1,
-                                         int T0, int lane, const unsigned short* imgb = nullptr) {
+// conv1 + bias + max-pool for NT tiles (T0, T0 + TS, ...): 8 windows x 32 channels each; the pooled
+// values are split into three bf16 terms on the way into LDS.
+// TS: tile stride between a wave's tiles (= waves per workgroup).  imgb: the staged image (or band of
+// it) as bf16 in the HWC order it was rendered in, so the 15 (kx, channel) values a window takes from
+// one image row are CONSECUTIVE: K = 5 rows x 16 (one zero-weight tap each) = 5 k-blocks, where a
+// planar image needs 8 (two (channel, ky) rows of 5 + 3 zero taps per block).
+template <class SH, int NT, int TS>
+__device__ __forceinline__ void x3_conv1(SH& S, const uint4 (&W)[kXC1Blocks][3], float bias1,
+                                         int T0, int lane, const unsigned short* imgb) {
   const int h = lane >> 5, r = lane & 31;
   const int g = r >> 2, q = r & 3;
   v16f acc[NT];
@@ -178,57 +205,54 @@ __device__ __forceinline__ void x3_conv1(SH& S, const uint4* __restrict__ w1x, f
     acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int w = 8 * (T0 + t * TS) + g;
     const int wy = w / 28, wx = w - wy * 28;
-    a0[t] = (2 * wy + (q >> 1)) * kXImgRow + 2 * wx + (q & 1);
+    // first element of this lane's half of the window's top row; its parity is that of q (the row
+    // pitch and 8 h are even, 3 * (2 wx + (q & 1)) has the parity of q): a lane-constant shift
+    a0[t] = (2 * wy + (q >> 1)) * kXImgRow + 3 * (2 * wx + (q & 1)) + 8 * h;
   }
-  uint4 nb0 = w1x[lane], nb1 = w1x[64 + lane], nb2 = w1x[128 + lane];
-#pragma unroll 1
-  for (int b = 0; b < kXC1Blocks; b++) {
-    const bf16x8 Bh = as_frag(nb0), Bm = as_frag(nb1), Bl = as_frag(nb2);
-    {  // next block's weights are in flight during this block's MFMAs
-      const uint4* wn = w1x + (size_t)min(b + 1, kXC1Blocks - 1) * (3 * 64) + lane;
-      nb0 = wn[0];
-      nb1 = wn[64];
-      nb2 = wn[128];
-    }
-    // image offset of this lane's (channel, ky) row; row 15 is the zero row under channel 2
-    const int rr = 2 * b + h;
-    const int cc = (rr * 13) >> 6;  // rr / 5 for rr < 16
-    const int c1off = (rr < 15) ? cc * PLANE + (rr - 5 * cc) * kXImgRow
-                                : 2 * PLANE + 5 * kXImgRow;
+  const unsigned sh = (unsigned)(q & 1) * 16u;
+  // eight consecutive bf16 values = five aligned dwords and a funnel shift by 0 or 16 bits; the 16th
+  // value of the row (half 1, element 7) meets a zero weight: any finite pixel will do.  The dwords
+  // of block b + 1 are requested before the MFMAs of block b are issued.
+  unsigned raw[2][NT][5];
+  auto request = [&](int b, unsigned (&d)[NT][5]) {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      uint4 au;
-      if constexpr (BF) {
-        // five consecutive bf16 pixels from three aligned dwords: the fragment starts at an even
-        // pixel for q & 1 == 0 and at an odd one otherwise (PLANE, the row pitch and so c1off are
-        // even), so the lane shifts by a constant 0 or 16 bits
-        const unsigned* pw = reinterpret_cast<const unsigned*>(imgb) + ((a0[t] + c1off) >> 1);
-        const unsigned d0 = pw[0], d1 = pw[1], d2 = pw[2];
-        const unsigned sh = (unsigned)(q & 1) * 16u;
-        au.x = __builtin_amdgcn_alignbit(d1, d0, sh);
-        au.y = __builtin_amdgcn_alignbit(d2, d1, sh);
-        au.z = (d2 >> sh) & 0xFFFFu;
-        au.w = 0u;
-      } else {
-        const unsigned char* px = &S.img[a0[t] + c1off];
-        // u8 -> float -> bf16 (exact): the high half of the float is the bf16
-        const unsigned f0 = __float_as_uint((float)px[0]), f1 = __float_as_uint((float)px[1]),
-                       f2 = __float_as_uint((float)px[2]), f3 = __float_as_uint((float)px[3]),
-                       f4 = __float_as_uint((float)px[4]);
-        au.x = (f1 & 0xFFFF0000u) | (f0 >> 16);
-        au.y = (f3 & 0xFFFF0000u) | (f2 >> 16);
-        au.z = f4 >> 16;
-        au.w = 0u;
-      }
-      const bf16x8 Af = as_frag(au);
-      v16f a = acc[t];
-      a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af, Bl, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af, Bm, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af, Bh, a, 0, 0, 0);
-      acc[t] = a;
+      const unsigned* pw = reinterpret_cast<const unsigned*>(imgb) + ((a0[t] + b * kXImgRow) >> 1);
+#pragma unroll
+      for (int k = 0; k < 5; k++) d[t][k] = pw[k];
     }
+  };
+  request(0, raw[0]);
+#pragma unroll
+  for (int b = 0; b < kXC1Blocks; b++) {
+    if (b + 1 < kXC1Blocks) request(b + 1, raw[(b + 1) & 1]);
+    x3_fence();
+    bf16x8 Af[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const unsigned(&d)[5] = raw[b & 1][t];
+      uint4 au;
+      au.x = __builtin_amdgcn_alignbit(d[1], d[0], sh);
+      au.y = __builtin_amdgcn_alignbit(d[2], d[1], sh);
+      au.z = __builtin_amdgcn_alignbit(d[3], d[2], sh);
+      au.w = __builtin_amdgcn_alignbit(d[4], d[3], sh);
+      Af[t] = as_frag(au);
+    }
+#pragma unroll
+    for (int k = 2; k >= 0; k--)  // low, middle, high term of the weights
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[t], as_frag(W[b][k]), acc[t], 0, 0, 0);
+    x3_fence();
   }
   if (r < 20) {
+    // channels 0-15 go to pa[term][r >> 3][pos][r & 7], 16-19 to pc[term][pos][r & 3]: one address
+    // expression with lane-constant base, term stride, row pitch and position stride (no branches)
+    const bool main = r < 16;
+    unsigned short* base = main ? &S.pa[0][r >> 3][0][r & 7] : &S.pc[0][0][r & 3];
+    const int sterm = main ? (int)(sizeof(S.pa[0]) / 2) : (int)(sizeof(S.pc[0]) / 2);
+    const int spos = main ? 8 : 4;
+    const int srow = main ? kXPA * 8 : kXPC * 4;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const int T = T0 + t * TS;
@@ -240,16 +264,20 @@ __device__ __forceinline__ void x3_conv1(SH& S, const uint4* __restrict__ w1x, f
         split3(m, s3);
         const int p = 8 * T + 2 * j + h;  // pooled position, row-major on the 28 x 28 map
         const int y = p / 28, x = p - 28 * y;
-        if (r < 16) {
+        unsigned short* o = base + y * srow + x * spos;
 #pragma unroll
-          for (int s = 0; s < 3; s++) S.pa[s][r >> 3][y * kXPA + x][r & 7] = s3[s];
-        } else {
-#pragma unroll
-          for (int s = 0; s < 3; s++) S.pc[s][y * kXPC + x][r & 3] = s3[s];
-        }
+        for (int s = 0; s < 3; s++) o[s * sterm] = s3[s];
       }
     }
   }
+}
+
+// the conv1 weights of this lane: 5 k-blocks x 3 terms, kept in registers for a whole unit of work
+__device__ __forceinline__ void x3_conv1_weights(const uint4* __restrict__ w1x, int lane, uint4 (&W)[kXC1Blocks][3]) {
+#pragma unroll
+  for (int b = 0; b < kXC1Blocks; b++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) W[b][k] = w1x[(b * 3 + k) * 64 + lane];
 }
 
 __global__ void __launch_bounds__(kXThreads, 2)
@@ -269,30 +297,30 @@ k_lenet_conv_x3(const unsigned char* __restrict__ images, int n_img, const unsig
 
   for (int im = blockIdx.x; im < n_img; im += gridDim.x) {
     __syncthreads();  // previous image's conv2 readers of the pooled map are done
-    {  // stage the image: HWC u8 -> planar u8 (+ one zero row per channel)
+    {  // stage the image: u8 -> bf16 (exact: the high half of the float), order unchanged
       const unsigned* src = reinterpret_cast<const unsigned*>(images + (size_t)im * 10800);
-      for (int i = tid; i < 2700; i += kXThreads) {
-        const unsigned v = src[i];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const int e = i * 4 + b;  // byte index = pixel * 3 + ch
-          const int pix = e / 3, ch = e - pix * 3;
-          S.img[ch * kXImgPlane + pix] = (unsigned char)((v >> (8 * b)) & 255u);
-        }
-      }
-      if (tid < 180) S.img[(tid / 60) * kXImgPlane + 3600 + (tid % 60)] = 0;
-      if (tid < 16) S.img[3 * kXImgPlane + tid] = 0;
+      for (int i = tid; i < 2700; i += kXThreads) x3_stage4(S.imgb, i, src[i]);
+      if (tid < 8) reinterpret_cast<unsigned*>(S.imgb)[5400 + tid] = 0u;
     }
     __syncthreads();
     // conv1: 98 tiles; wave w takes tiles w, w + 8, ... (12 each, waves 0 and 1 a 13th)
-    for (int k0 = 0; k0 < 12; k0 += 4) x3_conv1<X3Shared, 4, kXWaves, kXImgPlane>(S, w1x, bias1, wid + 8 * k0, lane);
-    if (wid < 2) x3_conv1<X3Shared, 1, kXWaves, kXImgPlane>(S, w1x, bias1, wid + 96, lane);
+    {
+      int ln = lane;  // opaque once per image, see k_lenet_conv_x3b
+      asm volatile("" : "+v"(ln));
+      uint4 W[kXC1Blocks][3];
+      x3_conv1_weights(w1x, ln, W);
+#pragma unroll 1
+      for (int k0 = 0; k0 < 12; k0 += 4) x3_conv1<X3Shared, 4, kXWaves>(S, W, bias1, wid + 8 * k0, ln, S.imgb);
+      if (wid < 2) x3_conv1<X3Shared, 1, kXWaves>(S, W, bias1, wid + 96, ln, S.imgb);
+    }
     __syncthreads();
     // conv2: 18 tiles x 2 channel halves over 8 waves
     {
       float* dst = pooled2 + (size_t)im * 7200;
-      if (mgrp < 2) x3_conv2<X3Shared, 5, 4>(S, w2x, dst, bias2, nh, mgrp, lane);   // tiles mgrp, +4, .., +16
-      else x3_conv2<X3Shared, 4, 4>(S, w2x, dst, bias2, nh, mgrp, lane);            // tiles mgrp, +4, .., +12
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      if (mgrp < 2) x3_conv2<X3Shared, 5, 4>(S, w2x, dst, bias2, nh, mgrp, ln);   // tiles mgrp, +4, .., +16
+      else x3_conv2<X3Shared, 4, 4>(S, w2x, dst, bias2, nh, mgrp, ln);            // tiles mgrp, +4, .., +12
     }
   }
 }
@@ -317,13 +345,12 @@ k_lenet_conv_x3(const unsigned char* __restrict__ images, int n_img, const unsig
 constexpr int kBThreads = 256;
 constexpr int kBWaves = kBThreads / 64;
 constexpr int kBRows = 12;                   // pooled conv1 rows of a band
-constexpr int kBImgRows = 28;                // image rows of a band (+ one zero row per channel)
-constexpr int kBImgPlane = (kBImgRows + 1) * 60;
+constexpr int kBImgRows = 28;                // image rows of a band
 
 struct X3Band {
   unsigned short pa[3][2][kBRows * kXPA][8];
   unsigned short pc[3][kBRows * kXPC][4];
-  unsigned short imgb[3 * kBImgPlane + 16];  // the band of the image as bf16 (u8 values are exact)
+  unsigned short imgb[kBImgRows * kXImgRow + 16];  // the band of the image as bf16 (u8 values are exact), HWC
 };
 static_assert(2 * sizeof(X3Band) <= 160 * 1024, "k_lenet_conv_x3b: two workgroups per CU");
 
@@ -345,31 +372,33 @@ k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsi
   for (int u = blockIdx.x; u < units; u += gridDim.x) {
     const int im = u / 3, band = u - 3 * im;
     __syncthreads();  // previous unit's conv2 readers of the pooled map are done
-    {  // stage image rows 16 band .. 16 band + 27: HWC u8 -> planar u8 (+ one zero row per channel)
+    {  // stage image rows 16 band .. 16 band + 27 as bf16, order unchanged
       const unsigned* src = reinterpret_cast<const unsigned*>(images + (size_t)im * 10800 + band * (16 * 180));
-      for (int i = tid; i < kBImgRows * 45; i += kBThreads) {  // 28 rows x 180 bytes
-        const unsigned v = src[i];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const int e = i * 4 + b;  // byte index = pixel * 3 + ch
-          const int pix = e / 3, ch = e - pix * 3;
-          // u8 -> float -> bf16 (exact): the high half of the float is the bf16
-          S.imgb[ch * kBImgPlane + pix] = (unsigned short)(__float_as_uint((float)((v >> (8 * b)) & 255u)) >> 16);
-        }
-      }
-      if (tid < 180) S.imgb[(tid / 60) * kBImgPlane + kBImgRows * 60 + (tid % 60)] = 0;
-      if (tid < 16) S.imgb[3 * kBImgPlane + tid] = 0;
+      for (int i = tid; i < kBImgRows * 45; i += kBThreads) x3_stage4(S.imgb, i, src[i]);  // 28 rows x 180 bytes
+      if (tid < 8) reinterpret_cast<unsigned*>(S.imgb)[kBImgRows * 90 + tid] = 0u;
     }
     __syncthreads();
     // conv1: 42 tiles; wave w takes tiles w, w + 4, ... (10 each, waves 0 and 1 an 11th)
-    x3_conv1<X3Band, 4, kBWaves, kBImgPlane, true>(S, w1x, bias1, wid, lane, S.imgb);
-    x3_conv1<X3Band, 4, kBWaves, kBImgPlane, true>(S, w1x, bias1, wid + 16, lane, S.imgb);
-    x3_conv1<X3Band, 2, kBWaves, kBImgPlane, true>(S, w1x, bias1, wid + 32, lane, S.imgb);
-    if (wid < 2) x3_conv1<X3Band, 1, kBWaves, kBImgPlane, true>(S, w1x, bias1, wid + 40, lane, S.imgb);
+    {
+      // (the lane index is made opaque once per unit: otherwise every address of the unrolled tile
+      // code is hoisted out of the unit loop as a loop invariant and spilled)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      uint4 W[kXC1Blocks][3];
+      x3_conv1_weights(w1x, ln, W);
+      x3_conv1<X3Band, 4, kBWaves>(S, W, bias1, wid, ln, S.imgb);
+      x3_conv1<X3Band, 4, kBWaves>(S, W, bias1, wid + 16, ln, S.imgb);
+      x3_conv1<X3Band, 2, kBWaves>(S, W, bias1, wid + 32, ln, S.imgb);
+      if (wid < 2) x3_conv1<X3Band, 1, kBWaves>(S, W, bias1, wid + 40, ln, S.imgb);
+    }
     __syncthreads();
     // conv2: 6 tiles x 2 channel halves over 4 waves; the band's 48 windows follow the 48 band
     // windows before them in the K' order of ip1
-    x3_conv2<X3Band, 3, 2>(S, w2x, pooled2 + (size_t)im * 7200 + band * (48 * 50), bias2, nh, mgrp, lane);
+    {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      x3_conv2<X3Band, 3, 2>(S, w2x, pooled2 + (size_t)im * 7200 + band * (48 * 50), bias2, nh, mgrp, ln);
+    }
   }
 }
 
@@ -377,14 +406,16 @@ k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsi
 int lenet_pack_weights_x3(ag2_ctx* c, const float* c1w, const float* c2w) {
   std::vector<unsigned short> w1x((size_t)kXC1Blocks * 3 * 64 * 8, 0), w2x((size_t)kXC2Blocks * 2 * 3 * 64 * 8, 0);
   unsigned short s3[3];
-  for (int b = 0; b < kXC1Blocks; b++)
+  for (int b = 0; b < kXC1Blocks; b++)  // block b = kernel row ky; k = 8 h + j = 3 kx + channel
     for (int l = 0; l < 64; l++) {
-      const int h = l >> 5, oc = l & 31, rr = 2 * b + h;
-      if (oc >= 20 || rr >= 15) continue;
-      const int ch = rr / 5, ky = rr % 5;
-      for (int kx = 0; kx < 5; kx++) {
-        split3(c1w[((oc * 3 + ch) * 5 + ky) * 5 + kx], s3);
-        for (int t = 0; t < 3; t++) w1x[(((size_t)b * 3 + t) * 64 + l) * 8 + kx] = s3[t];
+      const int h = l >> 5, oc = l & 31;
+      if (oc >= 20) continue;
+      for (int j = 0; j < 8; j++) {
+        const int e = 8 * h + j;
+        if (e >= 15) continue;
+        const int kx = e / 3, ch = e % 3;
+        split3(c1w[((oc * 3 + ch) * 5 + b) * 5 + kx], s3);
+        for (int t = 0; t < 3; t++) w1x[(((size_t)b * 3 + t) * 64 + l) * 8 + j] = s3[t];
       }
     }
   for (int b = 0; b < kXC2Blocks; b++)
