@@ -25,12 +25,25 @@
 // pre-split and pre-packed on the host in B-fragment order.
 #include <string.h>
 
+#include <type_traits>
+
 #include "ag2_internal.h"
 
 namespace ag2 {
 
+#ifndef AG2_EXP_ABL
+#define AG2_EXP_ABL 0
+#endif
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifdef AG2_EXP_DBG
+__device__ unsigned long long g_x3dbg2[512 * 4 * 32];
+__device__ int g_x3round;
+#define X3_STAMP2(b) do { if ((threadIdx.x & 63) == 0 && dbg_round == 2) g_x3dbg2[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (b)] = __builtin_readcyclecounter(); } while (0)
+extern "C" void ag2_dbg_x3b(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3dbg2), sizeof(g_x3dbg2)); }
+#else
+#define X3_STAMP2(b) do {} while (0)
+#endif
 
 constexpr int kXThreads = 512;
 constexpr int kXWaves = kXThreads / 64;
@@ -41,9 +54,16 @@ constexpr int kXC1Blocks = 5;        // one ky row per block: its 5 x 3 (kx, cha
 constexpr int kXC2Main = 25;
 constexpr int kXC2Blocks = kXC2Main + 7;
 
+// one bf16 term of the pooled conv1 map (ROWS rows of it); the three terms of a value sit one
+// sizeof(X3Term) apart, in pa and in pc alike, so a term is an immediate offset of a store
+template <int ROWS>
+struct X3Term {
+  unsigned short pa[2][ROWS * kXPA][8];
+  unsigned short pc[ROWS * kXPC][4];
+};
+
 struct X3Shared {
-  unsigned short pa[3][2][28 * kXPA][8];
-  unsigned short pc[3][28 * kXPC][4];
+  X3Term<28> t[3];
   unsigned short imgb[60 * kXImgRow + 16];  // the image as bf16 (u8 values are exact), HWC as handed over
 };
 static_assert(sizeof(X3Shared) <= 160 * 1024, "k_lenet_conv_x3: LDS");
@@ -68,6 +88,15 @@ __host__ __device__ __forceinline__ void split3(float v, unsigned short t[3]) {
   t[2] = (unsigned short)(b2 >> 16);
 }
 
+// max of four accumulator values (no NaNs by construction: the canonicalising form fmaxf compiles to
+// costs two more instructions per call)
+__device__ __forceinline__ float x3_max4(float a, float b, float c, float d) {
+  float m;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(d));
+  return m;
+}
+
 // requests in front of it stay in front, MFMAs behind it stay behind: a compiler-level memory fence
 // (the loads are plain reads the instruction selector may otherwise place anywhere) plus a
 // scheduling barrier for the machine scheduler
@@ -90,7 +119,7 @@ __device__ __forceinline__ void x3_stage4(unsigned short* imgb, int i, unsigned 
 template <class SH, int NT, int TS>
 __device__ __forceinline__ void x3_conv2(const SH& S, const uint4* __restrict__ w2x,
                                          float* __restrict__ dst, float bias2, int nh, int mgrp,
-                                         int lane) {
+                                         int lane, int dbg_round = -1) {
   const int h = lane >> 5, r = lane & 31;
   const int g = r >> 2, q = r & 3;
   v16f acc[NT];
@@ -105,81 +134,126 @@ __device__ __forceinline__ void x3_conv2(const SH& S, const uint4* __restrict__ 
     pc0[t] = y * kXPC + x;
   }
   const uint4* wl = w2x + (size_t)nh * 3 * 64 + lane;
-  // Two sets of operand fragments: while the 6 NT MFMAs of block b run, the B fragments of block
-  // b + 1 are on their way from L2 and its A fragments from LDS.  The scheduling barriers keep the
-  // requests in front of the MFMAs: left alone the compiler gives both blocks the same registers and
-  // so sinks every request behind the last use of the current block, i.e. in front of its own first
-  // use -- an L2 round trip and NT LDS round trips exposed per block.
-  struct Frags {
-    uint4 a[NT][3];
-    uint4 b[3];
-  };
-  // (the whole-image kernel's 4 or 5 tiles per wave leave no room for two sets of A fragments: there
-  // only the B fragments are requested a block ahead)
+  // Operand fragments are requested ahead of the MFMAs that use them: the B fragments (weights, from
+  // L2: several hundred cycles) three blocks ahead into a ring of four register sets, the A fragments
+  // (LDS) one block ahead into two.  One block's 6 NT MFMAs are 576 cycles of a wave that has the
+  // matrix pipe to itself -- less than an L2 round trip.  The fences keep the requests in front of
+  // the MFMAs: left alone the compiler gives consecutive blocks the same registers and so sinks
+  // every request behind the last use of the current block, i.e. in front of its own first use.
+  // (The whole-image kernel's 4 or 5 tiles per wave leave no room for two sets of A fragments:
+  // there only the B fragments run ahead.)
   constexpr bool kAhead = NT <= 3;
-  auto load = [&](int b, Frags& f, bool want_a, bool want_b) {
-    if (want_b) {
-      const uint4* wn = wl + (size_t)b * (2 * 3 * 64);
-      f.b[0] = wn[0];
-      f.b[1] = wn[64];
-      f.b[2] = wn[128];
-    }
-    if (!want_a) return;
-    if (b < kXC2Main) {  // one tap, channels 8 h .. 8 h + 7
-      const int ky = b / 5, kx = b - 5 * ky;
-      const int off = ky * kXPA + kx;
+  constexpr int kLast = kXC2Blocks - 1;
+  uint4 A[2][NT][3], B[4][3];
+  auto load_b = [&](int b, uint4(&d)[3]) {
+    const uint4* wn = wl + (size_t)b * (2 * 3 * 64);
+    d[0] = wn[0];
+    d[1] = wn[64];
+    d[2] = wn[128];
+  };
+  auto load_a_main = [&](int b, uint4(&d)[NT][3]) {  // one tap, channels 8 h .. 8 h + 7
+    const int ky = b / 5, kx = b - 5 * ky;
+    const int off = ky * kXPA + kx;
 #pragma unroll
-      for (int t = 0; t < NT; t++)
+    for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int s = 0; s < 3; s++) f.a[t][s] = *reinterpret_cast<const uint4*>(&S.pa[s][h][pa0[t] + off][0]);
-    } else {  // taps 4i + 2h and 4i + 2h + 1, channels 16-19; a tap past the 25th carries zero weights and re-reads tap 24
-      const int i = b - kXC2Main;
-      const int ta = min(4 * i + 2 * h, 24), tb = min(4 * i + 2 * h + 1, 24);
-      const int offa = (ta / 5) * kXPC + ta % 5, offb = (tb / 5) * kXPC + tb % 5;
+      for (int s = 0; s < 3; s++) d[t][s] = *reinterpret_cast<const uint4*>(&S.t[s].pa[h][pa0[t] + off][0]);
+  };
+  // taps 4i + 2h and 4i + 2h + 1, channels 16-19; a tap past the 25th carries zero weights and re-reads tap 24
+  auto load_a_tail = [&](int b, uint4(&d)[NT][3]) {
+    const int i = b - kXC2Main;
+    const int ta = min(4 * i + 2 * h, 24), tb = min(4 * i + 2 * h + 1, 24);
+    const int offa = (ta / 5) * kXPC + ta % 5, offb = (tb / 5) * kXPC + tb % 5;
 #pragma unroll
-      for (int t = 0; t < NT; t++)
+    for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int s = 0; s < 3; s++) {
-          const uint2 lo = *reinterpret_cast<const uint2*>(&S.pc[s][pc0[t] + offa][0]);
-          const uint2 hi = *reinterpret_cast<const uint2*>(&S.pc[s][pc0[t] + offb][0]);
-          f.a[t][s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-    }
+      for (int s = 0; s < 3; s++) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(&S.t[s].pc[pc0[t] + offa][0]);
+        const uint2 hi = *reinterpret_cast<const uint2*>(&S.t[s].pc[pc0[t] + offb][0]);
+        d[t][s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
   };
   // per accumulator the six terms in the order hl, lh, mm, hm, mh, hh (smallest first); the tiles
   // interleaved so that consecutive MFMAs are independent
-  auto mma = [&](const Frags& f) {
+  auto mma = [&](const uint4(&a)[NT][3], const uint4(&bb)[3]) {
     constexpr int ia[6] = {0, 2, 1, 0, 1, 0}, ib[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
     for (int k = 0; k < 6; k++)
 #pragma unroll
       for (int t = 0; t < NT; t++)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(f.a[t][ia[k]]), as_frag(f.b[ib[k]]), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a[t][ia[k]]), as_frag(bb[ib[k]]), acc[t], 0, 0, 0);
   };
-  static_assert(kXC2Blocks % 2 == 0, "x3_conv2: blocks are taken in pairs");
-  Frags f0, f1;
-  load(0, f0, kAhead, true);
+  // block b = 4 i + K: K picks the register sets at compile time; TC / TN: block b / b + 1 is one of
+  // the seven channel-16-19 blocks
+  auto step = [&](int b, auto K_, auto TC_, auto TN_) {
+    constexpr int K = decltype(K_)::value;
+    constexpr bool TC = decltype(TC_)::value, TN = decltype(TN_)::value;
+#if !(AG2_EXP_ABL & 8)
+    load_b(min(b + 3, kLast), B[(K + 3) & 3]);  // (the last requests are repeats nobody uses)
+#endif
+#if !(AG2_EXP_ABL & 4)
+    if constexpr (kAhead) {
+      if constexpr (TN) load_a_tail(min(b + 1, kLast), A[(K + 1) & 1]);
+      else load_a_main(b + 1, A[(K + 1) & 1]);
+    } else {
+      if constexpr (TC) load_a_tail(b, A[0]);
+      else load_a_main(b, A[0]);
+    }
+#endif
+    if constexpr (!kAhead) x3_fence();
+    mma(A[kAhead ? (K & 1) : 0], B[K & 3]);
+    if constexpr (kAhead) {
+      // issue order inside the step: one request behind each of the first MFMAs (an MFMA keeps the
+      // pipe busy for 32 cycles; a request issued in its shadow costs nothing, a block of twelve
+      // requests in front of the MFMAs drains the pipe)
+#pragma unroll
+      for (int i = 0; i < 3 * NT; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, TN ? 2 : 1, 0);   // LDS reads of the next block's A
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // one B fragment of block b + 3
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT - 3 * NT - 3, 0);
+    }
+    x3_fence();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  constexpr std::false_type M{};
+  constexpr std::true_type T{};
+  static_assert(kXC2Main == 25 && kXC2Blocks == 32, "x3_conv2: the block schedule below");
+  load_b(0, B[0]);
+  load_b(1, B[1]);
+  load_b(2, B[2]);
+  if constexpr (kAhead) load_a_main(0, A[0]);
 #pragma unroll 1
-  for (int b = 0; b < kXC2Blocks; b += 2) {
-    load(b + 1, f1, kAhead, true);
-    if (!kAhead) load(b, f0, true, false);
-    x3_fence();
-    mma(f0);
-    x3_fence();
-    load(min(b + 2, kXC2Blocks - 1), f0, kAhead, true);  // (the last request is a repeat nobody uses)
-    if (!kAhead) load(b + 1, f1, true, false);
-    x3_fence();
-    mma(f1);
-    x3_fence();
+  for (int b = 0; b < 24; b += 4) {
+    X3_STAMP2(b >> 2);
+    step(b, I0{}, M, M);
+    step(b + 1, I1{}, M, M);
+    step(b + 2, I2{}, M, M);
+    step(b + 3, I3{}, M, M);
   }
+  step(24, I0{}, M, T);
+  step(25, I1{}, T, T);
+  step(26, I2{}, T, T);
+  step(27, I3{}, T, T);
+  step(28, I0{}, T, T);
+  step(29, I1{}, T, T);
+  step(30, I2{}, T, T);
+  step(31, I3{}, T, T);
   const int oc = nh * 32 + r;
   if (oc < 50) {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const float m = fmaxf(fmaxf(acc[t][4 * j], acc[t][4 * j + 1]),
-                              fmaxf(acc[t][4 * j + 2], acc[t][4 * j + 3]));
+        const float m = x3_max4(acc[t][4 * j], acc[t][4 * j + 1], acc[t][4 * j + 2], acc[t][4 * j + 3]);
         const int wdw = 8 * (mgrp + TS * t) + 2 * j + h;
         dst[wdw * 50 + oc] = m + bias2;  // K' order of ip1: window-major, channel-minor
       }
@@ -198,28 +272,32 @@ __device__ __forceinline__ void x3_conv1(SH& S, const uint4 (&W)[kXC1Blocks][3],
                                          int T0, int lane, const unsigned short* imgb) {
   const int h = lane >> 5, r = lane & 31;
   const int g = r >> 2, q = r & 3;
+  const int T0u = __builtin_amdgcn_readfirstlane(T0);  // tiles are per wave: their arithmetic is scalar
   v16f acc[NT];
-  int a0[NT];
+  // Eight consecutive bf16 values = five aligned dwords and a funnel shift by 0 or 16 bits; the 16th
+  // value of the row (half 1, element 7) meets a zero weight: any finite pixel will do.  Two dword
+  // pointers per tile (image rows 0-1 and 2-4 of the window) keep every read an immediate offset.
+  const unsigned* pw[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int w = 8 * (T0 + t * TS) + g;
+    const int w = 8 * (T0u + t * TS) + g;
     const int wy = w / 28, wx = w - wy * 28;
     // first element of this lane's half of the window's top row; its parity is that of q (the row
     // pitch and 8 h are even, 3 * (2 wx + (q & 1)) has the parity of q): a lane-constant shift
-    a0[t] = (2 * wy + (q >> 1)) * kXImgRow + 3 * (2 * wx + (q & 1)) + 8 * h;
+    const int a0 = (2 * wy + (q >> 1)) * kXImgRow + 3 * (2 * wx + (q & 1)) + 8 * h;
+    pw[t][0] = reinterpret_cast<const unsigned*>(imgb) + (a0 >> 1);
+    pw[t][1] = pw[t][0] + 2 * (kXImgRow / 2);
   }
   const unsigned sh = (unsigned)(q & 1) * 16u;
-  // eight consecutive bf16 values = five aligned dwords and a funnel shift by 0 or 16 bits; the 16th
-  // value of the row (half 1, element 7) meets a zero weight: any finite pixel will do.  The dwords
-  // of block b + 1 are requested before the MFMAs of block b are issued.
+  // The dwords of block b + 1 are requested before the MFMAs of block b are issued.
   unsigned raw[2][NT][5];
   auto request = [&](int b, unsigned (&d)[NT][5]) {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      const unsigned* pw = reinterpret_cast<const unsigned*>(imgb) + ((a0[t] + b * kXImgRow) >> 1);
+      const unsigned* p = (b < 2 ? pw[t][0] : pw[t][1]) + (b < 2 ? b : b - 2) * (kXImgRow / 2);
 #pragma unroll
-      for (int k = 0; k < 5; k++) d[t][k] = pw[k];
+      for (int k = 0; k < 5; k++) d[t][k] = p[k];
     }
   };
   request(0, raw[0]);
@@ -246,25 +324,27 @@ __device__ __forceinline__ void x3_conv1(SH& S, const uint4 (&W)[kXC1Blocks][3],
     x3_fence();
   }
   if (r < 20) {
-    // channels 0-15 go to pa[term][r >> 3][pos][r & 7], 16-19 to pc[term][pos][r & 3]: one address
-    // expression with lane-constant base, term stride, row pitch and position stride (no branches)
+    // Channels 0-15 go to pa[r >> 3][pos][r & 7], 16-19 to pc[pos][r & 3] of each term: one address
+    // expression with lane-constant base, row pitch and position stride.  The eight positions of a
+    // tile are consecutive on the 28-wide map and tiles start at multiples of 8, so the row, the
+    // column and whether the tile's last four positions wrap into the next row are scalars.
     const bool main = r < 16;
-    unsigned short* base = main ? &S.pa[0][r >> 3][0][r & 7] : &S.pc[0][0][r & 3];
-    const int sterm = main ? (int)(sizeof(S.pa[0]) / 2) : (int)(sizeof(S.pc[0]) / 2);
-    const int spos = main ? 8 : 4;
+    const int spos = main ? 8 : 4;                   // in bf16 units
     const int srow = main ? kXPA * 8 : kXPC * 4;
+    unsigned short* base = (main ? &S.t[0].pa[r >> 3][0][r & 7] : &S.t[0].pc[0][r & 3]) + h * spos;
+    constexpr int sterm = (int)(sizeof(S.t[0]) / 2);
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      const int T = T0 + t * TS;
+      const int p0 = 8 * (T0u + t * TS);             // first pooled position of the tile
+      const int y0 = p0 / 28, x0 = p0 - 28 * y0;
+      unsigned short* oa = base + y0 * srow + x0 * spos;
+      unsigned short* ob = oa + (srow - 28 * spos);  // the same column count, one row on
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const float m = fmaxf(fmaxf(acc[t][4 * j], acc[t][4 * j + 1]),
-                              fmaxf(acc[t][4 * j + 2], acc[t][4 * j + 3])) + bias1;
+        const float m = x3_max4(acc[t][4 * j], acc[t][4 * j + 1], acc[t][4 * j + 2], acc[t][4 * j + 3]) + bias1;
         unsigned short s3[3];
         split3(m, s3);
-        const int p = 8 * T + 2 * j + h;  // pooled position, row-major on the 28 x 28 map
-        const int y = p / 28, x = p - 28 * y;
-        unsigned short* o = base + y * srow + x * spos;
+        unsigned short* o = (x0 + 2 * j >= 28 ? ob : oa) + 2 * j * spos;  // position p0 + 2 j + h
 #pragma unroll
         for (int s = 0; s < 3; s++) o[s * sterm] = s3[s];
       }
@@ -342,14 +422,20 @@ k_lenet_conv_x3(const unsigned char* __restrict__ images, int n_img, const unsig
 // -- the phases ADD even with two workgroups per CU, and also when conv1 of the next unit runs in the
 // same workgroup beside conv2 of the current one (tried: 0.244 ms): at the clock this kernel sustains
 // (~1.8 GHz) conv2 is matrix-pipe-bound (~0.9 busy) and the pipes are the shared resource.
+#ifdef AG2_EXP_DBG
+__device__ unsigned long long g_x3dbg[512 * 4 * 64];  // [workgroup < 512][wave < 4][round < 8][8]
+#define X3_STAMP(k) do { if (lane == 0 && rnd < 7) { g_x3dbg[((size_t)blockIdx.x * 4 + wid) * 64 + rnd * 8 + (k)] = __builtin_readcyclecounter(); if ((k) == 0) g_x3dbg[((size_t)blockIdx.x * 4 + wid) * 64 + rnd * 8 + 6] = wall_clock64(); if ((k)==0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_x3dbg[((size_t)blockIdx.x * 4 + wid) * 64 + rnd * 8 + 7] = hw; } } } while (0)
+extern "C" void ag2_dbg_x3(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3dbg), sizeof(g_x3dbg)); }
+#else
+#define X3_STAMP(k) do {} while (0)
+#endif
 constexpr int kBThreads = 256;
 constexpr int kBWaves = kBThreads / 64;
 constexpr int kBRows = 12;                   // pooled conv1 rows of a band
 constexpr int kBImgRows = 28;                // image rows of a band
 
 struct X3Band {
-  unsigned short pa[3][2][kBRows * kXPA][8];
-  unsigned short pc[3][kBRows * kXPC][4];
+  X3Term<kBRows> t[3];
   unsigned short imgb[kBImgRows * kXImgRow + 16];  // the band of the image as bf16 (u8 values are exact), HWC
 };
 static_assert(2 * sizeof(X3Band) <= 160 * 1024, "k_lenet_conv_x3b: two workgroups per CU");
@@ -369,15 +455,38 @@ k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsi
   const int mgrp = wid >> 1;  // conv2: tiles mgrp, mgrp + 2, mgrp + 4
   const float bias2 = b2[nh * 32 + r];
   const int units = 3 * n_img;
+  // The band of the NEXT unit is requested from global memory while this unit's conv1 runs and kept in
+  // registers (5 dwords per thread) through conv2; it goes into LDS at the top of the next round, when
+  // conv1 -- the only reader of the staged band -- is long done.  No global round trip and one barrier
+  // less on a unit's critical path.
+  constexpr int kBandDw = kBImgRows * 45;                       // 28 rows x 180 bytes
+  constexpr int kBandPer = (kBandDw + kBThreads - 1) / kBThreads;
+  unsigned nxt[kBandPer];
+  auto fetch = [&](int u) {
+    const int im = u / 3, band = u - 3 * im;
+    const unsigned* src = reinterpret_cast<const unsigned*>(images + (size_t)im * 10800 + band * (16 * 180));
+#pragma unroll
+    for (int k = 0; k < kBandPer; k++) {
+      const int i = tid + k * kBThreads;
+      nxt[k] = src[min(i, kBandDw - 1)];
+    }
+  };
+  if ((int)blockIdx.x < units) fetch(blockIdx.x);
+  int rnd = -1;
   for (int u = blockIdx.x; u < units; u += gridDim.x) {
     const int im = u / 3, band = u - 3 * im;
-    __syncthreads();  // previous unit's conv2 readers of the pooled map are done
-    {  // stage image rows 16 band .. 16 band + 27 as bf16, order unchanged
-      const unsigned* src = reinterpret_cast<const unsigned*>(images + (size_t)im * 10800 + band * (16 * 180));
-      for (int i = tid; i < kBImgRows * 45; i += kBThreads) x3_stage4(S.imgb, i, src[i]);  // 28 rows x 180 bytes
+    rnd++;
+    X3_STAMP(0);
+    {  // image rows 16 band .. 16 band + 27 as bf16, order unchanged
+#pragma unroll
+      for (int k = 0; k < kBandPer; k++) {
+        const int i = tid + k * kBThreads;
+        if (i < kBandDw) x3_stage4(S.imgb, i, nxt[k]);
+      }
       if (tid < 8) reinterpret_cast<unsigned*>(S.imgb)[kBImgRows * 90 + tid] = 0u;
     }
-    __syncthreads();
+    __syncthreads();  // the band is staged; the previous unit's conv2 readers of the pooled map are done
+    X3_STAMP(1);
     // conv1: 42 tiles; wave w takes tiles w, w + 4, ... (10 each, waves 0 and 1 an 11th)
     {
       // (the lane index is made opaque once per unit: otherwise every address of the unrolled tile
@@ -386,19 +495,27 @@ k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsi
       asm volatile("" : "+v"(ln));
       uint4 W[kXC1Blocks][3];
       x3_conv1_weights(w1x, ln, W);
+      if (u + (int)gridDim.x < units) fetch(u + gridDim.x);  // (after the weights: waiting for those does not wait for these)
+#if !(AG2_EXP_ABL & 1)
       x3_conv1<X3Band, 4, kBWaves>(S, W, bias1, wid, ln, S.imgb);
       x3_conv1<X3Band, 4, kBWaves>(S, W, bias1, wid + 16, ln, S.imgb);
       x3_conv1<X3Band, 2, kBWaves>(S, W, bias1, wid + 32, ln, S.imgb);
       if (wid < 2) x3_conv1<X3Band, 1, kBWaves>(S, W, bias1, wid + 40, ln, S.imgb);
+#endif
     }
+    X3_STAMP(2);
     __syncthreads();
+    X3_STAMP(3);
     // conv2: 6 tiles x 2 channel halves over 4 waves; the band's 48 windows follow the 48 band
     // windows before them in the K' order of ip1
     {
       int ln = lane;
       asm volatile("" : "+v"(ln));
-      x3_conv2<X3Band, 3, 2>(S, w2x, pooled2 + (size_t)im * 7200 + band * (48 * 50), bias2, nh, mgrp, ln);
+#if !(AG2_EXP_ABL & 2)
+      x3_conv2<X3Band, 3, 2>(S, w2x, pooled2 + (size_t)im * 7200 + band * (48 * 50), bias2, nh, mgrp, ln, rnd);
+#endif
     }
+    X3_STAMP(4);
   }
 }
 
