@@ -31,19 +31,12 @@
 
 namespace ag2 {
 
+// ablation switches for tools/ab_build.sh (timing only, wrong results): 1 no conv1, 2 no conv2, 4 / 8 no A / B requests in conv2
 #ifndef AG2_EXP_ABL
 #define AG2_EXP_ABL 0
 #endif
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#ifdef AG2_EXP_DBG
-__device__ unsigned long long g_x3dbg2[512 * 4 * 32];
-__device__ int g_x3round;
-#define X3_STAMP2(b) do { if ((threadIdx.x & 63) == 0 && dbg_round == 2) g_x3dbg2[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (b)] = __builtin_readcyclecounter(); } while (0)
-extern "C" void ag2_dbg_x3b(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3dbg2), sizeof(g_x3dbg2)); }
-#else
-#define X3_STAMP2(b) do {} while (0)
-#endif
 
 constexpr int kXThreads = 512;
 constexpr int kXWaves = kXThreads / 64;
@@ -119,7 +112,7 @@ __device__ __forceinline__ void x3_stage4(unsigned short* imgb, int i, unsigned 
 template <class SH, int NT, int TS>
 __device__ __forceinline__ void x3_conv2(const SH& S, const uint4* __restrict__ w2x,
                                          float* __restrict__ dst, float bias2, int nh, int mgrp,
-                                         int lane, int dbg_round = -1) {
+                                         int lane) {
   const int h = lane >> 5, r = lane & 31;
   const int g = r >> 2, q = r & 3;
   v16f acc[NT];
@@ -233,7 +226,6 @@ __device__ __forceinline__ void x3_conv2(const SH& S, const uint4* __restrict__ 
   if constexpr (kAhead) load_a_main(0, A[0]);
 #pragma unroll 1
   for (int b = 0; b < 24; b += 4) {
-    X3_STAMP2(b >> 2);
     step(b, I0{}, M, M);
     step(b + 1, I1{}, M, M);
     step(b + 2, I2{}, M, M);
@@ -290,9 +282,11 @@ __device__ __forceinline__ void x3_conv1(SH& S, const uint4 (&W)[kXC1Blocks][3],
     pw[t][1] = pw[t][0] + 2 * (kXImgRow / 2);
   }
   const unsigned sh = (unsigned)(q & 1) * 16u;
-  // The dwords of block b + 1 are requested before the MFMAs of block b are issued.
+  // Issue order of a block: the funnel shifts of tile t directly in front of its first MFMA (only
+  // tile 0's are not in the shadow of an MFMA), then the other 2 NT MFMAs with the requests for block
+  // b + 1's dwords behind them, one or two per MFMA.
   unsigned raw[2][NT][5];
-  auto request = [&](int b, unsigned (&d)[NT][5]) {
+  auto request = [&](int b, unsigned(&d)[NT][5]) {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const unsigned* p = (b < 2 ? pw[t][0] : pw[t][1]) + (b < 2 ? b : b - 2) * (kXImgRow / 2);
@@ -303,8 +297,6 @@ __device__ __forceinline__ void x3_conv1(SH& S, const uint4 (&W)[kXC1Blocks][3],
   request(0, raw[0]);
 #pragma unroll
   for (int b = 0; b < kXC1Blocks; b++) {
-    if (b + 1 < kXC1Blocks) request(b + 1, raw[(b + 1) & 1]);
-    x3_fence();
     bf16x8 Af[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -315,12 +307,27 @@ __device__ __forceinline__ void x3_conv1(SH& S, const uint4 (&W)[kXC1Blocks][3],
       au.z = __builtin_amdgcn_alignbit(d[3], d[2], sh);
       au.w = __builtin_amdgcn_alignbit(d[4], d[3], sh);
       Af[t] = as_frag(au);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[t], as_frag(W[b][2]), acc[t], 0, 0, 0);  // low term
     }
 #pragma unroll
-    for (int k = 2; k >= 0; k--)  // low, middle, high term of the weights
+    for (int t = 0; t < NT; t++) {
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    x3_fence();
+    if (b + 1 < kXC1Blocks) request(b + 1, raw[(b + 1) & 1]);
+#pragma unroll
+    for (int k = 1; k >= 0; k--)  // middle, high term of the weights
 #pragma unroll
       for (int t = 0; t < NT; t++)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[t], as_frag(W[b][k]), acc[t], 0, 0, 0);
+    if (b + 1 < kXC1Blocks) {
+#pragma unroll
+      for (int i = 0; i < 2 * NT; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    }
     x3_fence();
   }
   if (r < 20) {
@@ -422,13 +429,6 @@ k_lenet_conv_x3(const unsigned char* __restrict__ images, int n_img, const unsig
 // -- the phases ADD even with two workgroups per CU, and also when conv1 of the next unit runs in the
 // same workgroup beside conv2 of the current one (tried: 0.244 ms): at the clock this kernel sustains
 // (~1.8 GHz) conv2 is matrix-pipe-bound (~0.9 busy) and the pipes are the shared resource.
-#ifdef AG2_EXP_DBG
-__device__ unsigned long long g_x3dbg[512 * 4 * 64];  // [workgroup < 512][wave < 4][round < 8][8]
-#define X3_STAMP(k) do { if (lane == 0 && rnd < 7) { g_x3dbg[((size_t)blockIdx.x * 4 + wid) * 64 + rnd * 8 + (k)] = __builtin_readcyclecounter(); if ((k) == 0) g_x3dbg[((size_t)blockIdx.x * 4 + wid) * 64 + rnd * 8 + 6] = wall_clock64(); if ((k)==0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_x3dbg[((size_t)blockIdx.x * 4 + wid) * 64 + rnd * 8 + 7] = hw; } } } while (0)
-extern "C" void ag2_dbg_x3(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3dbg), sizeof(g_x3dbg)); }
-#else
-#define X3_STAMP(k) do {} while (0)
-#endif
 constexpr int kBThreads = 256;
 constexpr int kBWaves = kBThreads / 64;
 constexpr int kBRows = 12;                   // pooled conv1 rows of a band
@@ -472,11 +472,8 @@ k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsi
     }
   };
   if ((int)blockIdx.x < units) fetch(blockIdx.x);
-  int rnd = -1;
   for (int u = blockIdx.x; u < units; u += gridDim.x) {
     const int im = u / 3, band = u - 3 * im;
-    rnd++;
-    X3_STAMP(0);
     {  // image rows 16 band .. 16 band + 27 as bf16, order unchanged
 #pragma unroll
       for (int k = 0; k < kBandPer; k++) {
@@ -486,7 +483,6 @@ k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsi
       if (tid < 8) reinterpret_cast<unsigned*>(S.imgb)[kBImgRows * 90 + tid] = 0u;
     }
     __syncthreads();  // the band is staged; the previous unit's conv2 readers of the pooled map are done
-    X3_STAMP(1);
     // conv1: 42 tiles; wave w takes tiles w, w + 4, ... (10 each, waves 0 and 1 an 11th)
     {
       // (the lane index is made opaque once per unit: otherwise every address of the unrolled tile
@@ -503,19 +499,16 @@ k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsi
       if (wid < 2) x3_conv1<X3Band, 1, kBWaves>(S, W, bias1, wid + 40, ln, S.imgb);
 #endif
     }
-    X3_STAMP(2);
     __syncthreads();
-    X3_STAMP(3);
     // conv2: 6 tiles x 2 channel halves over 4 waves; the band's 48 windows follow the 48 band
     // windows before them in the K' order of ip1
     {
       int ln = lane;
       asm volatile("" : "+v"(ln));
 #if !(AG2_EXP_ABL & 2)
-      x3_conv2<X3Band, 3, 2>(S, w2x, pooled2 + (size_t)im * 7200 + band * (48 * 50), bias2, nh, mgrp, ln, rnd);
+      x3_conv2<X3Band, 3, 2>(S, w2x, pooled2 + (size_t)im * 7200 + band * (48 * 50), bias2, nh, mgrp, ln);
 #endif
     }
-    X3_STAMP(4);
   }
 }
 
