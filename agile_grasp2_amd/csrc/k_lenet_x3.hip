@@ -576,22 +576,24 @@ __global__ void __launch_bounds__(256, 2)
 k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restrict__ d_n, int n_pad,
                const uint4* __restrict__ w3x, int chunks_per_split, float* __restrict__ part) {
   __shared__ FxShared S;
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;  // image tile, column group, K split
   if (d_n) {
-    // frame mode: a 1-D launch as large as any batch up to the list's capacity can need; the batch
-    // size is read here and the split chosen by the SAME rule the host applies to a known batch
-    // size, so the partial sums (and with them every logit) are bit-identical to those of an
-    // exact-size launch
+    // frame mode: a launch as large as any batch up to the list's capacity can need; the batch size
+    // is read here and the split chosen by the SAME rule the host applies to a known batch size, so
+    // the partial sums (and with them every logit) are bit-identical to those of an exact-size launch
     n_img = min(n_img, (int)*d_n);
-    const int mtiles = (n_img + kFxBM - 1) / kFxBM;
-    const int ks = fc1_x3_ksplit(mtiles);
-    const int w = blockIdx.x;
-    if (w >= mtiles * 4 * ks) return;  // uniform
-    bx = w % mtiles;
-    by = (w / mtiles) & 3;
-    bz = w / (mtiles * 4);
-    chunks_per_split = 150 / ks;
+    chunks_per_split = 150 / fc1_x3_ksplit((n_img + kFxBM - 1) / kFxBM);
   }
+  // Work item -> (image tile bx, column group by, K split bz), K split slowest.  Workgroups go to the
+  // 8 XCDs round-robin by their index and every XCD has its own L2, so the items are dealt such that
+  // one XCD gets a CONTIGUOUS eighth of them, i.e. one or two K splits: it then fetches an eighth of
+  // the weights (2.8 of 22 MB: they stay in its L2 for all image tiles) instead of all of them.
+  const int mtiles = (n_img + kFxBM - 1) / kFxBM;
+  const int items = mtiles * 4 * (150 / chunks_per_split);
+  const int per_xcd = (items + 7) >> 3;
+  const int slot = blockIdx.x >> 3;
+  const int item = (int)(blockIdx.x & 7) * per_xcd + slot;
+  if (slot >= per_xcd || item >= items) return;  // uniform
+  const int bx = item % mtiles, by = (item / mtiles) & 3, bz = item / (mtiles * 4);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
   const int img0 = bx * kFxBM;
@@ -708,12 +710,12 @@ int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out, c
   const int n_pad = mtiles * kFxBM;
   const int ksplit = d_n ? kFc1X3MaxSplit : fc1_x3_ksplit(mtiles);
   AG2_HIP(c, c->d_fcpart.reserve((size_t)ksplit * n_pad * kFxN * 4));
-  dim3 grid(mtiles, 4, ksplit);
+  int items = mtiles * 4 * ksplit;
   if (d_n) {  // the largest number of work items any batch of 1 .. mtiles tiles needs
-    int items = 0;
+    items = 0;
     for (int m = 1; m <= mtiles; m++) items = std::max(items, m * 4 * fc1_x3_ksplit(m));
-    grid = dim3(items, 1, 1);
   }
+  const dim3 grid((items + 7) / 8 * 8, 1, 1);
   hipLaunchKernelGGL(k_lenet_fc1_x3, grid, dim3(256), 0, c->stream,
                      c->d_act1.as<float>(), (int)n, d_n, n_pad, d.w3x.as<uint4>(), 150 / ksplit,
                      c->d_fcpart.as<float>());
