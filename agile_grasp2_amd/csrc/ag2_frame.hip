@@ -186,7 +186,7 @@ int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
   const size_t ctl_words = (scan_ctl_words((int)cap_cells + 1) + 3) & ~size_t(3);
   AG2_HIP(c, c->d_cell.reserve((cell_words + ctl_words) * 4));
   AG2_HIP(c, c->d_perm.reserve(n_max * 4));
-  AG2_HIP(c, c->d_sorted.reserve(n_max * 16));
+  AG2_HIP(c, c->d_sorted.reserve((n_max + 1) * 16));  // + the NaN point behind the cloud
   AG2_HIP(c, c->d_nrm.reserve(n_max * 16));
   unsigned* cell = c->d_cell.as<unsigned>();
   AG2_HIP(c, hipMemsetAsync(cell, 0, (cell_words + ctl_words) * 4, c->stream));

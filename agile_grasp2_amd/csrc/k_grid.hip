@@ -330,6 +330,12 @@ __global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ 
   __shared__ int cs[257];  // sorted position at which each of the workgroup's cells starts
   const int c0 = blockIdx.x * 256, tid = threadIdx.x;
   for (int t = tid; t <= 256; t += 256) cs[t] = (int)cell[min(c0 + t, ncells)];
+  // one all-NaN point behind the sorted cloud: what k_normals reads where a load step reaches past
+  // the end of its span (cell[ncells] = number of valid points)
+  if (blockIdx.x == 0 && tid == 0) {
+    const float nanv = __builtin_nanf("");
+    sorted[cell[ncells]] = make_float4(nanv, nanv, nanv, nanv);
+  }
   __syncthreads();
   int cb = 0;  // first cell of the batch (everything below is uniform across the workgroup)
   while (cb < 256 && cs[256] > cs[cb]) {
@@ -519,7 +525,7 @@ int build_grid(ag2_ctx* c) {
   const size_t ctl_words = (scan_ctl_words((int)ncells + 1) + 3) & ~size_t(3);
   AG2_HIP(c, c->d_cell.reserve((cell_words + ctl_words) * 4));
   AG2_HIP(c, c->d_perm.reserve((size_t)n * 4));
-  AG2_HIP(c, c->d_sorted.reserve((size_t)n * 16));
+  AG2_HIP(c, c->d_sorted.reserve(((size_t)n + 1) * 16));  // + the NaN point behind the cloud
   AG2_HIP(c, c->d_nrm.reserve((size_t)n * 16));
   unsigned* cell = c->d_cell.as<unsigned>();
   AG2_HIP(c, hipMemsetAsync(cell, 0, (cell_words + ctl_words) * 4, c->stream));

@@ -11,6 +11,9 @@
 // algorithmic bytes = N * (K1 * 12 + 12).
 #include "ag2_internal.h"
 
+#ifndef AG2_EXP_NABL
+#define AG2_EXP_NABL 0
+#endif
 namespace ag2 {
 
 __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
@@ -21,6 +24,10 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
   // gp (frame mode): grid description left in device memory by k_grid_desc; the launch covers the
   // frame's maximum point count and the threads beyond n_valid leave
   const GridDesc g = gp ? *gp : g_arg;
+  constexpr int kRows = 16;  // 4 x 4 stencil rows
+  __shared__ int s_rb[kRows][256];             // [row][thread]: a thread's column is its own
+  __shared__ unsigned short s_rn[kRows][256];  // span lengths (a span is three cells of one row)
+  __shared__ int s_tot[4];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int cnt = 0;
   if (i < g.n_valid) {
@@ -34,16 +41,15 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
     }
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
     typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 A01 = {0.f, 0.f}, A23 = {0.f, 0.f}, A45 = {0.f, 0.f}, A67 = {0.f, 0.f};  // the row walk below
-    const f2 qxy = {q.x, q.y};
-    // The kernel is bound by the latency of each thread's chain of dependent loads (one wave per
-    // SIMD slot, every wave runs once), so the chain is kept short: the span bounds of ALL stencil
-    // rows (<= 4 x 4: q +- 1.001 r reaches 3, rarely 4, cells per axis) are requested first, and a
-    // row is walked four points per step with the four loads issued together.  The moments are
-    // still accumulated one point at a time in canonical order (cz, cy, then sorted position).
-    constexpr int kRows = 16;
-    int nrows = (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
-    if (nrows > kRows) {  // normals_radius much larger than grid_cell: plain nested walk, same order
+    // accumulators of the flat walk below, paired the way a float4 point sits in registers -- (x, y)
+    // and (z, w) are the two aligned register pairs a 16-byte load returns, so no operand has to be
+    // moved into place: (xx, xy), (xy, yy), (xz, yz), (zz, ww), (x, y), (z, w).  The second xy and
+    // everything made from w are by-products nobody reads.
+    f2 Ax = {0.f, 0.f}, Ay = {0.f, 0.f}, Az = {0.f, 0.f}, Aw = {0.f, 0.f}, Sxy = {0.f, 0.f}, Szw = {0.f, 0.f};
+    const f2 qxy = {q.x, q.y}, qzw = {q.z, 0.f};
+    // plain nested walk, same order: for a radius much larger than the cell (more than 4 x 4 stencil
+    // rows) and for spans too long for the 16-bit lengths of the span table
+    auto nested_walk = [&]() {
       for (int cz = lo[2]; cz <= hi[2]; cz++)
         for (int cy = lo[1]; cy <= hi[1]; cy++) {
           const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
@@ -66,77 +72,128 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
             }
           }
         }
-      nrows = 0;
-    }
-    int rb[kRows], re[kRows];
-    {
-      // The kernel's time is the VALU work of the distance tests, six of seven of which fail: each
-      // row's x-cell range is shrunk to what the sphere |p - q| < r can reach given the row's
-      // distance in y and z (a row out of reach is skipped).  Purely conservative -- mg of slack on
-      // every bound, two orders above the float rounding of these few operations -- so the exact
-      // per-point test still decides and the accepted set and its order are unchanged.
+    };
+    const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+    bool plain = ny > 4 || nz > 4;
+    // Non-empty row spans of this thread, in canonical order (cz, then cy), in its own column of the
+    // LDS tables.  The stencil is walked as a fixed 4 x 4 grid of (cy, cz) offsets (q +- 1.001 r
+    // reaches 3, rarely 4, cells per axis; a wave skips the offsets none of its lanes has).
+    // Six of seven distance tests fail, so each row's x-cell range is shrunk to what the sphere
+    // |p - q| < r can reach given the row's distance in y and z (a row out of reach is skipped).
+    // Purely conservative -- mg of slack on every bound, two orders above the rounding of these few
+    // float operations (the square root may be the 1-ulp hardware one) -- so the exact per-point test
+    // still decides and the accepted set and its order are unchanged.
+    int nr = 0;
+    if (!plain) {
       const float mg = 1.0e-4f, h = 1.0f / g.inv, rm = rq + mg;
-      int cy = lo[1], cz = lo[2];
+      float dy2[4], dz2[4];
 #pragma unroll
-      for (int r = 0; r < kRows; r++) {
-        rb[r] = 0;
-        re[r] = 0;
-        if (r < nrows) {
-          const float dyl = (g.o[1] + (float)cy * h) - q.y - mg, dyh = dyl + h + 2.0f * mg;
-          const float dzl = (g.o[2] + (float)cz * h) - q.z - mg, dzh = dzl + h + 2.0f * mg;
-          const float dym = dyl > 0.f ? dyl : (dyh < 0.f ? -dyh : 0.f);
-          const float dzm = dzl > 0.f ? dzl : (dzh < 0.f ? -dzh : 0.f);
-          const float rho2 = rm * rm - dym * dym - dzm * dzm;
-          if (rho2 > 0.f) {
-            const float rho = __builtin_sqrtf(rho2) + mg;
+      for (int k = 0; k < 4; k++) {
+        const float dyl = (g.o[1] + (float)(lo[1] + k) * h) - q.y - mg, dyh = dyl + h + 2.0f * mg;
+        const float dzl = (g.o[2] + (float)(lo[2] + k) * h) - q.z - mg, dzh = dzl + h + 2.0f * mg;
+        const float dym = dyl > 0.f ? dyl : (dyh < 0.f ? -dyh : 0.f);
+        const float dzm = dzl > 0.f ? dzl : (dzh < 0.f ? -dzh : 0.f);
+        dy2[k] = dym * dym;
+        dz2[k] = dzm * dzm;
+      }
+      const float rm2 = rm * rm;
+      const unsigned row0 = (unsigned)((lo[2] * g.dims[1] + lo[1]) * g.dims[0]);
+      const unsigned zstep = (unsigned)(g.dims[1] * g.dims[0]), ystep = (unsigned)g.dims[0];
+#pragma unroll
+      for (int iz = 0; iz < 4; iz++)
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++) {
+          const float rho2 = rm2 - dy2[iy] - dz2[iz];
+          if (iy < ny && iz < nz && rho2 > 0.f) {
+            const float rho = __builtin_amdgcn_sqrtf(rho2) + mg;
             const int cxa = max(lo[0], cell_of(q.x - rho, g.o[0], g.inv));
             const int cxb = min(hi[0], cell_of(q.x + rho, g.o[0], g.inv));
             if (cxa <= cxb) {
-              const int rowbase = (cz * g.dims[1] + cy) * g.dims[0];
-              rb[r] = (int)cell[rowbase + cxa];
-              re[r] = (int)cell[rowbase + cxb + 1];
+              const unsigned rowbase = row0 + (unsigned)iz * zstep + (unsigned)iy * ystep;
+              const int b = (int)cell[rowbase + (unsigned)cxa], e = (int)cell[rowbase + (unsigned)cxb + 1u];
+              if (b < e) {
+                plain = plain || (e - b > 65535);
+                s_rb[nr][threadIdx.x] = b;
+                s_rn[nr][threadIdx.x] = (unsigned short)(e - b);
+                nr++;
+              }
             }
           }
-          if (++cy > hi[1]) {
-            cy = lo[1];
-            cz++;
+        }
+    }
+    if (plain) {
+      nested_walk();
+      nr = 0;
+    }
+#if AG2_EXP_NABL & 2
+    nr = min(nr, 1);
+#endif
+    // One flat walk over the spans, four points per step, with the NEXT step's four loads in flight
+    // while this step's points are tested and accumulated: a thread's chain of dependent load round
+    // trips overlaps its arithmetic instead of adding to it.  A step that reaches past its span reads
+    // the all-NaN point k_cell_sort leaves behind the sorted cloud: it fails the distance test like
+    // any far point, no bounds test per candidate.
+    if (nr > 0) {
+      const unsigned sentinel = (unsigned)g.n_valid;
+      int r = 0, j = s_rb[0][threadIdx.x], e = j + (int)s_rn[0][threadIdx.x];
+      int nj = 0, ne = 0;  // bounds of row r + 1, read one row ahead
+      if (nr > 1) {
+        nj = s_rb[1][threadIdx.x];
+        ne = nj + (int)s_rn[1][threadIdx.x];
+      }
+      float4 nx[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) nx[k] = pts[j + k < e ? (unsigned)(j + k) : sentinel];
+      bool more = true;
+      while (more) {
+        float4 p4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) p4[k] = nx[k];
+        j += 4;
+        if (j >= e) {
+          r++;
+          if (r < nr) {
+            j = nj;
+            e = ne;
+            if (r + 1 < nr) {
+              nj = s_rb[r + 1][threadIdx.x];
+              ne = nj + (int)s_rn[r + 1][threadIdx.x];
+            }
+          } else {
+            more = false;
+          }
+        }
+        if (more) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) nx[k] = pts[j + k < e ? (unsigned)(j + k) : sentinel];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          // two-wide packed f32 operations (v_pk_mul_f32 / v_pk_add_f32): every component is the
+          // IEEE multiply or add of the scalar formulation -- nothing is contracted or reassociated --
+          // at half the instruction count
+          const f2 pxy = {p4[k].x, p4[k].y}, pzw = {p4[k].z, p4[k].w};
+          const f2 dxy = pxy - qxy, dzw = pzw - qzw;
+          const f2 dd = dxy * dxy, ee = dzw * dzw;
+          const float d2 = (dd.x + dd.y) + ee.x;
+          if (d2 < r2f) {
+            const f2 bx = {pxy.x, pxy.x}, by = {pxy.y, pxy.y}, bz = {pzw.x, pzw.x};
+            Ax = Ax + bx * pxy;    // xx, xy
+            Ay = Ay + by * pxy;    // (xy), yy
+            Az = Az + bz * pxy;    // xz, yz
+            Aw = Aw + pzw * pzw;   // zz, (ww)
+            Sxy = Sxy + pxy;       // x, y
+            Szw = Szw + pzw;       // z, (w)
+            cnt++;
           }
         }
       }
     }
-#pragma unroll
-    for (int r = 0; r < kRows; r++) {
-      if (r < nrows) {
-        const int e = re[r];
-        for (int j = rb[r]; j < e; j += 4) {
-          float4 p4[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) p4[k] = pts[min(j + k, e - 1)];
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float4 p = p4[k];
-            // two-wide packed f32 operations (v_pk_mul_f32 / v_pk_add_f32): every component is the
-            // same IEEE multiply or add as before -- nothing is contracted or reassociated -- at half
-            // the instruction count
-            const f2 pxy = {p.x, p.y}, dxy = pxy - qxy;
-            const float dz = p.z - q.z;
-            const f2 dd = dxy * dxy;
-            const float d2 = (dd.x + dd.y) + dz * dz;
-            if (j + k < e && d2 < r2f) {
-              const f2 pxx = {p.x, p.x}, pzy = {p.z, p.y}, pyz = {p.y, p.z}, pzz = {p.z, p.z};
-              A01 = A01 + pxx * pxy;   // xx, xy
-              A23 = A23 + pxy * pzy;   // xz, yy
-              A45 = A45 + pyz * pzz;   // yz, zz
-              A67 = A67 + pxy;         // x, y
-              a8 = a8 + p.z;
-              cnt++;
-            }
-          }
-        }
-      }
-    }
-    a0 = a0 + A01.x; a1 = a1 + A01.y; a2 = a2 + A23.x; a3 = a3 + A23.y;  // (one of the two sets is zero:
-    a4 = a4 + A45.x; a5 = a5 + A45.y; a6 = a6 + A67.x; a7 = a7 + A67.y;  //  x + 0 is exact)
+    // the by-products count as used, so that the pairs stay pairs (and the loads 16 bytes wide)
+    asm volatile("" ::"v"(Ay.x), "v"(Aw.y), "v"(Szw.y));
+    a0 = a0 + Ax.x; a1 = a1 + Ax.y; a2 = a2 + Az.x; a3 = a3 + Ay.y;  // (one of the two sets is zero:
+    a4 = a4 + Az.y; a5 = a5 + Aw.x; a6 = a6 + Sxy.x; a7 = a7 + Sxy.y;  //  x + 0 is exact)
+    a8 = a8 + Szw.x;
     float4 out;
     if (cnt < 3) {
       const float nanv = __builtin_nanf("");
@@ -152,7 +209,11 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
       m.a11 = (double)(a3 - a7 * a7);
       m.a12 = (double)(a4 - a7 * a8);
       m.a22 = (double)(a5 - a8 * a8);
+#if AG2_EXP_NABL & 1
+      Eig3 e; e.d[0]=m.a00; e.d[1]=m.a11; e.d[2]=m.a22; e.v[0][0]=m.a01; e.v[0][1]=m.a02; e.v[0][2]=m.a12; e.v[1][0]=1; e.v[1][1]=0; e.v[1][2]=0; e.v[2][0]=0; e.v[2][1]=1; e.v[2][2]=0;
+#else
       const Eig3 e = jacobi3(m);
+#endif
       const int mi = argmin3(e.d);
       const V3 v{mi == 0 ? e.v[0][0] : (mi == 1 ? e.v[0][1] : e.v[0][2]),
                  mi == 0 ? e.v[1][0] : (mi == 1 ? e.v[1][1] : e.v[1][2]),
@@ -168,8 +229,17 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
     }
     nrm[i] = out;
   }
+  // statistics: ONE atomic per workgroup.  (One per wave -- 4 700 on one address -- serialises in the
+  // L2 at ~13 ns each: a 0.06 ms floor under the kernel, whatever else it does.)
   const int tot = wave_sum_i(cnt);
-  if (lane_id() == 0 && tot) atomicAdd(&st->sum_k1, (unsigned long long)tot);
+  if (lane_id() == 0) s_tot[wave_id()] = tot;
+  __syncthreads();
+#if !(AG2_EXP_NABL & 4)
+  if (threadIdx.x == 0) {
+    const int t4 = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
+    if (t4) atomicAdd(&st->sum_k1, (unsigned long long)t4);
+  }
+#endif
 }
 
 int launch_normals(ag2_ctx* c) {
