@@ -141,32 +141,29 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
         nj = s_rb[1][threadIdx.x];
         ne = nj + (int)s_rn[1][threadIdx.x];
       }
-      float4 nx[4];
+      // two register sets of four points, used alternately: no copies between the steps
+      float4 pa[4], pb[4];
+      auto fetch = [&](float4(&d)[4]) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) nx[k] = pts[j + k < e ? (unsigned)(j + k) : sentinel];
-      bool more = true;
-      while (more) {
-        float4 p4[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) p4[k] = nx[k];
+        for (int k = 0; k < 4; k++) d[k] = pts[j + k < e ? (unsigned)(j + k) : sentinel];
+      };
+      // moves on to the next step (the next span when this one is used up) and requests its points
+      auto advance = [&](float4(&d)[4]) -> bool {
         j += 4;
         if (j >= e) {
           r++;
-          if (r < nr) {
-            j = nj;
-            e = ne;
-            if (r + 1 < nr) {
-              nj = s_rb[r + 1][threadIdx.x];
-              ne = nj + (int)s_rn[r + 1][threadIdx.x];
-            }
-          } else {
-            more = false;
+          if (r >= nr) return false;
+          j = nj;
+          e = ne;
+          if (r + 1 < nr) {
+            nj = s_rb[r + 1][threadIdx.x];
+            ne = nj + (int)s_rn[r + 1][threadIdx.x];
           }
         }
-        if (more) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) nx[k] = pts[j + k < e ? (unsigned)(j + k) : sentinel];
-        }
+        fetch(d);
+        return true;
+      };
+      auto take = [&](const float4(&p4)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           // two-wide packed f32 operations (v_pk_mul_f32 / v_pk_add_f32): every component is the
@@ -187,6 +184,15 @@ __global__ void __launch_bounds__(256) k_normals(const float4* __restrict__ pts,
             cnt++;
           }
         }
+      };
+      fetch(pa);
+      for (;;) {
+        const bool mb = advance(pb);
+        take(pa);
+        if (!mb) break;
+        const bool ma = advance(pa);
+        take(pb);
+        if (!ma) break;
       }
     }
     // the by-products count as used, so that the pairs stay pairs (and the loads 16 bytes wide)
