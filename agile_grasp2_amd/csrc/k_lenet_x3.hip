@@ -13,13 +13,16 @@
 // Only the order of the fp32 additions differs from k_lenet_conv; both are held to the same
 // tolerance against the oracle (tests/test_gpu_lenet_detect.py).
 //
-// One 512-thread workgroup per image (one per CU: 148 KB of LDS).  The u8 image and the pooled conv1
-// map stay in LDS; the map is stored already split and channel-interleaved, so a lane's A fragment
-// needs no VALU work:
-//   pa[term][group][y * 40 + x][8]  channels 0-7 / 8-15: 8 k-values = ONE ds_read_b128
-//   pc[term][y * 48 + x][4]         channels 16-19:      4 k-values = one ds_read_b64
+// Unit of work: a third of an image per 256-thread workgroup, two workgroups per CU (k_lenet_conv_x3b,
+// the default) or a whole image per 512-thread workgroup (k_lenet_conv_x3, AG2_LENET_WHOLE=1: A/B).
+// The image (band) is staged as bf16 in the HWC order it was rendered in; the pooled conv1 map stays
+// in LDS, stored already split (one X3Term per bf16 term) and channel-interleaved, so a lane's A
+// fragment needs no VALU work:
+//   pa[group][y * 40 + x][8]  channels 0-7 / 8-15: 8 k-values = ONE ds_read_b128
+//   pc[y * 48 + x][4]         channels 16-19:      4 k-values = one ds_read_b64
 // The row pitches (40 = 8 mod 16 slots of 16 B, 48 = 16 mod 32 slots of 8 B) put the two pixel
-// rows of a tile's pooling windows on disjoint LDS banks.  K order of conv2: 25 taps x channels
+// rows of a tile's pooling windows on disjoint LDS banks.  K order of conv1: 5 kernel rows x (15
+// consecutive (kx, channel) values + one zero-weight tap).  K order of conv2: 25 taps x channels
 // 0-15 (lanes 0-31 take channels 0-7, lanes 32-63 channels 8-15), then 7 blocks that cover four
 // taps each for channels 16-19 (half h of the wave takes taps 4i + 2h and 4i + 2h + 1).  Weights are
 // pre-split and pre-packed on the host in B-fragment order.
@@ -418,17 +421,17 @@ k_lenet_conv_x3(const unsigned char* __restrict__ images, int n_img, const unsig
 // the pooling / store epilogue all leave the matrix pipes idle (MFMA busy 0.54).  Here the unit of work
 // is a third of an image: the conv2 output rows 8k .. 8k+7 (pooled-output rows 4k .. 4k+3, 48 of the
 // 144 windows) need the pooled conv1 rows 8k .. 8k+11, i.e. image rows 16k .. 16k+27.  A band's map is
-// 12 rows (64 KB with the band of the image), so TWO 256-thread workgroups share a CU and one's
+// 12 rows (70 KB with the band of the image), so TWO 256-thread workgroups share a CU and one's
 // staging / conv1 / epilogue overlaps the other's conv2; 3 x n units instead of n also cut the last,
 // partly empty round of workgroups to a third.  Cost: the four pooled rows two neighbouring bands share
-// are computed twice (conv1 + 29 %, 7 % of all MFMA work).  The band of the image is staged as bf16 (a
-// u8 value is exact), so a conv1 A fragment is three aligned dword reads and a funnel shift instead of
-// five byte reads, five conversions and the packing.  Every output is the same chain of MFMAs in
+// are computed twice (conv1 + 29 %, 5 % of all MFMA work).  The band of the image is staged as bf16 (a
+// u8 value is exact), so a conv1 A fragment is aligned dword reads and funnel shifts instead of byte
+// reads, conversions and the packing.  Every output is the same chain of MFMAs in
 // the same k order as in the whole-image kernel: bit-identical results.  Measured (934 images): whole
-// image 0.276 ms, bands 0.245 ms.  Ablation: conv1 alone 0.085 ms, conv2 alone 0.127 ms, staging 0.015 ms
-// -- the phases ADD even with two workgroups per CU, and also when conv1 of the next unit runs in the
-// same workgroup beside conv2 of the current one (tried: 0.244 ms): at the clock this kernel sustains
-// (~1.8 GHz) conv2 is matrix-pipe-bound (~0.9 busy) and the pipes are the shared resource.
+// image 0.276 ms, bands 0.245 ms at the time; 0.194 ms with the operand requests in the shadow of the
+// MFMAs (x3_conv2 / x3_conv1) -- ablations of the current kernel (AG2_EXP_ABL): conv2 alone 0.132 ms
+// (0.114 with no operand requests at all = the matrix pipe at the ~1.9 GHz this kernel sustains), conv1
+// alone 0.058 ms (pipe: 0.029), neither 0.008 ms.
 constexpr int kBThreads = 256;
 constexpr int kBWaves = kBThreads / 64;
 constexpr int kBRows = 12;                   // pooled conv1 rows of a band

@@ -55,9 +55,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 CONV_FLOP = 2.0 * (20 * 56 * 56 * 75 + 50 * 24 * 24 * 500)   # 38.208 MFLOP / image
 FC_FLOP = 2.0 * (500 * 7200 + 2 * 500)                        # 7.202 MFLOP / image
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16)
-# k_lenet_conv_x3: v_mfma_f32_32x32x16_bf16 issued per image = conv1 98 tiles x 8 k-blocks x 3 terms
-# + conv2 18 tiles x 2 channel halves x 32 k-blocks x 6 terms; 32*32*16*2 flop each
-CONV_X3_ISSUED_FLOP = (98 * 8 * 3 + 18 * 2 * 32 * 6) * 32768.0
+# k_lenet_conv_x3b: v_mfma_f32_32x32x16_bf16 issued per image = conv1 3 bands x 42 tiles x 5 k-blocks x 3
+# terms (the bands overlap: 126 tiles for 98 tiles' worth of output) + conv2 18 tiles x 2 channel halves
+# x 32 k-blocks x 6 terms; 32*32*16*2 flop each
+CONV_X3_ISSUED_FLOP = (3 * 42 * 5 * 3 + 18 * 2 * 32 * 6) * 32768.0
 # k_lenet_fc1_x3: per 32-image tile 16 column tiles x 450 k-blocks x 6 terms (ip2 and the padding of
 # the batch to 128 images not counted)
 FC_X3_ISSUED_FLOP = 16 * 450 * 6 * 32768.0 / 32

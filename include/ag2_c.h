@@ -97,14 +97,15 @@ typedef struct ag2_times {
   float grid_ms;        /* K0 search grid (ag2_set_cloud*) */
   float normals_ms;     /* K1 k_normals */
   float frames_ms;      /* K2 k_frames */
-  float sweep_ms;       /* K3 k_sweep, first stage (cropped list in 80 KiB of LDS) */
+  float sweep_ms;       /* K3 k_sweep, first stage (cropped list in LDS), up to the finger-placement gates */
   float compact_ms;     /* prune-flag compaction + image descriptors */
   float render_ms;      /* K4 k_render */
   float lenet_conv_ms;  /* K5 k_lenet_conv */
   float lenet_fc_ms;    /* K5 k_lenet_fc */
   float select_ms;      /* K6 score scatter, threshold compaction, record gather */
   float total_ms;       /* first to last event of the call */
-  float sweep_overflow_ms; /* K3 k_sweep, second stage for oversized neighbourhoods (global scratch) */
+  float sweep_overflow_ms; /* K3: k_sweep's second stage (long lists, written to the list arena) + k_sweep_orient (one
+                              workgroup per surviving (sample, orientation) pair) + k_hyp_stats */
   float preprocess_ms;  /* workspace filter + voxel grid (ag2_preprocess_cloud*), without the grid build */
 } ag2_times;
 
