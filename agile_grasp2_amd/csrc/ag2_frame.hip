@@ -204,7 +204,10 @@ int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
   if (rc) return rc;
   rc = launch_frames(c, s_max, 0, 0);
   if (rc) return rc;
+  c->defer_hyp_stats = true;  // (the compaction below takes the statistics along)
+  c->hyp_stats_pending = false;
   rc = launch_sweep(c, s_max, 0, /*emit_lists=*/true, /*run_cleared=*/true);
+  c->defer_hyp_stats = false;
   if (rc) return rc;
   // -- prune (predicate evaluated in the sweep) + image descriptors ------------------------------
   rc = compact_slots_async(c, n_slots, do_prune ? 1 : 0, c->d_list2, &st->n_list, /*with_descs=*/true);

@@ -151,6 +151,8 @@ struct ag2_ctx {
   ag2::DevBuf d_lists;     // split sweep: cropped lists (float4: centred xyz, sorted position) of the samples with a passing orientation
   ag2::DevBuf d_pairs;     // split sweep: SweepPair queue
   ag2::DevBuf d_obox;      // split sweep: per-workgroup closing-region index lists beyond the LDS part
+  bool defer_hyp_stats = false;    // set around launch_sweep by a caller that compacts the slot table next
+  bool hyp_stats_pending = false;  // the split sweep has left its statistics to compact_slots_async
   size_t list_ints = 0;    // capacity of d_lists in points; grown on demand like the arena
   int sweep_gcap = 1 << 16;  // points per workgroup of that scratch; grows to the longest list met
   int sweep_g2 = 1024;       // workgroups of the stage that uses it
@@ -222,10 +224,11 @@ inline char* pin_bulk(ag2_ctx* c) { return (char*)c->h_pin + kPinSmall; }
 int build_grid(ag2_ctx* c);
 // Per-stage timing events cost a few microseconds of stream serialisation each (about 3 % of a cfg2
 // step for all of them), so how many are recorded is a setting (ag2_set_stage_timing): 0 none,
-// 1 only the three around the sweep's two stages (the dominant kernel), 2 all.  Stages whose events
+// 1 only the two around the whole sweep (the dominant kernel; sweep_ms is then its total and
+// sweep_overflow_ms 0), 2 all.  Stages whose events
 // are not recorded report 0 ms.
 inline bool stage_event_on(const ag2_ctx* c, int i) {
-  return c->stage_timing >= 2 || (c->stage_timing == 1 && (i == 1 || i == 2 || i == 11));
+  return c->stage_timing >= 2 || (c->stage_timing == 1 && (i == 1 || i == 11));
 }
 inline hipError_t stage_event(ag2_ctx* c, int i) {
   return stage_event_on(c, i) ? hipEventRecord(c->ev[i], c->stream) : hipSuccess;
@@ -259,6 +262,7 @@ int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
 int launch_sample_queries(ag2_ctx* c, const int* d_idx, size_t s, bool clear_run);
 int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed);
 int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool run_cleared = false);
+int launch_hyp_stats(ag2_ctx* c, size_t n_slots);  // k_sweep_orient.hip: n_hyp, sum_p, max_p from the slot table
 // k_select.hip
 int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out);
 int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count,

@@ -73,7 +73,10 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     rc = launch_frames(c, s, slot_base, seed);
     if (rc) return rc;
     AG2_HIP(c, stage_event(c, 1));
+    c->defer_hyp_stats = compact_mode >= 0;
+    c->hyp_stats_pending = false;
     rc = launch_sweep(c, s, slot_base, emit_lists, fused_clear);  // records ev[2] and ev[11]
+    c->defer_hyp_stats = false;
     if (rc) return rc;
     if (compact_mode >= 0) {
       rc = compact_slots_async(c, s * (size_t)c->p.num_orientations, compact_mode, c->d_list2,
@@ -123,8 +126,13 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
     if (compact_mode >= 0) c->n_img = hs.n_list;
     c->max_p = (int)hs.max_p;
     stage_elapsed(c, &c->times.frames_ms, 0, 1);
-    stage_elapsed(c, &c->times.sweep_ms, 1, 2);
-    stage_elapsed(c, &c->times.sweep_overflow_ms, 2, 11);
+    if (stage_event_on(c, 2)) {
+      stage_elapsed(c, &c->times.sweep_ms, 1, 2);
+      stage_elapsed(c, &c->times.sweep_overflow_ms, 2, 11);
+    } else {  // timing level 1: the sweep as a whole
+      stage_elapsed(c, &c->times.sweep_ms, 1, 11);
+      c->times.sweep_overflow_ms = 0.f;
+    }
     if (c->grid_pending) {
       stage_elapsed(c, &c->times.grid_ms, 12, 13);
       c->grid_pending = false;

@@ -6,6 +6,7 @@
 // (grasp_detector.cpp:363-395; the predicate itself is evaluated inside k_sweep) and the
 // score >= min_score_diff filter (grasp_detector.cpp:198-207).  Slot order (sample, orientation)
 // IS the reference's output order, so a flag + exclusive scan + scatter keeps it.
+#include <stddef.h>
 #include <string.h>
 
 #include "ag2_internal.h"
@@ -45,18 +46,21 @@ __global__ void k_slot_scatter(const unsigned* __restrict__ pref, int n_slots,
 // 4 hypothesis pruned away), 16 slots per load, never the 176-byte records.
 // With desc_off / desc_cnt the image descriptors (arena offset, point count) of the listed slots are
 // written in the same pass (one launch less between the sweep and the renderer).
+// With st_hyp the run's hypothesis statistics (count, points, largest list: what k_hyp_stats gathers
+// from the same state bytes) are taken along: one launch less between the sweep and the read-back.
 __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __restrict__ keep,
                                                         int n_slots, int mode, int* __restrict__ list,
                                                         unsigned* __restrict__ count,
                                                         const ag2_hypothesis* __restrict__ table,
                                                         const long long* __restrict__ tab_off,
                                                         long long* __restrict__ desc_off,
-                                                        int* __restrict__ desc_cnt) {
-  __shared__ unsigned wsum[16];
+                                                        int* __restrict__ desc_cnt, DevStats* st_hyp) {
+  __shared__ unsigned wsum[16], wcnt[16], wmax[16];
+  __shared__ unsigned long long wpts[16];
   const int t = threadIdx.x;
   const int per = (((n_slots + 1023) / 1024) + 15) & ~15;  // 16 .. 64, a multiple of 16
   const int s0 = t * per;
-  unsigned long long mask = 0ull;
+  unsigned long long mask = 0ull, occ = 0ull;
   for (int i = 0; i < per; i += 16) {
     if (s0 + i < n_slots) {  // the buffer is 16-byte padded past n_slots (DevBuf slack)
       const uint4 v = *reinterpret_cast<const uint4*>(keep + s0 + i);
@@ -64,8 +68,10 @@ __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __r
 #pragma unroll
       for (int k = 0; k < 16; k++) {
         const unsigned b = (w[k >> 2] >> (8 * (k & 3))) & 255u;
-        const bool f = (s0 + i + k < n_slots) && (mode == 1 ? (b == 1u) : (b != 0u));
+        const bool in = s0 + i + k < n_slots;
+        const bool f = in && (mode == 1 ? (b == 1u) : (b != 0u));
         mask |= f ? (1ull << (i + k)) : 0ull;
+        occ |= (in && b != 0u) ? (1ull << (i + k)) : 0ull;
       }
     }
   }
@@ -77,6 +83,25 @@ __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __r
     if (lane_id() >= o) inc += v;
   }
   if (lane_id() == 63) wsum[wave_id()] = inc;
+  if (st_hyp) {  // uniform
+    unsigned hc = 0, hm = 0;
+    unsigned long long hp = 0;
+    for (unsigned long long m = occ; m; m &= m - 1ull) {
+      const unsigned p = (unsigned)table[s0 + __ffsll((long long)m) - 1].n_points;
+      hc++;
+      hp += p;
+      hm = max(hm, p);
+    }
+    hc = (unsigned)wave_sum_i((int)hc);
+    const unsigned plo = (unsigned)wave_sum_i((int)(unsigned)(hp & 0xFFFFFFu));  // < 2^24 per lane: no overflow
+    const unsigned phi = (unsigned)wave_sum_i((int)(unsigned)(hp >> 24));
+    hm = (unsigned)(-wave_min_i(-(int)hm));
+    if (lane_id() == 0) {
+      wcnt[wave_id()] = hc;
+      wpts[wave_id()] = (unsigned long long)plo + ((unsigned long long)phi << 24);
+      wmax[wave_id()] = hm;
+    }
+  }
   __syncthreads();
   unsigned woff = 0, all = 0;
 #pragma unroll
@@ -96,19 +121,44 @@ __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __r
     }
     pos++;
   }
-  if (t == 0) *count = all;
+  if (t == 0) {
+    *count = all;
+    if (st_hyp) {
+      unsigned c = 0, m = 0;
+      unsigned long long p = 0;
+      for (int w = 0; w < 16; w++) {
+        c += wcnt[w];
+        p += wpts[w];
+        m = max(m, wmax[w]);
+      }
+      if (c) {  // (added, like k_hyp_stats: the one-kernel sweep counts into the same fields itself)
+        atomicAdd(&st_hyp->n_hyp, c);
+        atomicAdd(&st_hyp->sum_p, p);
+        atomicMax(&st_hyp->max_p, m);
+      }
+    }
+  }
 }
 
 // Asynchronous: the list length is left on the device (*d_count) -- no host round trip.
 int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, unsigned* d_count,
                         bool with_descs) {
   c->desc_stride = 0;
+  // statistics the split sweep left to be gathered from the slot table: along with the small
+  // compaction when that runs, by their own kernel otherwise
+  const bool stats_due = c->hyp_stats_pending;
+  const bool small = n_slots <= 65536 && mode <= 1;
+  c->hyp_stats_pending = false;
   if (n_slots == 0) {
     AG2_HIP(c, hipMemsetAsync(d_count, 0, 4, c->stream));
     return 0;
   }
+  if (stats_due && !small) {
+    const int rc = launch_hyp_stats(c, n_slots);
+    if (rc) return rc;
+  }
   AG2_HIP(c, out_list.reserve(n_slots * 4));
-  if (n_slots <= 65536 && mode <= 1) {
+  if (small) {
     long long* d_off = nullptr;
     if (with_descs) {  // descriptors for up to n_slots images: offsets, then counts
       AG2_HIP(c, c->d_desc.reserve(n_slots * 12));
@@ -118,7 +168,8 @@ int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, 
     hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, c->stream,
                        c->d_tab_keep.as<unsigned char>(), (int)n_slots, mode, out_list.as<int>(), d_count,
                        c->d_table.as<ag2_hypothesis>(), c->d_tab_off.as<long long>(), d_off,
-                       d_off ? (int*)(d_off + n_slots) : (int*)nullptr);
+                       d_off ? (int*)(d_off + n_slots) : (int*)nullptr,
+                       stats_due ? c->d_stats.as<DevStats>() : (DevStats*)nullptr);
     AG2_HIP(c, hipGetLastError());
     return 0;
   }
@@ -201,6 +252,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_small(
     unsigned char* __restrict__ keep, double thr, ag2_hypothesis* __restrict__ out,
     unsigned* __restrict__ count) {
   __shared__ unsigned wsum[kSelThreads / kWave];
+  __shared__ int sel_slot[kSelSmall];
   const int n_cap = n;  // the count trailer sits behind the list's capacity
   if (d_n) n = min(n, (int)*d_n);
   const int tid = threadIdx.x;
@@ -239,11 +291,20 @@ __global__ void __launch_bounds__(kSelThreads) k_select_small(
   unsigned run = woff + inc - tot;
 #pragma unroll
   for (int k = 0; k < kSelPer; k++)
-    if (sel & (1u << k)) {
-      ag2_hypothesis h = table[slot[k]];  // (the score this thread has just written included)
-      h.full_antipodal = 1;               // grasp_detector.cpp:205
-      out[run++] = h;
-    }
+    if (sel & (1u << k)) sel_slot[run++] = slot[k];
+  __syncthreads();  // the slots of the selected records in output order; every score is in the table
+  // the records are copied by all threads, 16 bytes each (a thread copying its own up to eight
+  // 176-byte records one after the other was most of this kernel's time)
+  constexpr int kParts = (int)(sizeof(ag2_hypothesis) / 16);
+  static_assert(sizeof(ag2_hypothesis) == 176 && offsetof(ag2_hypothesis, full_antipodal) == 169, "record layout");
+  const uint4* src = reinterpret_cast<const uint4*>(table);
+  uint4* dst = reinterpret_cast<uint4*>(out);
+  for (int e = tid; e < (int)total * kParts; e += kSelThreads) {
+    const int q = e / kParts, part = e - q * kParts;
+    uint4 v = src[(size_t)sel_slot[q] * kParts + part];
+    if (part == kParts - 1) v.z = (v.z & ~0xFF00u) | 0x0100u;  // full_antipodal = 1 (grasp_detector.cpp:205)
+    dst[(size_t)q * kParts + part] = v;
+  }
   if (tid == 0) {
     *count = total;
     *reinterpret_cast<unsigned*>(out + n_cap) = total;  // trailer: one copy brings records + count

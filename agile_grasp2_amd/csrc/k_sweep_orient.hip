@@ -460,8 +460,19 @@ int launch_sweep_orient(ag2_ctx* c, const SweepArgs& A, size_t n_slots) {
   // the queue length is read on the device: a fixed launch, the surplus workgroups leave at once
   const int grid = (int)std::min<size_t>(std::max<size_t>(n_slots, 1), 256 * 8);
   hipLaunchKernelGGL(k_sweep_orient, dim3(grid), dim3(kOThreads), 0, c->stream, A);
-  hipLaunchKernelGGL(k_hyp_stats, dim3((unsigned)((n_slots + 4095) / 4096)), dim3(256), 0, c->stream, A.tab_keep,
-                     A.table, (int)n_slots, A.st);
+  // the statistics: along with the slot compaction when the caller has announced one (one launch less)
+  if (c->defer_hyp_stats) {
+    c->hyp_stats_pending = true;
+    AG2_HIP(c, hipGetLastError());
+    return 0;
+  }
+  return launch_hyp_stats(c, n_slots);
+}
+
+int launch_hyp_stats(ag2_ctx* c, size_t n_slots) {
+  hipLaunchKernelGGL(k_hyp_stats, dim3((unsigned)((n_slots + 4095) / 4096)), dim3(256), 0, c->stream,
+                     c->d_tab_keep.as<unsigned char>(), c->d_table.as<ag2_hypothesis>(), (int)n_slots,
+                     c->d_stats.as<DevStats>());
   AG2_HIP(c, hipGetLastError());
   return 0;
 }

@@ -427,6 +427,12 @@ def main():
     for k_, v_ in acc2.items():
         if k_ not in ("sweep_ms", "sweep_overflow_ms") and not k_.startswith("reserved"):
             ms[k_] = v_ / K2
+    # the timed region records the sweep as a whole (two events); how it divides into the part up to the
+    # gates and the rest (second stage, orientation kernel) is taken from the untimed pass
+    sweep_total = ms["sweep_ms"] + ms["sweep_overflow_ms"]
+    a2, b2 = acc2.get("sweep_ms", 0.0), acc2.get("sweep_overflow_ms", 0.0)
+    if a2 + b2 > 0:
+        ms["sweep_ms"], ms["sweep_overflow_ms"] = sweep_total * a2 / (a2 + b2), sweep_total * b2 / (a2 + b2)
     n_img = c.n_scored
     # algorithmic work per launch, measured neighbourhood sizes of this run
     kernels = {

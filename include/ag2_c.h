@@ -243,7 +243,8 @@ int ag2_export_candidates_compact_device(ag2_ctx* c, void* d_dst, size_t bytes, 
 int ag2_set_grid_origin(ag2_ctx* c, const float* origin3);
 /* Which of the HIP events behind ag2_get_stage_times are recorded.  Each costs a few microseconds of
  * stream serialisation (all of them about 3 % of a 1 ms detect step): 2 = every stage (default),
- * 1 = only the sweep (sweep_ms, sweep_overflow_ms), 0 = none.  Stages without events report 0 ms.
+ * 1 = only the sweep as a whole (sweep_ms = both stages and the orientation kernel, sweep_overflow_ms = 0),
+ * 0 = none.  Stages without events report 0 ms.
  * The reference has no counterpart (it times with std::clock() around whole calls,
  * grasp_detector.cpp:86-88, :262-266). */
 int ag2_set_stage_timing(ag2_ctx* c, int level);
