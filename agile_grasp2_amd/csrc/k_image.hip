@@ -8,8 +8,8 @@
 // k_render_sparse (P <= 1024, the usual case: P ~ 250 << 3600 cells): every point finds, among the
 // earlier points, how many share its cell (its rank) and the first that does (the cell's leader).
 // Round r then adds the normals of all rank-r points to their leader's accumulator -- distinct
-// cells within a round, list order across rounds -- and only the leaders quantise a pixel.  40 KB of
-// LDS: three workgroups per CU.
+// cells within a round, list order across rounds -- and only the leaders quantise a pixel.  34 KB of
+// LDS: four workgroups per CU.
 // k_render_sorted (1024 < P <= 16384): cell-major sort of the points in LDS, then one run per cell.
 // k_render (any P): every cell is owned by one thread (cell % 256) which adds the normals of its
 // points in list order; two passes of 30 image rows, 76 KB of LDS.
@@ -190,9 +190,9 @@ __global__ void __launch_bounds__(kImgThreads) k_render(const double* __restrict
 
 // The accumulators (one f64 triple per leader point) are dead once the leaders have quantised their
 // cell, and the pixel map + the staged output image are needed only from then on: the two share one
-// area, which brings a workgroup to 27 KB -- five to six per CU (80 VGPRs), 1 280+ images in flight, so the ~900 images of
-// a configuration-2 step run in one round instead of two (the kernel is bound by the latency of one
-// image: ~15 barriers and a dependent read of its point list).
+// area.  With the cell -> first-point table a workgroup takes 34 KB: four per CU, 1 024 images in
+// flight, so the ~900 images of a configuration-2 step run in one round (the kernel is bound by the
+// latency of its largest image: the rank loop, ~15 barriers and a dependent read of its point list).
 struct SparseShared {
   union {
     double acc[kSparseMax * 3];
@@ -202,10 +202,11 @@ struct SparseShared {
     } img;
   } u;
   short cid[kSparseMax];
+  unsigned short lead[kCells];  // list position of each occupied cell's first point
   double red[kImgThreads / kWave];
   int max_rank;
 };
-static_assert(sizeof(SparseShared) * 5 <= 160 * 1024, "k_render_sparse: five workgroups per CU");
+static_assert(sizeof(SparseShared) * 4 <= 160 * 1024, "k_render_sparse: four workgroups per CU");
 
 __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __restrict__ arena,
                                                                const long long* __restrict__ desc_off,
@@ -238,37 +239,38 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
     }
     if (tid == 0) S.max_rank = 0;
     __syncthreads();
-    // rank of every point among the earlier points of its cell, and the cell's first point
+    // rank of every point among the earlier points of its cell: a count only -- whole groups of eight
+    // ids (one LDS read, the same address in every lane) without any index test, the group that
+    // straddles the point itself masked.  This loop is the renderer's critical path (P^2 / 2 compares
+    // for the largest image, and the kernel lasts as long as its largest image).
     int my_rank[kPer], my_lead[kPer], mx = 0;
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
       const int b = tid + k * kImgThreads;
-      my_rank[k] = 0;
+      my_rank[k] = -1;  // beyond the list, or a dropped point (:156)
       my_lead[k] = b;
       if (b < P) {
         const int c = S.cid[b];
         if (c >= 0) {
-          int r = 0, first = b;
-          for (int b0 = 0; b0 < b; b0 += 8) {  // 8 ids per LDS read; entries >= b are masked off
+          const unsigned short cs = (unsigned short)c;
+          int r = 0, b0 = 0;
+          for (; b0 + 8 <= b; b0 += 8) {
             const uint4 w = *reinterpret_cast<const uint4*>(&S.cid[b0]);
             const unsigned ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-              const int id = (int)(short)((ww[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
-              if (id == c && b0 + j < b) {
-                first = min(first, b0 + j);
-                r++;
-              }
-            }
+            for (int j = 0; j < 8; j++) r += ((unsigned short)(ww[j >> 1] >> (16 * (j & 1))) == cs) ? 1 : 0;
+          }
+          if (b0 < b) {
+            const uint4 w = *reinterpret_cast<const uint4*>(&S.cid[b0]);
+            const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+              r += ((unsigned short)(ww[j >> 1] >> (16 * (j & 1))) == cs && b0 + j < b) ? 1 : 0;
           }
           my_rank[k] = r;
-          my_lead[k] = first;
           mx = max(mx, r);
-        } else {
-          my_rank[k] = -1;  // dropped point (:156)
+          if (r == 0) S.lead[c] = (unsigned short)b;  // the cell's first point: one writer per cell
         }
-      } else {
-        my_rank[k] = -1;
       }
       if (b < kSparseMax) {  // every leader starts from 0.0 like the reference's running sum
         S.u.acc[3 * b] = 0.0;
@@ -278,6 +280,9 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
     }
     if (mx > 0) atomicMax(&S.max_rank, mx);
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; k++)
+      if (my_rank[k] > 0) my_lead[k] = S.lead[S.cid[tid + k * kImgThreads]];
     const int rounds = S.max_rank;
     for (int r = 0; r <= rounds; r++) {  // :166-179, list order within each cell
 #pragma unroll
