@@ -183,24 +183,29 @@ __global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ x
   }
   // Consecutive points of a sensor cloud fall into a handful of cells, so the 64 lanes of a wave
   // would queue up on the same few counters: the lanes that share a cell send ONE atomic (their
-  // count) and split the range it returns among themselves by lane order.
-  // (a wave whose points are scattered over many cells falls back to one atomic per lane after a
-  // few rounds)
-  unsigned long long todo = __ballot(k >= 0);
-  for (int round = 0; todo && round < 8; round++) {
-    const int lead = __ffsll((long long)todo) - 1;
-    const int k0 = __builtin_amdgcn_readlane(k, lead);
+  // count) and split the range it returns among themselves by lane order.  The groups are formed
+  // first, in registers (one ballot per distinct cell of the wave), and then all the group leaders'
+  // atomics go out together: one round trip per wave, however its points are scattered -- a
+  // returning atomic inside the grouping loop made a wave of 64 distinct cells wait for nine.
+  const int lane = lane_id();
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int lead = lane;
+  unsigned within = 0, gsize = 1;
+  for (unsigned long long todo = __ballot(k >= 0); todo;) {
+    const int l0 = __ffsll((long long)todo) - 1;
+    const int k0 = __builtin_amdgcn_readlane(k, l0);
     const unsigned long long same = __ballot(k == k0) & todo;
-    unsigned base = 0;
-    if (lane_id() == lead) base = atomicAdd(&cell[k0], (unsigned)__popcll(same));
-    base = (unsigned)__builtin_amdgcn_readlane((int)base, lead);
     if (k == k0) {
-      const unsigned long long below = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
-      r = (int)(base + (unsigned)__popcll(same & below));
+      lead = l0;
+      within = (unsigned)__popcll(same & below);
+      gsize = (unsigned)__popcll(same);
     }
     todo &= ~same;
   }
-  if ((todo >> lane_id()) & 1ull) r = (int)atomicAdd(&cell[k], 1u);
+  unsigned base = 0;
+  if (k >= 0 && lane == lead) base = atomicAdd(&cell[k], gsize);
+  base = (unsigned)__shfl((int)base, lead, 64);
+  r = (int)(base + within);
   if (i < n) key[i] = make_int2(k, r);
 }
 
