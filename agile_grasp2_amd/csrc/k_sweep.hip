@@ -362,6 +362,8 @@ struct SweepShared {
   Red<NW> red;
   int wave_cnt[NW + 1];
   long long arena_off;
+  ListSegs segs;                 // split sweep, long-list stage: this sample's list in the arena
+  int wrun[NW];                  // ... survivors each wave wrote
   int flag;
   unsigned dead;                 // pass A: orientations known to have a point behind the hand
   int next_w[2];                 // work item of the next loop iteration (double-buffered)
@@ -491,8 +493,9 @@ k_sweep(SweepArgs A) {
     if (!A.frame_ok[t]) continue;  // uniform
     const float4 q = A.sample_q[t];
     bool gmode = false;  // stage 0: this sample's list lives in the global slice (set once K is known)
+    ListSegs lsegs = {{0x7fffffff, 0x7fffffff, 0x7fffffff}, {0, 0, 0}};  // (long-list stage: set by the crop)
     auto pos_at = [&](int j) -> int {
-      if (ARENA) return __float_as_int(L[j].w);
+      if (ARENA) return __float_as_int(L[list_slot(lsegs, j)].w);
       return (LITE && gmode) ? gpos[j] : POS[j];
     };
     auto ldp = [&](int j, float& x, float& y, float& z) {  // cropped point j, centred on the sample
@@ -503,7 +506,7 @@ k_sweep(SweepArgs A) {
         z = p.z - q.z;
       } else {
         if (ARENA) {
-          const float4 v = L[j];
+          const float4 v = L[list_slot(lsegs, j)];
           x = v.x;
           y = v.y;
           z = v.z;
@@ -576,7 +579,9 @@ k_sweep(SweepArgs A) {
       }
       continue;
     }
-    int PL = kGrp;  // piece length; grows only if the table would overflow (dense clouds)
+    int PL = kGrp, n_pieces = 0, K = 0;
+    if constexpr (!ARENA) {
+    PL = kGrp;  // piece length; grows only if the table would overflow (dense clouds)
     while (kcand / PL + nrows_c > kMaxPieces) PL <<= 1;
     if (LITE && PL > 32) {  // (cannot happen below the hand-on threshold above; the masks are 32 bits)
       if (tid == 0) {
@@ -585,7 +590,6 @@ k_sweep(SweepArgs A) {
       }
       continue;
     }
-    int n_pieces = 0;
     {
       int len[kRowsPerThread], st[kRowsPerThread], np = 0;
 #pragma unroll
@@ -620,6 +624,7 @@ k_sweep(SweepArgs A) {
         }
       __syncthreads();
     }
+    }
     AG2_PROF(0);
 
     // ---- crop to the +-hand_height slab, ordered compaction --------------------------------
@@ -639,6 +644,7 @@ k_sweep(SweepArgs A) {
       const double zf = (F[0][2] * p0 + F[1][2] * p1) + F[2][2] * p2;
       return (zf > -1.0 * hh && zf < hh) ? 3 : 1;
     };
+    if constexpr (!ARENA) {
     // pass 1: survivors per piece.  A GROUP of kGrp lanes takes one piece (rows of a surface-sheet
     // cloud hold ~8-10 candidates after the culling, so wider groups would idle most lanes), one
     // load instruction covers 64 / kGrp pieces with 16-B-per-lane contiguous reads, and four such
@@ -693,7 +699,7 @@ k_sweep(SweepArgs A) {
     __syncthreads();
     AG2_PROF(1);
     // exclusive scan of the per-piece counts (thread t owns pieces 4t .. 4t+3)
-    int K = 0, k2 = 0;
+    int k2 = 0;
     {
       int c[kPiecesPerThread], tot = 0;
 #pragma unroll
@@ -822,6 +828,145 @@ k_sweep(SweepArgs A) {
           cls = (j < pl[u]) ? classify(A.pts[pb[u] + j], d) : 0;
         }
       }
+    }
+    }
+    if constexpr (ARENA) {
+      // ---- long lists: the crop in ONE pass -------------------------------------------------------
+      // This stage is bound by bytes (a list of a dense cloud is tens of thousands of points), and
+      // counting the survivors before writing them reads every candidate twice.  Here every wave
+      // takes a contiguous quarter of the candidates (units of one row's 64 consecutive candidates: fully
+      // coalesced loads, four in flight), and writes its survivors at once, in order,
+      // into its own part of a reservation as long as the CANDIDATE list.  The list is then up to four
+      // dense segments in canonical order (ListSegs); no piece table, no scan, no barrier in the crop.
+      // Unit table (the piece tables' arrays, unused in this stage): a unit is up to UL consecutive
+      // candidates of one row, UL = 64 unless the table would overflow; start, length and the number of
+      // candidates in front of it (= its place in the reservation).
+      int UL = 64;
+      while (kcand / UL + nrows_c > kMaxPieces) UL <<= 1;
+      int n_units = 0;
+      {
+        int len[kRowsPerThread], st[kRowsPerThread], ctot = 0, nu = 0;
+#pragma unroll
+        for (int k = 0; k < kRowsPerThread; k++) {
+          const int r = tid * kRowsPerThread + k;
+          len[k] = (r < nrows) ? S.row_len[r] : 0;
+          st[k] = (r < nrows) ? S.row_start[r] : 0;
+          ctot += len[k];
+          nu += (len[k] + UL - 1) / UL;
+        }
+        int cinc = ctot, uinc = nu;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(cinc, o, 64), w2 = __shfl_up(uinc, o, 64);
+          if (lane >= o) {
+            cinc += v;
+            uinc += w2;
+          }
+        }
+        __syncthreads();  // the totals above have been read by everyone
+        if (lane == 63) {
+          S.wave_cnt[wid] = cinc;
+          S.wrun[wid] = uinc;
+        }
+        if (tid == 0) {
+          long long loff = (long long)atomicAdd(&A.st->list_top, (unsigned long long)kcand);
+          if (loff + kcand > A.list_cap) {
+            atomicOr(&A.st->err_flags, 2u);  // the host grows the list arena and repeats the run
+            loff = -1;
+          }
+          S.arena_off = loff;
+        }
+        __syncthreads();
+        int coff = 0, uoff = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+          if (k < wid) {
+            coff += S.wave_cnt[k];
+            uoff += S.wrun[k];
+          }
+          n_units += S.wrun[k];
+        }
+        int cp = coff + cinc - ctot, ui = uoff + uinc - nu;
+#pragma unroll
+        for (int k = 0; k < kRowsPerThread; k++) {
+          for (int o = 0; o < len[k]; o += UL) {
+            S.piece_start[ui] = st[k] + o;
+            S.piece_lc[ui] = (unsigned)min(UL, len[k] - o);
+            S.piece_mask[ui] = (unsigned)(cp + o);
+            ui++;
+          }
+          cp += len[k];
+        }
+        __syncthreads();
+      }
+      if (S.arena_off < 0) continue;  // uniform
+      if (kcand == 0) continue;
+      // wave w: units [w, w + 1) * n_units / NW, written from the place of its first unit on
+      const int ubeg = (int)(((long long)wid * n_units) / NW), uend = (int)(((long long)(wid + 1) * n_units) / NW);
+      const int seg0 = (ubeg < n_units) ? (int)S.piece_mask[ubeg] : kcand;
+      float4* Lw = A.lists + S.arena_off + seg0;
+      int run = 0, my_k2 = 0;
+      for (int u0 = ubeg; u0 < uend; u0 += 4) {  // (wave-uniform)
+        int ub[4], ul[4];
+        float4 pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool ok = u0 + u < uend;
+          ub[u] = ok ? S.piece_start[u0 + u] : 0;
+          ul[u] = ok ? (int)S.piece_lc[u0 + u] : 0;
+          // unconditional load from a clamped position: the four loads are issued back to back
+          pv[u] = A.pts[ub[u] + max(min(lane, ul[u] - 1), 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          float4 d;
+          int j = lane;
+          int cls = (j < ul[u]) ? classify(pv[u], d) : 0;
+          for (int o = 0;;) {
+            const unsigned long long mask = __ballot(cls == 3);
+            if (cls == 3) Lw[run + __popcll(mask & lt_mask)] = make_float4(d.x, d.y, d.z, __int_as_float(ub[u] + j));
+            run += __popcll(mask);
+            my_k2 += (cls != 0) ? 1 : 0;
+            o += 64;
+            if (o >= ul[u]) break;  // (units longer than a wave: very dense clouds only)
+            j = o + lane;
+            cls = (j < ul[u]) ? classify(A.pts[ub[u] + j], d) : 0;
+          }
+        }
+      }
+      __syncthreads();  // (the unit counts in S.wrun have been read by everyone)
+      my_k2 = wave_sum_i(my_k2);
+      if (lane == 0) {
+        S.red.i[0][wid][0] = my_k2;
+        S.wrun[wid] = run;
+        S.wave_cnt[wid] = seg0;
+      }
+      __syncthreads();
+      int k2 = 0;
+      {
+        int cum[NW + 1];
+        cum[0] = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+          cum[k + 1] = cum[k] + S.wrun[k];
+          k2 += S.red.i[0][k][0];
+        }
+        K = cum[NW];
+        static_assert(NW == 4, "ListSegs describes four segments");
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          lsegs.end[k] = cum[k + 1];
+          lsegs.shift[k] = S.wave_cnt[k + 1] - cum[k + 1];
+        }
+      }
+      if (tid == 0) {
+        S.segs = lsegs;
+        if (!tighten) atomicAdd(&A.st->sum_k2, (unsigned long long)k2);
+        atomicAdd(&A.st->sum_kcrop, (unsigned long long)K);
+        S.dead = 0u;  // read in pass A, two barriers further down
+      }
+      if (K == 0) continue;
+      L = A.lists + S.arena_off;
     }
     __syncthreads();
     AG2_PROF(2);
@@ -1049,6 +1194,8 @@ k_sweep(SweepArgs A) {
               pr.hand = hand_l;
               pr.K = K;
               pr.list_off = loff;
+              pr.segs = lsegs;
+              pr.pad[0] = pr.pad[1] = 0;
               A.pairs[base + (unsigned)__popcll(todo & lt_mask)] = pr;
             }
           }

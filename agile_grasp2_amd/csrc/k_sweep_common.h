@@ -59,12 +59,28 @@ struct SweepArgs {
   struct SweepPair* pairs;   // [n_samples * R]
 };
 
+// A sample's cropped list in the list arena: up to four dense SEGMENTS in canonical order inside one
+// reservation (the long-list stage writes it in one pass, every wave its own rows, into room reserved
+// from the candidate count: the survivors of a wave's rows are not known before they are written).
+// Entry j of the list sits at arena index list_off + j + shift of its segment; a list written after
+// its length was known (first stage) is one segment: end = K, shift = 0.
+struct ListSegs {
+  int end[3];    // list index at which segments 1, 2, 3 begin
+  int shift[3];  // arena offset - list index within segments 1, 2, 3 (segment 0: 0)
+};
+__device__ __forceinline__ int list_slot(const ListSegs& g, int j) {
+  return j + (j >= g.end[0] ? (j >= g.end[1] ? (j >= g.end[2] ? g.shift[2] : g.shift[1]) : g.shift[0]) : 0);
+}
+
 struct SweepPair {
   int t, oi;                 // sample (position in this run's list), orientation
   unsigned hand;             // the 10 hand bits of the orientation (finger_hand.cpp:313-325)
   int K;                     // length of the sample's cropped list
-  long long list_off;        // its first entry in the list arena
+  long long list_off;        // its reservation in the list arena
+  ListSegs segs;
+  int pad[2];
 };
+static_assert(sizeof(SweepPair) == 56, "pair queue entry");
 
 template <int NW>
 struct Red {

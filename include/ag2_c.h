@@ -87,7 +87,8 @@ typedef struct ag2_counters {
   int64_t n_points, n_valid_points, n_samples, n_frames, n_hypotheses, n_pruned, n_scored, n_selected;
   int64_t sum_k1, sum_k2, sum_kcrop, sum_p;  /* measured neighbourhood sizes (roofline bytes) */
   int64_t n_overflow_samples;                /* samples whose cropped list did not fit the first sweep stage */
-  int64_t list_points;                       /* split sweep: points written to the list arena (16 B each) */
+  int64_t list_points;                       /* split sweep: room taken in the list arena, points of 16 B (long lists
+                                                reserve their candidate count, about 1.7 x their length) */
 } ag2_counters;
 
 /* Device time of the last call per stage, milliseconds (HIP events on the context's stream).
