@@ -98,12 +98,18 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
   int rank = 0;
   for (int j0 = 0; j0 < n; j0 += kTopkThreads) {
     __syncthreads();
-    if (j0 + (int)threadIdx.x < n) sc[threadIdx.x] = recs[j0 + threadIdx.x].score;
+    sc[threadIdx.x] = (j0 + (int)threadIdx.x < n) ? recs[j0 + threadIdx.x].score : -__builtin_inf();
     __syncthreads();
-    const int m = min(kTopkThreads, n - j0);
-    for (int t = 0; t < m; t++) {
-      const double sj = sc[t];
-      rank += (sj > si || (sj == si && j0 + t < i)) ? 1 : 0;
+    // (scores beyond n are padded so that they never count.)  Eight LDS reads in flight and no branch:
+    // one read per iteration, each waited for, behind a short-circuit compare made this loop the
+    // whole kernel.
+    for (int t = 0; t < kTopkThreads; t += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = sc[t + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        rank += (int)(v[u] > si) | ((int)(v[u] == si) & (int)(j0 + t + u < i));
     }
   }
   if (i < n && rank < k) out[rank] = recs[i];
