@@ -54,14 +54,15 @@ struct HandConst {
   int slot_span, pad0;           // floor(finger_width / spacing) + 1
 };
 
-// k_lenet_fc1_x3: split of K (150 chunks of 48) for a batch of `mtiles` 128-image tiles, so that
+// k_lenet_fc1_x3: split of K (225 chunks of 32) for a batch of `mtiles` 128-image tiles, so that
 // small batches still put about two workgroups on every CU.  One rule for the host (exact-size
 // launches) and the device (frame mode, batch size known only there): the split decides the order
 // in which the partial sums are added, so it must not depend on who chose it.
-constexpr int kFc1X3MaxSplit = 30;
+constexpr int kFc1X3Chunks = 225;
+constexpr int kFc1X3MaxSplit = 45;
 __host__ __device__ inline int fc1_x3_ksplit(int mtiles) {
-  const int splits[9] = {1, 2, 3, 5, 6, 10, 15, 25, 30};
-  for (int i = 0; i < 9; i++)
+  const int splits[7] = {1, 3, 5, 9, 15, 25, 45};
+  for (int i = 0; i < 7; i++)
     if ((long long)mtiles * 4 * splits[i] >= 448) return splits[i];
   return kFc1X3MaxSplit;
 }

@@ -563,17 +563,24 @@ int lenet_pack_weights_x3(ag2_ctx* c, const float* c1w, const float* c2w) {
 // ---- ip1 on the bf16 matrix cores, same three-term split ------------------------------------------
 // One 128-image x 128-output tile per workgroup over a K range (split-K; k_lenet_fc_finish adds the
 // partial sums in split order).  The fp32 activations are split into three bf16 terms while they are
-// staged into LDS (row pitch 56 bf16: the 16 rows of an LDS pass fall on disjoint banks), the
-// weights are pre-split and pre-packed in B-fragment order.  Twice the tile height of k_lenet_fc1:
-// the weight stream from L2, which bounds this layer, is read half as often.
+// staged into LDS (row pitch 40 bf16 = 80 bytes: the eight rows of one quarter of a b128 read fall on
+// disjoint banks), the weights are pre-split and pre-packed in B-fragment order.  Twice the tile
+// height of k_lenet_fc1: the weight stream from L2 is read half as often.
+// The stage is DOUBLE-BUFFERED in chunks of 32 k: while the MFMAs of chunk c read one buffer, the same
+// waves split chunk c + 1 (in registers since the chunk before) into the other and request chunk
+// c + 2 -- the conversion, the LDS writes and every request are issued in the shadow of the MFMAs,
+// and a chunk costs one barrier.  (Staging, then MFMAs, two barriers per chunk: matrix pipes 49 %
+// busy.)
 constexpr int kFxBM = 128;
-constexpr int kFxKC = 48;              // k per chunk: 7200 = 150 chunks of three 16-k blocks
-constexpr int kFxPitch = 56;           // bf16 per staged row
+constexpr int kFxKC = 32;              // k per chunk: 7200 = 225 chunks of two 16-k blocks
+constexpr int kFxPitch = 40;           // bf16 per staged row
 constexpr int kFxN = 512;
+static_assert(kFc1X3Chunks * kFxKC == 7200, "ip1: K");
 
 struct FxShared {
-  unsigned short a[3][kFxBM][kFxPitch];
+  unsigned short a[2][3][kFxBM][kFxPitch];  // [buffer][term]
 };
+static_assert(2 * sizeof(FxShared) <= 160 * 1024, "k_lenet_fc1_x3: two workgroups per CU");
 
 __global__ void __launch_bounds__(256, 2)
 k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restrict__ d_n, int n_pad,
@@ -584,14 +591,14 @@ k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restric
     // is read here and the split chosen by the SAME rule the host applies to a known batch size, so
     // the partial sums (and with them every logit) are bit-identical to those of an exact-size launch
     n_img = min(n_img, (int)*d_n);
-    chunks_per_split = 150 / fc1_x3_ksplit((n_img + kFxBM - 1) / kFxBM);
+    chunks_per_split = kFc1X3Chunks / fc1_x3_ksplit((n_img + kFxBM - 1) / kFxBM);
   }
   // Work item -> (image tile bx, column group by, K split bz), K split slowest.  Workgroups go to the
   // 8 XCDs round-robin by their index and every XCD has its own L2, so the items are dealt such that
   // one XCD gets a CONTIGUOUS eighth of them, i.e. one or two K splits: it then fetches an eighth of
   // the weights (2.8 of 22 MB: they stay in its L2 for all image tiles) instead of all of them.
   const int mtiles = (n_img + kFxBM - 1) / kFxBM;
-  const int items = mtiles * 4 * (150 / chunks_per_split);
+  const int items = mtiles * 4 * (kFc1X3Chunks / chunks_per_split);
   const int per_xcd = (items + 7) >> 3;
   const int slot = blockIdx.x >> 3;
   const int item = (int)(blockIdx.x & 7) * per_xcd + slot;
@@ -605,74 +612,102 @@ k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restric
   v16f acc[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // staging: thread t owns image row t / 2 and 24 consecutive k of the chunk
-  const int srow = tid >> 1, scol = (tid & 1) * 24;
+  // staging: thread t owns image row t / 2 and 16 consecutive k of the chunk
+  const int srow = tid >> 1, scol = (tid & 1) * 16;
   const bool srow_ok = (img0 + srow) < n_img;
   const float* sx = x + (size_t)(img0 + srow) * 7200 + scol + (size_t)chunk0 * kFxKC;
-  float4 v[6];
-  auto gload = [&](int ci) {
+  auto gload = [&](int ci, float4(&v)[4]) {
+    const int cc = min(ci, chunks_per_split - 1);  // (requests past the split repeat its last chunk)
 #pragma unroll
-    for (int i = 0; i < 6; i++)
-      v[i] = srow_ok ? *reinterpret_cast<const float4*>(sx + (size_t)ci * kFxKC + 4 * i)
-                     : make_float4(0, 0, 0, 0);
+    for (int i = 0; i < 4; i++)
+      v[i] = srow_ok ? *reinterpret_cast<const float4*>(sx + (size_t)cc * kFxKC + 4 * i) : make_float4(0, 0, 0, 0);
   };
-  auto lstore = [&]() {
-    unsigned short t3[24][3];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      split3(v[i].x, t3[4 * i]);
-      split3(v[i].y, t3[4 * i + 1]);
-      split3(v[i].z, t3[4 * i + 2]);
-      split3(v[i].w, t3[4 * i + 3]);
-    }
+  // one float4 (four k) of the thread's row: three terms, 8 bytes each
+  auto lstore4 = [&](int buf, int i, const float4& v) {
+    unsigned short t3[4][3];
+    split3(v.x, t3[0]);
+    split3(v.y, t3[1]);
+    split3(v.z, t3[2]);
+    split3(v.w, t3[3]);
 #pragma unroll
     for (int s = 0; s < 3; s++) {
-      uint4* d = reinterpret_cast<uint4*>(&S.a[s][srow][scol]);
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        uint4 u;
-        u.x = (unsigned)t3[8 * q][s] | ((unsigned)t3[8 * q + 1][s] << 16);
-        u.y = (unsigned)t3[8 * q + 2][s] | ((unsigned)t3[8 * q + 3][s] << 16);
-        u.z = (unsigned)t3[8 * q + 4][s] | ((unsigned)t3[8 * q + 5][s] << 16);
-        u.w = (unsigned)t3[8 * q + 6][s] | ((unsigned)t3[8 * q + 7][s] << 16);
-        d[q] = u;
-      }
+      uint2 u;
+      u.x = (unsigned)t3[0][s] | ((unsigned)t3[1][s] << 16);
+      u.y = (unsigned)t3[2][s] | ((unsigned)t3[3][s] << 16);
+      *reinterpret_cast<uint2*>(&S.a[buf][s][srow][scol + 4 * i]) = u;
     }
   };
-  const uint4* wl = w3x + ((size_t)(chunk0 * 3) * 16 + nt) * 3 * 64 + lane;  // k-block stride: 16*3*64
-  uint4 nb0 = wl[0], nb1 = wl[64], nb2 = wl[128];
-  gload(0);
-  for (int ci = 0; ci < chunks_per_split; ci++) {
-    __syncthreads();  // the previous chunk's readers are done
-    lstore();
-    __syncthreads();
-    if (ci + 1 < chunks_per_split) gload(ci + 1);  // in flight during this chunk's MFMAs
+  // B fragments: k-block kb of this split, ring of four sets, requested two k-blocks ahead
+  const uint4* wl = w3x + ((size_t)(chunk0 * 2) * 16 + nt) * 3 * 64 + lane;  // k-block stride: 16*3*64
+  const int nkb = chunks_per_split * 2;
+  uint4 B[4][3];
+  auto load_b = [&](int kb, uint4(&d)[3]) {
+    const uint4* wn = wl + (size_t)min(kb, nkb - 1) * (16 * 3 * 64);
+    d[0] = wn[0];
+    d[1] = wn[64];
+    d[2] = wn[128];
+  };
+  // A fragments of two image tiles (t0, t0 + 1) for k-block kb of the chunk in buffer buf
+  auto load_a = [&](int buf, int kbl, int t0, uint4(&d)[2][3]) {
 #pragma unroll
-    for (int kb = 0; kb < 3; kb++) {
-      const bf16x8 Bh = as_frag(nb0), Bm = as_frag(nb1), Bl = as_frag(nb2);
-      {  // next k-block's weights (the last prefetch re-reads the final block)
-        const int nxt = min(ci * 3 + kb + 1, chunks_per_split * 3 - 1);
-        const uint4* wn = wl + (size_t)nxt * (16 * 3 * 64);
-        nb0 = wn[0];
-        nb1 = wn[64];
-        nb2 = wn[128];
-      }
+    for (int t = 0; t < 2; t++)
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int row = 32 * t + r, kk = 16 * kb + 8 * h;
-        const bf16x8 Ah = as_frag(*reinterpret_cast<const uint4*>(&S.a[0][row][kk]));
-        const bf16x8 Am = as_frag(*reinterpret_cast<const uint4*>(&S.a[1][row][kk]));
-        const bf16x8 Al = as_frag(*reinterpret_cast<const uint4*>(&S.a[2][row][kk]));
-        v16f a = acc[t];
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, a, 0, 0, 0);
-        acc[t] = a;
+      for (int s = 0; s < 3; s++)
+        d[t][s] = *reinterpret_cast<const uint4*>(&S.a[buf][s][32 * (t0 + t) + r][16 * kbl + 8 * h]);
+  };
+  auto mma2 = [&](int t0, const uint4(&a)[2][3], const uint4(&bb)[3]) {
+    constexpr int ia[6] = {0, 2, 1, 0, 1, 0}, ib[6] = {2, 0, 1, 1, 0, 0};  // hl, lh, mm, hm, mh, hh
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+        acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a[t][ia[k]]), as_frag(bb[ib[k]]), acc[t0 + t], 0, 0, 0);
+  };
+  float4 RA[4], RB[4];
+  gload(0, RA);
+#pragma unroll
+  for (int i = 0; i < 4; i++) lstore4(0, i, RA[i]);
+  gload(1, RA);
+  gload(2, RB);
+  load_b(0, B[0]);
+  load_b(1, B[1]);
+  uint4 A[2][2][3];
+  __syncthreads();
+  load_a(0, 0, 0, A[0]);
+  // One chunk: four half-steps of 12 MFMAs (k-block 0 tiles 0-1, tiles 2-3, k-block 1 tiles 0-1, tiles 2-3).
+  // Behind the MFMAs of a half-step: the A fragments of the next one, one quarter of the next chunk's
+  // conversion + LDS writes, and (per k-block) the B fragments two k-blocks on.
+  auto chunk = [&](int ci, auto PAR_, float4(&R)[4]) {
+    constexpr int PAR = decltype(PAR_)::value;  // ci & 1: buffer of this chunk, B ring phase
+    const int buf = PAR, nbuf = PAR ^ 1;
+#pragma unroll
+    for (int hs = 0; hs < 4; hs++) {
+      const int kbl = hs >> 1, t0 = 2 * (hs & 1);
+      if (hs == 0) load_b(2 * ci + 2, B[(2 * PAR + 2) & 3]);
+      if (hs == 2) load_b(2 * ci + 3, B[(2 * PAR + 3) & 3]);
+      // next half-step's A fragments (the first of the next chunk come after the barrier)
+      if (hs < 3) load_a(buf, (hs + 1) >> 1, 2 * ((hs + 1) & 1), A[(hs + 1) & 1]);
+      lstore4(nbuf, hs, R[hs]);
+      mma2(t0, A[hs & 1], B[(2 * PAR + kbl) & 3]);
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // an A-fragment read of the next half-step
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // conversion of the next chunk
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // its LDS writes
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // B fragments two k-blocks on
       }
+      x3_fence();
     }
+    gload(ci + 3, R);  // (in flight for a chunk and a half)
+    __syncthreads();   // chunk ci + 1 is staged; every reader of this chunk's buffer is done
+    load_a(nbuf, 0, 0, A[0]);
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  for (int ci = 0; ci < chunks_per_split; ci += 2) {
+    chunk(ci, P0{}, RA);
+    if (ci + 1 < chunks_per_split) chunk(ci + 1, P1{}, RB);
   }
   float* dst = part + ((size_t)bz * n_pad + img0) * kFxN + nt * 32 + r;
 #pragma unroll
@@ -720,7 +755,7 @@ int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out, c
   }
   const dim3 grid((items + 7) / 8 * 8, 1, 1);
   hipLaunchKernelGGL(k_lenet_fc1_x3, grid, dim3(256), 0, c->stream,
-                     c->d_act1.as<float>(), (int)n, d_n, n_pad, d.w3x.as<uint4>(), 150 / ksplit,
+                     c->d_act1.as<float>(), (int)n, d_n, n_pad, d.w3x.as<uint4>(), kFc1X3Chunks / ksplit,
                      c->d_fcpart.as<float>());
   AG2_HIP(c, hipGetLastError());
   *n_pad_out = n_pad;
