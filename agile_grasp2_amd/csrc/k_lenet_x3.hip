@@ -498,8 +498,10 @@ k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsi
 #if !(AG2_EXP_ABL & 1)
       x3_conv1<X3Band, 4, kBWaves>(S, W, bias1, wid, ln, S.imgb);
       x3_conv1<X3Band, 4, kBWaves>(S, W, bias1, wid + 16, ln, S.imgb);
-      x3_conv1<X3Band, 2, kBWaves>(S, W, bias1, wid + 32, ln, S.imgb);
-      if (wid < 2) x3_conv1<X3Band, 1, kBWaves>(S, W, bias1, wid + 40, ln, S.imgb);
+      // (tiles wid + 32, + 36 and, for waves 0 and 1, + 40: three tiles at once rather than a single
+      // one with its chain of dependent MFMAs)
+      if (wid < 2) x3_conv1<X3Band, 3, kBWaves>(S, W, bias1, wid + 32, ln, S.imgb);
+      else x3_conv1<X3Band, 2, kBWaves>(S, W, bias1, wid + 32, ln, S.imgb);
 #endif
     }
     __syncthreads();
