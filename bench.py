@@ -529,12 +529,14 @@ def main():
                  "when it ends (pcie_inclusive.value: the same step with the cloud handed over in host memory)"),
         "config": {
             "workload": (f"{args.config}: {n_cloud}-pt {'voxelised (3 mm)' if voxelised else 'un-voxelised'} "
-                         f"synthetic tabletop cloud, num_samples={S}/GPU, {R} orientations, launch-file hand "
+                         f"synthetic tabletop cloud, num_samples={S}"
+                         f"{'/GPU' if (args.scaling == 'weak' or not dist_on) else ' in total, shared by the GPUs'}, "
+                         f"{R} orientations, launch-file hand "
                          f"geometry, seeded LeNet weights"),
             "n_points": int(n_cloud), "num_samples_per_gpu": (S if args.scaling == "weak" or not dist_on else S // world),
             "num_orientations": R, "per_rank": per_rank,
             "hypotheses_per_step_per_gpu": int(c.n_hypotheses), "scored_per_step_per_gpu": int(n_img),
-            "slots_swept_per_s": S * R * world / (elapsed / K),
+            "slots_swept_per_s": S * R * (world if (args.scaling == "weak" or not dist_on) else 1) / (elapsed / K),
             "mean_K1": c.sum_k1 / max(1, c.n_valid_points), "mean_K2": sum_k2 / max(1, c.n_frames),
             "mean_Kcrop": c.sum_kcrop / max(1, c.n_frames), "mean_P": c.sum_p / max(1, c.n_hypotheses),
             "overflow_samples": int(c.n_overflow_samples),
