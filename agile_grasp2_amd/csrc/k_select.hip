@@ -86,11 +86,19 @@ __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __r
   if (st_hyp) {  // uniform
     unsigned hc = 0, hm = 0;
     unsigned long long hp = 0;
-    for (unsigned long long m = occ; m; m &= m - 1ull) {
-      const unsigned p = (unsigned)table[s0 + __ffsll((long long)m) - 1].n_points;
-      hc++;
-      hp += p;
-      hm = max(hm, p);
+    for (unsigned long long m = occ; m;) {  // four point counts requested at a time (few slots are occupied)
+      unsigned p[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        p[u] = m ? (unsigned)table[s0 + __ffsll((long long)m) - 1].n_points : 0u;
+        hc += m ? 1u : 0u;
+        m &= m - 1ull;  // (0 stays 0)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        hp += p[u];
+        hm = max(hm, p[u]);
+      }
     }
     hc = (unsigned)wave_sum_i((int)hc);
     const unsigned plo = (unsigned)wave_sum_i((int)(unsigned)(hp & 0xFFFFFFu));  // < 2^24 per lane: no overflow
