@@ -183,6 +183,23 @@ def test_cropped_list_longer_than_default_scratch():
     d.close()
 
 
+def test_very_dense_cloud_units_longer_than_a_wave():
+    """Half-millimetre spacing: a neighbourhood holds well over 100 000 candidates, so the one-pass
+    crop of the long-list stage works in units of more than 64 points (the unit table has 1 024
+    entries) and a list spans all four of its segments many times over."""
+    xyz, ws = scene.make_scene(seed=5, n_target=400000, kind="objects", voxel=None, spacing=0.0005)
+    idx = scene.draw_samples(5, xyz.shape[0], 24)
+    o, d = make_pair(xyz, ws, num_orientations=8)
+    got = d.generate_hypotheses(sample_idx=idx, seed=5)
+    want = o.generate_hypotheses(sample_idx=idx, seed=5)
+    c = d.counters()
+    assert c.sum_kcrop // max(1, c.n_frames) > 40000
+    assert_hyps_equal(got, want)
+    assert got.tobytes() == want.tobytes()
+    check_lists_and_images(o, d, want, stride=2)
+    d.close()
+
+
 def test_images_from_points_edge_cases():
     from agile_grasp2_amd import capi
     from oracle import api
