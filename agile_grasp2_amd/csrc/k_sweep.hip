@@ -1123,6 +1123,28 @@ k_sweep(SweepArgs A) {
             blk_acc[i] |= (i == ie) ? bits : 0u;
           }
         }
+        // Long lists: every eighth step, an orientation whose finger slots are already so occupied --
+        // by the points THIS wave has seen -- that no hand placement is left (the gates below:
+        // finger_hand.cpp:313-325, hand_search.cpp:366) is retired as well.  Occupancy only grows with
+        // more points, so it cannot come back; it is marked like one with a point behind the hand
+        // (its slot mask stays incomplete, and the gates must not read it as open).
+        if (STAGE == 1 && (sidx & 7) == 7) {  // (compiled into the long-list stage only: in the other it
+                                               //  cost more -- 3 % of the kernel at cfg2 -- than the few lists
+                                               //  long enough to profit gave back)
+          unsigned full = 0;
+#pragma unroll
+          for (int i = 0; i < RMAX; i++) {
+            if (i < R && ((alive >> i) & 1u)) {  // wave-uniform
+              const unsigned pm = (raw_acc[i] >> 2) & 0x7FFFFu;
+              const unsigned cbw = wave_or_u(blk_acc[i] | (pm & 0x3FFu) | ((pm >> 9) << 10));
+              const unsigned fr = (~cbw) & 0xFFFFFu;
+              if ((fr & (fr >> 10) & 0x3FFu) == 0u || __popc(fr) <= 2) full |= 1u << i;
+            }
+          }
+          full = (unsigned)__builtin_amdgcn_readfirstlane((int)full);
+          s_behind |= full;
+          newly |= full;
+        }
         if (newly) {
           alive &= ~newly;
           if (lane == 0) atomicOr(&S.dead, newly);
