@@ -11,6 +11,8 @@
 // algorithmic bytes = N * (K1 * 12 + 12).
 #include "ag2_internal.h"
 
+// ablation switches for tools/ab_build.sh (timing only, wrong results): 1 no Jacobi, 2 one stencil row
+// only, 4 no statistics atomic
 #ifndef AG2_EXP_NABL
 #define AG2_EXP_NABL 0
 #endif
