@@ -334,12 +334,18 @@ class Detector:
                                        C.byref(ns), None, C.c_size_t(0), C.byref(na)))
             return np.zeros(0, dtype=HYP_DTYPE), na.value
         cap = max(1, s * int(self.params.num_orientations))
-        sel = np.zeros(cap, dtype=HYP_DTYPE)
-        allh = np.zeros(cap if want_all else 1, dtype=HYP_DTYPE)
+        # the selection is at most num_selected records (when that is >= 0): a buffer of that size, kept
+        # between calls -- a fresh zero-filled table of every slot per call is host time inside a step
+        nsel = int(self.params.num_selected)
+        cap_sel = cap if nsel < 0 else max(1, min(cap, nsel))
+        if getattr(self, "_sel_buf", None) is None or len(self._sel_buf) < cap_sel:
+            self._sel_buf = np.zeros(cap_sel, dtype=HYP_DTYPE)
+        sel = self._sel_buf
+        allh = np.zeros(cap, dtype=HYP_DTYPE) if want_all else None
         ns, na = C.c_size_t(0), C.c_size_t(0)
         self._ck(self.L.ag2_detect(self.h, _ptr(si), _ptr(sx), C.c_size_t(s), C.c_uint64(slot_base),
                                    C.c_uint64(seed), C.c_int(1 if do_prune else 0), _ptr(sel),
-                                   C.c_size_t(cap), C.byref(ns),
+                                   C.c_size_t(cap_sel), C.byref(ns),
                                    _ptr(allh) if want_all else None,
                                    C.c_size_t(cap if want_all else 0), C.byref(na)))
         return sel[: ns.value].copy(), (allh[: na.value].copy() if want_all else na.value)
