@@ -163,6 +163,51 @@ __device__ __forceinline__ uint64_t draw_u64(uint64_t seed, uint64_t slot, uint6
 }
 
 // ---- wave / block primitives (64-wide wavefronts) --------------------------------------------
+// ---- rank of record i among n records by (score descending, position ascending) ----------------------
+// grasp_detector.cpp:239-252 (partial_sort by score; ties by list position, as ag2_detect's host sort
+// orders them).  Scores are float differences widened to double, so a record's place in the order is
+// one 64-bit key -- the float's bits made monotone, then the complement of the position -- and the rank
+// is the number of larger keys: every key staged ONCE in LDS, two instructions per compare.  A list
+// longer than kRankKeys, or a score that is not exactly a float, is left to the caller's general loop
+// (returns -1; uniform over the workgroup).  `keys` = kRankKeys x 8 bytes of LDS, `flag` one LDS word.
+constexpr int kRankKeys = 4096;
+__device__ __forceinline__ int rank_by_keys(const ag2_hypothesis* __restrict__ recs, int n, int i,
+                                            unsigned long long* keys, int* flag) {
+  if (n > kRankKeys) return -1;
+  const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+  if (tid == 0) *flag = 0;
+  __syncthreads();
+  const int npad = (n + 7) & ~7;
+  bool inexact = false;
+  for (int j = tid; j < npad; j += nt) {
+    unsigned long long k = 0ull;  // padding: never larger than a real key
+    if (j < n) {
+      const double sd = recs[j].score;
+      const float f = (float)sd + 0.0f;  // (-0.0 and +0.0 compare equal as doubles: one key for both)
+      inexact = inexact || !((double)f == sd);
+      const unsigned b = __float_as_uint(f);
+      const unsigned ok = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+      k = ((unsigned long long)ok << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
+    }
+    keys[j] = k;
+  }
+  if (inexact) *flag = 1;
+  __syncthreads();
+  if (*flag) return -1;
+  int rank = 0;
+  if (i < n) {
+    const unsigned long long ki = keys[i];
+    for (int j0 = 0; j0 < npad; j0 += 8) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = keys[j0 + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) rank += (v[u] > ki) ? 1 : 0;
+    }
+  }
+  return rank;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 

@@ -36,12 +36,6 @@ using namespace ag2;
 
 namespace ag2 {
 
-struct FrameOut {  // copied back once per frame
-  DevStats st;
-  GridDesc g;
-  unsigned n_out;  // records that follow (top-k)
-  unsigned topk_overflow;
-};
 
 }  // namespace ag2
 
@@ -88,15 +82,19 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
     fo->topk_overflow = (k > k_cap) ? (unsigned)k : 0u;
     fo->n_out = (unsigned)min(k, k_cap);
     fo->st = *st;  // (every kernel that updates the statistics has finished)
-    fo->g = *gp;
+    if (gp) fo->g = *gp;
   }
   k = min(k, k_cap);
   const int base = blockIdx.x * kTopkThreads;
   if (base >= n) return;  // uniform
   const int i = base + threadIdx.x;
-  const double si = (i < n) ? recs[i].score : 0.0;
-  int rank = 0;
-  for (int j0 = 0; j0 < n; j0 += kTopkThreads) {
+  __shared__ unsigned long long keys[kRankKeys];
+  __shared__ int inexact;
+  int rank = rank_by_keys(recs, n, i, keys, &inexact);
+  const bool general = rank < 0;  // (uniform) longer than the key stage, or a score that is no float
+  const double si = (general && i < n) ? recs[i].score : 0.0;
+  if (general) rank = 0;
+  for (int j0 = 0; general && j0 < n; j0 += kTopkThreads) {
     __syncthreads();
     sc[threadIdx.x] = (j0 + (int)threadIdx.x < n) ? recs[j0 + threadIdx.x].score : -__builtin_inf();
     __syncthreads();
@@ -113,6 +111,15 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
     }
   }
   if (i < n && rank < k) out[rank] = recs[i];
+}
+
+int launch_topk(ag2_ctx* c, const ag2_hypothesis* d_recs, const unsigned* d_n, size_t cap, size_t k_cap,
+                ag2_hypothesis* d_out, FrameOut* d_fo, const GridDesc* gp) {
+  hipLaunchKernelGGL(k_topk, dim3((unsigned)((std::max<size_t>(cap, 1) + kTopkThreads - 1) / kTopkThreads)),
+                     dim3(kTopkThreads), 0, c->stream, d_recs, d_n, (int)cap, c->p.num_selected, (int)k_cap, d_out,
+                     d_fo, c->d_stats.as<DevStats>(), gp);
+  AG2_HIP(c, hipGetLastError());
+  return 0;
 }
 
 namespace {

@@ -151,6 +151,11 @@ struct ag2_ctx {
   ag2::DevBuf d_lists;     // split sweep: cropped lists (float4: centred xyz, sorted position) of the samples with a passing orientation
   ag2::DevBuf d_pairs;     // split sweep: SweepPair queue
   ag2::DevBuf d_obox;      // split sweep: per-workgroup closing-region index lists beyond the LDS part
+  // ag2_detect without the host round trip in its middle: shapes learned from the previous call
+  size_t spec_cap_img = 0, spec_s = 0;
+  int spec_max_p = 0, spec_prune = -1;
+  long long spec_runs = 0, spec_fallbacks = 0;
+  ag2::DevBuf d_spec;
   bool defer_hyp_stats = false;    // set around launch_sweep by a caller that compacts the slot table next
   bool hyp_stats_pending = false;  // the split sweep has left its statistics to compact_slots_async
   size_t list_ints = 0;    // capacity of d_lists in points; grown on demand like the arena
@@ -261,6 +266,16 @@ int upload_samples(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
                    bool clear_run = false);
 int launch_sample_queries(ag2_ctx* c, const int* d_idx, size_t s, bool clear_run);
 int launch_frames(ag2_ctx* c, size_t s, uint64_t slot_base, uint64_t seed);
+// what the device top-k leaves for the host beside the records: statistics, grid, counts
+struct FrameOut {
+  DevStats st;
+  GridDesc g;
+  unsigned n_out;  // records that follow (top-k)
+  unsigned topk_overflow;
+};
+// ag2_frame.hip: top num_selected of d_recs[0 .. min(*d_n, cap)) by (score desc, position asc) -> d_out, *d_fo
+int launch_topk(ag2_ctx* c, const ag2_hypothesis* d_recs, const unsigned* d_n, size_t cap, size_t k_cap,
+                ag2_hypothesis* d_out, FrameOut* d_fo, const GridDesc* gp);
 int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool run_cleared = false);
 int launch_hyp_stats(ag2_ctx* c, size_t n_slots);  // k_sweep_orient.hip: n_hyp, sum_p, max_p from the slot table
 // k_select.hip

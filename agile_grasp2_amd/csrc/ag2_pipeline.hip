@@ -47,12 +47,44 @@ int read_stats(ag2_ctx* c, DevStats* hs) {
   return 0;
 }
 
+// counters and stage times a finished sweep leaves (hs: its statistics record)
+void note_sweep(ag2_ctx* c, size_t s, const DevStats& hs, int compact_mode) {
+  c->cnt.n_samples = (int64_t)s;
+  c->cnt.n_frames = hs.n_frames;
+  c->cnt.n_hypotheses = hs.n_hyp;
+  c->cnt.sum_k2 = (int64_t)hs.sum_k2;
+  c->cnt.sum_kcrop = (int64_t)hs.sum_kcrop;
+  c->cnt.sum_p = (int64_t)hs.sum_p;
+  c->cnt.n_overflow_samples = hs.n_overflow;  // handed to the sweep's long-list stage
+  c->cnt.list_points = (int64_t)hs.list_top;
+  if (compact_mode >= 0) c->n_img = hs.n_list;
+  c->max_p = (int)hs.max_p;
+  stage_elapsed(c, &c->times.frames_ms, 0, 1);
+  if (stage_event_on(c, 2)) {
+    stage_elapsed(c, &c->times.sweep_ms, 1, 2);
+    stage_elapsed(c, &c->times.sweep_overflow_ms, 2, 11);
+  } else {  // timing level 1: the sweep as a whole
+    stage_elapsed(c, &c->times.sweep_ms, 1, 11);
+    c->times.sweep_overflow_ms = 0.f;
+  }
+  if (c->grid_pending) {
+    stage_elapsed(c, &c->times.grid_ms, 12, 13);
+    c->grid_pending = false;
+  }
+  if (c->normals_pending) {  // the stream has been synchronised: k_normals is long done
+    stage_elapsed(c, &c->times.normals_ms, 9, 10);
+    c->cnt.sum_k1 = (int64_t)hs.sum_k1;
+    c->normals_pending = false;
+  }
+}
+
 // frames + sweep for s samples; fills the slot table (and the arena when emit_lists).
 // compact_mode >= 0 additionally queues the order-preserving compaction of the slot table into
 // d_list2 (0: every hypothesis, 1: those surviving the prune) BEFORE the one host read-back, so the
 // caller learns the list length (c->n_img) without a second round trip.
 int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
-                   uint64_t slot_base, uint64_t seed, bool emit_lists, int compact_mode = -1) {
+                   uint64_t slot_base, uint64_t seed, bool emit_lists, int compact_mode = -1,
+                   bool defer_read = false) {
   if (s * (size_t)c->p.num_orientations > ((size_t)1 << 30))
     return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 table slots");
   c->s = s;
@@ -83,6 +115,7 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
                                &c->d_stats.as<DevStats>()->n_list, /*with_descs=*/true);
       if (rc) return rc;
     }
+    if (defer_read) return 0;  // (ag2_detect's one-round-trip form reads the statistics at its end)
     DevStats hs;
     rc = read_stats(c, &hs);
     if (rc) return rc;
@@ -115,36 +148,86 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
       c->arena_points = std::max<size_t>((size_t)hs.arena_top + ((size_t)hs.arena_top >> 3), c->arena_points * 2);
       continue;
     }
-    c->cnt.n_samples = (int64_t)s;
-    c->cnt.n_frames = hs.n_frames;
-    c->cnt.n_hypotheses = hs.n_hyp;
-    c->cnt.sum_k2 = (int64_t)hs.sum_k2;
-    c->cnt.sum_kcrop = (int64_t)hs.sum_kcrop;
-    c->cnt.sum_p = (int64_t)hs.sum_p;
-    c->cnt.n_overflow_samples = hs.n_overflow;  // handed to the sweep's global-scratch stage
-    c->cnt.list_points = (int64_t)hs.list_top;
-    if (compact_mode >= 0) c->n_img = hs.n_list;
-    c->max_p = (int)hs.max_p;
-    stage_elapsed(c, &c->times.frames_ms, 0, 1);
-    if (stage_event_on(c, 2)) {
-      stage_elapsed(c, &c->times.sweep_ms, 1, 2);
-      stage_elapsed(c, &c->times.sweep_overflow_ms, 2, 11);
-    } else {  // timing level 1: the sweep as a whole
-      stage_elapsed(c, &c->times.sweep_ms, 1, 11);
-      c->times.sweep_overflow_ms = 0.f;
-    }
-    if (c->grid_pending) {
-      stage_elapsed(c, &c->times.grid_ms, 12, 13);
-      c->grid_pending = false;
-    }
-    if (c->normals_pending) {  // the stream has been synchronised: k_normals is long done
-      stage_elapsed(c, &c->times.normals_ms, 9, 10);
-      c->cnt.sum_k1 = (int64_t)hs.sum_k1;
-      c->normals_pending = false;
-    }
+    note_sweep(c, s, hs, compact_mode);
     return 0;
   }
   return set_err(c, AG2_ERR_CAPACITY, "point-list arena could not be sized");
+}
+
+// ag2_detect with ONE host round trip.  The step-by-step form reads the sweep's statistics in the
+// middle (it needs the number of images to size the renderer's and LeNet's launches) and sorts the
+// selected records on the host.  From the second call of a context on, the tail is launched at shapes
+// learned from the previous call -- capacity for a quarter more images, the renderers the largest
+// in-box list so far needs -- with the list length read on the device (the kernels of frame mode),
+// the top num_selected are picked on the device (k_topk), and statistics + records come back in one
+// copy.  The statistics then say whether the shapes held (and whether a buffer was too small):
+// if not, kSpecRedo sends the caller through the step-by-step form, which also learns the new shapes.
+// Results are byte for byte those of the step-by-step form (tests/test_gpu_lenet_detect.py).
+constexpr int kSpecRedo = 1;
+int detect_speculative(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
+                       uint64_t slot_base, uint64_t seed, int do_prune, ag2_hypothesis* selected, size_t cap,
+                       size_t* n_selected, size_t* n_scored) {
+  const size_t n_slots = s * (size_t)c->p.num_orientations;
+  const size_t cap_img = std::min(c->spec_cap_img, n_slots);
+  const size_t k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, cap_img) : cap_img;
+  if (k_cap > cap) return kSpecRedo;  // (the step-by-step form reports the caller's short buffer)
+  int rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true, do_prune ? 1 : 0, /*defer_read=*/true);
+  if (rc) return rc;
+  if (c->desc_stride == 0) return kSpecRedo;  // (no descriptors from the compaction: more than 64 Ki slots)
+  DevStats* st = c->d_stats.as<DevStats>();
+  const unsigned* d_n = &st->n_list;
+  AG2_HIP(c, c->d_images.reserve(cap_img * 10800));
+  AG2_HIP(c, c->d_logits.reserve(cap_img * 8));
+  AG2_HIP(c, stage_event(c, 3));
+  rc = launch_render(c, c->d_arena.as<double>(), c->d_desc.as<long long>(),
+                     (const int*)(c->d_desc.as<long long>() + c->desc_stride), cap_img,
+                     c->d_images.as<uint8_t>(), c->spec_max_p, d_n);
+  if (rc) return rc;
+  AG2_HIP(c, stage_event(c, 4));
+  rc = launch_lenet(c, c->d_images.as<uint8_t>(), cap_img, c->d_logits.as<float>(), 5, d_n);
+  if (rc) return rc;
+  AG2_HIP(c, stage_event(c, 6));
+  const size_t out_bytes = sizeof(FrameOut) + k_cap * sizeof(ag2_hypothesis);
+  AG2_HIP(c, c->d_spec.reserve(out_bytes));
+  FrameOut* d_fo = c->d_spec.as<FrameOut>();
+  ag2_hypothesis* d_rec = reinterpret_cast<ag2_hypothesis*>(d_fo + 1);
+  rc = score_and_select_async(c, c->d_list2.as<int>(), cap_img, &st->n_sel, d_n);
+  if (rc) return rc;
+  c->d_last_sel = c->d_sel.p;  // for ag2_export_selected_compact_device
+  c->d_last_nsel = &st->n_sel;
+  rc = launch_topk(c, c->d_sel.as<ag2_hypothesis>(), &st->n_sel, cap_img, k_cap, d_rec, d_fo, nullptr);
+  if (rc) return rc;
+  AG2_HIP(c, stage_event(c, 7));
+  rc = pin_reserve(c, out_bytes);
+  if (rc) return rc;
+  AG2_HIP(c, hipMemcpyAsync(pin_bulk(c), d_fo, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  FrameOut fo;
+  memcpy(&fo, pin_bulk(c), sizeof(FrameOut));
+  const DevStats& hs = fo.st;
+  // did the shapes hold?  (err_flags: a buffer of the sweep was too small; the step-by-step form grows it)
+  if ((hs.err_flags & (1u | 2u | 8u)) || (size_t)hs.n_list > cap_img ||
+      (int)hs.max_p > render_capacity_for(c->spec_max_p) || fo.topk_overflow)
+    return kSpecRedo;
+  note_sweep(c, s, hs, 1);
+  const size_t n_img = hs.n_list;
+  c->cnt.n_pruned = (int64_t)n_img;
+  c->cnt.n_scored = (int64_t)n_img;
+  c->cnt.n_selected = (int64_t)fo.n_out;
+  *n_selected = fo.n_out;
+  if (n_scored) *n_scored = n_img;
+  stage_elapsed(c, &c->times.compact_ms, 11, 3);
+  stage_elapsed(c, &c->times.render_ms, 3, 4);
+  stage_elapsed(c, &c->times.lenet_conv_ms, 4, 5);
+  stage_elapsed(c, &c->times.lenet_fc_ms, 5, 6);
+  stage_elapsed(c, &c->times.select_ms, 6, 7);
+  stage_elapsed(c, &c->times.total_ms, 8, 7);
+  if (fo.n_out) memcpy(selected, pin_bulk(c) + sizeof(FrameOut), (size_t)fo.n_out * sizeof(ag2_hypothesis));
+  // the shapes follow the workload (never below what just ran)
+  c->spec_cap_img = std::max(c->spec_cap_img, ((n_img + n_img / 4 + 256 + 255) / 256) * 256);
+  c->spec_max_p = std::max(c->spec_max_p, (int)hs.max_p);
+  c->spec_runs++;
+  return 0;
 }
 
 }  // namespace
@@ -323,11 +406,30 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   const size_t n_slots = s * (size_t)c->p.num_orientations;
   (void)n_slots;
   AG2_HIP(c, stage_event(c, 8));
+  // The one-round-trip form, when the previous call on this context left its shapes and nothing asks
+  // for the step-by-step one (all scored records, clustering, the multi-GPU export without read-back,
+  // the f32-input LeNet kernels, AG2_DETECT_STEPWISE=1 for A/B).
+  static const bool spec_off = getenv("AG2_DETECT_STEPWISE") != nullptr;
+  const bool spec = !spec_off && selected && !(scored_all && cap_all) && c->min_inliers <= 0 && c->net.use_x3 &&
+                    !c->fm_on && c->spec_cap_img > 0 && c->spec_s == s && c->spec_prune == (do_prune ? 1 : 0) &&
+                    n_slots > 0 && n_slots <= 65536;
+  if (spec) {
+    rc = detect_speculative(c, sample_idx, sample_xyz, s, slot_base, seed, do_prune, selected, cap, n_selected,
+                            n_scored);
+    if (rc != kSpecRedo) return rc;
+    c->spec_fallbacks++;
+    AG2_HIP(c, stage_event(c, 8));
+  }
   // 1. hypotheses + 2. prune (predicate evaluated in the sweep; the survivor list is compacted on
   // the device and its length comes back with the sweep's statistics: one host round trip)
   rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true, do_prune ? 1 : 0);
   if (rc) return rc;
   const size_t n_img = c->n_img;
+  // shapes for the next call's one-round-trip form
+  c->spec_cap_img = ((n_img + n_img / 4 + 256 + 255) / 256) * 256;
+  c->spec_max_p = c->max_p;
+  c->spec_s = s;
+  c->spec_prune = do_prune ? 1 : 0;
   c->cnt.n_pruned = (int64_t)n_img;
   AG2_HIP(c, c->d_images.reserve(std::max<size_t>(n_img, 1) * 10800));
   AG2_HIP(c, c->d_logits.reserve(std::max<size_t>(n_img, 1) * 8));

@@ -491,9 +491,13 @@ __global__ void __launch_bounds__(256) k_merge_topk(const ag2_hypothesis* __rest
   const int base = blockIdx.x * 256;
   if (base >= n) return;  // uniform
   const int i = base + threadIdx.x;
-  const double si = (i < n) ? recs[i].score : 0.0;
-  int rank = 0;
-  for (int j0 = 0; j0 < n; j0 += 256) {
+  __shared__ unsigned long long keys[kRankKeys];
+  __shared__ int inexact;
+  int rank = rank_by_keys(recs, n, i, keys, &inexact);
+  const bool general = rank < 0;  // (uniform) longer than the key stage, or a score that is no float
+  const double si = (general && i < n) ? recs[i].score : 0.0;
+  if (general) rank = 0;
+  for (int j0 = 0; general && j0 < n; j0 += 256) {
     __syncthreads();
     sc[threadIdx.x] = (j0 + (int)threadIdx.x < n) ? recs[j0 + threadIdx.x].score : -__builtin_inf();
     __syncthreads();

@@ -157,6 +157,67 @@ def test_detect_on_the_null_stream_with_growing_lists(small_scene):
     d.close()
 
 
+def test_one_round_trip_detect_equals_the_step_by_step_form(small_scene):
+    """From its second call on a context, ag2_detect launches its tail at the shapes the previous call
+    left and picks the top-k on the device (one host round trip); asking for all scored records keeps
+    the step-by-step form.  Same bytes either way, also when the shapes do not hold (a busier cloud:
+    the call notices at its end and runs again step by step)."""
+    from agile_grasp2_amd import capi
+    xyz, ws, idx = small_scene
+    w = make_lenet_weights(5)
+    for nsel, thr in ((7, -1e30), (-1, -1e30), (30, None)):
+        prm = scene_params(ws, num_selected=nsel, **({} if thr is None else {"min_score_diff": thr}))
+        if thr is None:
+            prm = dict(prm, min_score_diff=0.0)
+        d = capi.Detector(**prm)
+        d.set_cloud(xyz)
+        d.compute_normals()
+        d.lenet_load(w)
+        ref_sel, ref_all = d.detect(sample_idx=idx, seed=3, do_prune=True)             # step by step
+        ref_cnt = d.counters()
+        for rep in range(3):
+            sel, n_scored = d.detect(sample_idx=idx, seed=3, do_prune=True, want_all=False)
+            assert sel.tobytes() == ref_sel.tobytes(), (nsel, rep)
+            assert n_scored == len(ref_all)
+            c = d.counters()
+            for f in ("n_frames", "n_hypotheses", "sum_kcrop", "sum_p", "n_scored", "n_selected", "n_pruned"):
+                assert getattr(c, f) == getattr(ref_cnt, f), f
+            assert d.times().total_ms > 0
+        # another seed / prune setting through the same context
+        a_sel, a_all = d.detect(sample_idx=idx, seed=4, do_prune=False)
+        b_sel, b_n = d.detect(sample_idx=idx, seed=4, do_prune=False, want_all=False)
+        c_sel, c_n = d.detect(sample_idx=idx, seed=4, do_prune=False, want_all=False)
+        assert b_sel.tobytes() == a_sel.tobytes() == c_sel.tobytes() and b_n == c_n == len(a_all)
+        d.close()
+    # shapes that do not hold: learn on a bare table (no hypotheses: capacity for 256 images), then a
+    # cluttered one with the same number of samples
+    bare, ws1 = scene.make_scene(seed=21, n_target=20000, kind="plane")
+    busy, ws2 = scene.make_scene(seed=22, n_target=60000, kind="tabletop")
+    wsu = [min(ws1[0], ws2[0]), max(ws1[1], ws2[1]), min(ws1[2], ws2[2]), max(ws1[3], ws2[3]),
+           min(ws1[4], ws2[4]), max(ws1[5], ws2[5])]
+    prm = scene_params(wsu, num_selected=20, min_score_diff=-1e30)
+    d, e = capi.Detector(**prm), capi.Detector(**prm)
+    for x in (d, e):
+        x.lenet_load(w)
+    s = 2500
+    i1, i2 = scene.draw_samples(1, bare.shape[0], s), scene.draw_samples(2, busy.shape[0], s)
+    d.set_cloud(bare)
+    d.compute_normals()
+    for _ in range(2):
+        d.detect(sample_idx=i1, seed=1, do_prune=False, want_all=False)
+    d.set_cloud(busy)
+    d.compute_normals()
+    got, n_got = d.detect(sample_idx=i2, seed=2, do_prune=False, want_all=False)   # must fall back
+    again, n_again = d.detect(sample_idx=i2, seed=2, do_prune=False, want_all=False)
+    e.set_cloud(busy)
+    e.compute_normals()
+    want, want_all = e.detect(sample_idx=i2, seed=2, do_prune=False)
+    assert len(want_all) > 300 and n_got == n_again == len(want_all)
+    assert got.tobytes() == want.tobytes() == again.tobytes()
+    d.close()
+    e.close()
+
+
 def test_banded_convolutions_equal_the_whole_image_kernel_bit_for_bit(monkeypatch):
     """k_lenet_conv_x3b (default: a third of an image per workgroup, two workgroups per CU) runs every
     output through the same chain of MFMAs in the same k order as k_lenet_conv_x3 (AG2_LENET_WHOLE=1:
