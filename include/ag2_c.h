@@ -188,7 +188,14 @@ int ag2_lenet_load(ag2_ctx* c, const float* conv1_w, const float* conv1_b, const
 int ag2_lenet_forward(ag2_ctx* c, const uint8_t* images_hwc, size_t n, float* ip2_out);
 /* GraspDetector::detectGraspPoses, grasp_detector.cpp:84-282 (antipodal_mode PREDICTION, no
  * clustering): hypotheses -> [prune] -> images -> LeNet -> score >= min_score_diff -> top
- * num_selected by score.  scored_all (optional) receives every scored hypothesis in order. */
+ * num_selected by score.  scored_all (optional) receives every scored hypothesis in order.
+ * Host round trips: two on a context's first call (the sweep's statistics size the launches of the
+ * renderer and of LeNet; the selected records come back and are sorted on the host), ONE from the
+ * second call on when only the selection is asked for (scored_all == NULL, no clustering): the tail is
+ * launched at the shapes the previous call left with the list length read on the device, the top
+ * num_selected are picked on the device, and if the statistics that come back with them say the
+ * shapes did not hold the call runs again in the two-trip form.  Same bytes either way
+ * (AG2_DETECT_STEPWISE=1 in the environment keeps the two-trip form, for A/B). */
 int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
                uint64_t slot_base, uint64_t seed, int do_prune, ag2_hypothesis* selected,
                size_t cap, size_t* n_selected, ag2_hypothesis* scored_all, size_t cap_all,
