@@ -121,10 +121,13 @@ int pin_reserve(ag2_ctx* c, size_t bulk_bytes) {
   AG2_HIP(c, hipStreamSynchronize(c->stream));  // nothing may still be copying
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   c->h_pin = nullptr;
+  c->h_pin_dev = nullptr;
   c->h_pin_bytes = 0;
   const size_t want = need + need / 2 + 65536;
   AG2_HIP(c, hipHostMalloc(&c->h_pin, want, hipHostMallocDefault));
   c->h_pin_bytes = want;
+  c->h_pin_dev = nullptr;
+  AG2_HIP(c, hipHostGetDevicePointer(&c->h_pin_dev, c->h_pin, 0));
   return 0;
 }
 
@@ -235,7 +238,7 @@ void ag2_destroy(ag2_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);  // NULL = the default stream: still to be waited for
   frame_release(c);
-  DevBuf* bufs[] = {&c->d_spec, &c->d_griddesc, &c->d_lists, &c->d_pairs, &c->d_obox, &c->d_xyz_in, &c->d_key, &c->d_bounds, &c->d_gpos, &c->d_export_list, &c->d_cell, &c->d_perm, &c->d_sorted,
+  DevBuf* bufs[] = {&c->d_griddesc, &c->d_lists, &c->d_pairs, &c->d_obox, &c->d_xyz_in, &c->d_key, &c->d_bounds, &c->d_gpos, &c->d_export_list, &c->d_cell, &c->d_perm, &c->d_sorted,
                     &c->d_nrm, &c->d_scan, &c->d_stats, &c->d_hc, &c->d_sample_q, &c->d_frames,
                     &c->d_frame_ok, &c->d_table, &c->d_tab_off, &c->d_tab_keep, &c->d_arena,
                     &c->d_overflow, &c->d_gscratch, &c->d_list, &c->d_list2, &c->d_images,

@@ -155,7 +155,6 @@ struct ag2_ctx {
   size_t spec_cap_img = 0, spec_s = 0;
   int spec_max_p = 0, spec_prune = -1;
   long long spec_runs = 0, spec_fallbacks = 0;
-  ag2::DevBuf d_spec;
   bool defer_hyp_stats = false;    // set around launch_sweep by a caller that compacts the slot table next
   bool hyp_stats_pending = false;  // the split sweep has left its statistics to compact_slots_async
   size_t list_ints = 0;    // capacity of d_lists in points; grown on demand like the arena
@@ -180,6 +179,8 @@ struct ag2_ctx {
   // page-locked host staging (small read-backs, sample indices, result records): copies from / to it
   // are true asynchronous DMA, so the host keeps enqueueing while the GPU works
   void* h_pin = nullptr;
+  void* h_pin_dev = nullptr;      // the same block as the device sees it (kernels that write results where the host reads them)
+  bool bounds_in_pin = false;     // the extent partials of the current cloud were written straight into pin_small
   size_t h_pin_bytes = 0;
   std::vector<ag2_hypothesis> h_hyps;   // compacted hypotheses of the last generate call
   std::vector<int32_t> h_slots;         // their slot ids
@@ -225,6 +226,8 @@ constexpr size_t kPinSmall = 4096;
 int pin_reserve(ag2_ctx* c, size_t bulk_bytes);
 inline char* pin_small(ag2_ctx* c) { return (char*)c->h_pin; }
 inline char* pin_bulk(ag2_ctx* c) { return (char*)c->h_pin + kPinSmall; }
+inline char* pin_small_dev(ag2_ctx* c) { return (char*)c->h_pin_dev; }
+inline char* pin_bulk_dev(ag2_ctx* c) { return (char*)c->h_pin_dev + kPinSmall; }
 // k_grid.hip
 int build_grid(ag2_ctx* c);
 // Per-stage timing events cost a few microseconds of stream serialisation each (about 3 % of a cfg2

@@ -187,9 +187,13 @@ int detect_speculative(ag2_ctx* c, const int32_t* sample_idx, const double* samp
   rc = launch_lenet(c, c->d_images.as<uint8_t>(), cap_img, c->d_logits.as<float>(), 5, d_n);
   if (rc) return rc;
   AG2_HIP(c, stage_event(c, 6));
+  // the top-k kernel writes statistics + records where the host reads them (page-locked memory through
+  // its device view): no copy operation behind it
   const size_t out_bytes = sizeof(FrameOut) + k_cap * sizeof(ag2_hypothesis);
-  AG2_HIP(c, c->d_spec.reserve(out_bytes));
-  FrameOut* d_fo = c->d_spec.as<FrameOut>();
+  rc = pin_reserve(c, out_bytes);
+  if (rc) return rc;
+  if (!c->h_pin_dev) return kSpecRedo;
+  FrameOut* d_fo = reinterpret_cast<FrameOut*>(pin_bulk_dev(c));
   ag2_hypothesis* d_rec = reinterpret_cast<ag2_hypothesis*>(d_fo + 1);
   rc = score_and_select_async(c, c->d_list2.as<int>(), cap_img, &st->n_sel, d_n);
   if (rc) return rc;
@@ -198,9 +202,6 @@ int detect_speculative(ag2_ctx* c, const int32_t* sample_idx, const double* samp
   rc = launch_topk(c, c->d_sel.as<ag2_hypothesis>(), &st->n_sel, cap_img, k_cap, d_rec, d_fo, nullptr);
   if (rc) return rc;
   AG2_HIP(c, stage_event(c, 7));
-  rc = pin_reserve(c, out_bytes);
-  if (rc) return rc;
-  AG2_HIP(c, hipMemcpyAsync(pin_bulk(c), d_fo, out_bytes, hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
   FrameOut fo;
   memcpy(&fo, pin_bulk(c), sizeof(FrameOut));

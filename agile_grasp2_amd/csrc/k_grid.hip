@@ -417,8 +417,21 @@ int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes
   if (with_bounds) {
     const int nb = std::min(((int)n_pad + 255) / 256, kBoundsBlocks);  // (frame mode: a function of n_pad only)
     AG2_HIP(c, c->d_bounds.reserve((size_t)kBoundsBlocks * 8 * 4));
+    // Step-by-step use: the host reduces the partials, so the kernel writes them where the host reads
+    // them (page-locked memory through its device view): no copy operation in front of the read-back.
+    // Frame mode reduces them on the device (k_cell_count).
+    int* part = c->d_bounds.as<int>();
+    c->bounds_in_pin = false;
+    if (!c->fm_on) {
+      const int rc = pin_reserve(c, 0);
+      if (rc) return rc;
+      if (c->h_pin_dev) {
+        part = reinterpret_cast<int*>(pin_small_dev(c));
+        c->bounds_in_pin = true;
+      }
+    }
     hipLaunchKernelGGL(k_bounds<true>, dim3(nb), dim3(256), 0, c->stream, (const char*)d_xyz,
-                       stride_bytes, dst, (int)n, (int)n_pad, c->d_bounds.as<int>(), c->d_stats.as<DevStats>());
+                       stride_bytes, dst, (int)n, (int)n_pad, part, c->d_stats.as<DevStats>());
     c->bounds_blocks = nb;
   } else {
     hipLaunchKernelGGL(k_pack_xyz, dim3(((int)n + 255) / 256), dim3(256), 0, c->stream,
@@ -483,8 +496,10 @@ int build_grid(ag2_ctx* c) {
       hipLaunchKernelGGL(k_bounds<false>, dim3(nb), dim3(256), 0, c->stream, (const char*)nullptr,
                          (size_t)0, c->d_xyz_in.as<float4>(), n, n, c->d_bounds.as<int>(), st);
     }
-    AG2_HIP(c, hipMemcpyAsync(pin_small(c), c->d_bounds.p, (size_t)nb * 32, hipMemcpyDeviceToHost,
-                              c->stream));
+    if (!(packed_blocks && c->bounds_in_pin))  // (else the pack kernel wrote them into pin_small itself)
+      AG2_HIP(c, hipMemcpyAsync(pin_small(c), c->d_bounds.p, (size_t)nb * 32, hipMemcpyDeviceToHost,
+                                c->stream));
+    c->bounds_in_pin = false;
     AG2_HIP(c, hipStreamSynchronize(c->stream));
     const int* part = (const int*)pin_small(c);
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
