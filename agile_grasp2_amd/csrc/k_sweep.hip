@@ -362,7 +362,6 @@ struct SweepShared {
   Red<NW> red;
   int wave_cnt[NW + 1];
   long long arena_off;
-  ListSegs segs;                 // split sweep, long-list stage: this sample's list in the arena
   int wrun[NW];                  // ... survivors each wave wrote
   int flag;
   unsigned dead;                 // pass A: orientations known to have a point behind the hand
@@ -493,9 +492,11 @@ k_sweep(SweepArgs A) {
     if (!A.frame_ok[t]) continue;  // uniform
     const float4 q = A.sample_q[t];
     bool gmode = false;  // stage 0: this sample's list lives in the global slice (set once K is known)
-    ListSegs lsegs = {{0x7fffffff, 0x7fffffff, 0x7fffffff}, {0, 0, 0}};  // (long-list stage: set by the crop)
+    // the list's segments (long-list stage: set by the crop; else one segment)
+    int ge0 = 0x7fffffff, ge1 = 0x7fffffff, ge2 = 0x7fffffff, gs0 = 0, gs1 = 0, gs2 = 0;
+    auto lslot = [&](int j) { return list_slot6(ge0, ge1, ge2, gs0, gs1, gs2, j); };
     auto pos_at = [&](int j) -> int {
-      if (ARENA) return __float_as_int(L[list_slot(lsegs, j)].w);
+      if (ARENA) return __float_as_int(L[lslot(j)].w);
       return (LITE && gmode) ? gpos[j] : POS[j];
     };
     auto ldp = [&](int j, float& x, float& y, float& z) {  // cropped point j, centred on the sample
@@ -506,7 +507,7 @@ k_sweep(SweepArgs A) {
         z = p.z - q.z;
       } else {
         if (ARENA) {
-          const float4 v = L[list_slot(lsegs, j)];
+          const float4 v = L[lslot(j)];
           x = v.x;
           y = v.y;
           z = v.z;
@@ -953,14 +954,15 @@ k_sweep(SweepArgs A) {
         }
         K = cum[NW];
         static_assert(NW == 4, "ListSegs describes four segments");
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          lsegs.end[k] = cum[k + 1];
-          lsegs.shift[k] = S.wave_cnt[k + 1] - cum[k + 1];
-        }
+        // (the same in every lane: scalar registers)
+        ge0 = __builtin_amdgcn_readfirstlane(cum[1]);
+        ge1 = __builtin_amdgcn_readfirstlane(cum[2]);
+        ge2 = __builtin_amdgcn_readfirstlane(cum[3]);
+        gs0 = __builtin_amdgcn_readfirstlane(S.wave_cnt[1] - cum[1]);
+        gs1 = __builtin_amdgcn_readfirstlane(S.wave_cnt[2] - cum[2]);
+        gs2 = __builtin_amdgcn_readfirstlane(S.wave_cnt[3] - cum[3]);
       }
       if (tid == 0) {
-        S.segs = lsegs;
         if (!tighten) atomicAdd(&A.st->sum_k2, (unsigned long long)k2);
         atomicAdd(&A.st->sum_kcrop, (unsigned long long)K);
         S.dead = 0u;  // read in pass A, two barriers further down
@@ -1216,7 +1218,8 @@ k_sweep(SweepArgs A) {
               pr.hand = hand_l;
               pr.K = K;
               pr.list_off = loff;
-              pr.segs = lsegs;
+              pr.segs.end[0] = ge0; pr.segs.end[1] = ge1; pr.segs.end[2] = ge2;
+              pr.segs.shift[0] = gs0; pr.segs.shift[1] = gs1; pr.segs.shift[2] = gs2;
               pr.pad[0] = pr.pad[1] = 0;
               A.pairs[base + (unsigned)__popcll(todo & lt_mask)] = pr;
             }

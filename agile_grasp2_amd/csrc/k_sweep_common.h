@@ -68,8 +68,14 @@ struct ListSegs {
   int end[3];    // list index at which segments 1, 2, 3 begin
   int shift[3];  // arena offset - list index within segments 1, 2, 3 (segment 0: 0)
 };
-__device__ __forceinline__ int list_slot(const ListSegs& g, int j) {
-  return j + (j >= g.end[0] ? (j >= g.end[1] ? (j >= g.end[2] ? g.shift[2] : g.shift[1]) : g.shift[0]) : 0);
+// (taken by VALUE, six scalars: handed a struct in a local variable the compiler kept it in scratch
+// memory and turned the selection below into an indexed load from it)
+__device__ __forceinline__ int list_slot6(int e0, int e1, int e2, int s0, int s1, int s2, int j) {
+  int sh = 0;
+  sh = (j >= e0) ? s0 : sh;
+  sh = (j >= e1) ? s1 : sh;
+  sh = (j >= e2) ? s2 : sh;
+  return j + sh;
 }
 
 struct SweepPair {

@@ -81,12 +81,12 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     const int t = pr.t, oi = pr.oi, K = pr.K;
     const unsigned hand = pr.hand;
     const float4* plist = A.lists + pr.list_off;
-    ListSegs segs;  // (the same in every lane: kept in scalar registers)
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      segs.end[k] = __builtin_amdgcn_readfirstlane(pr.segs.end[k]);
-      segs.shift[k] = __builtin_amdgcn_readfirstlane(pr.segs.shift[k]);
-    }
+    // (the list's segments: the same in every lane, kept in scalar registers)
+    const int ge0 = __builtin_amdgcn_readfirstlane(pr.segs.end[0]), ge1 = __builtin_amdgcn_readfirstlane(pr.segs.end[1]),
+              ge2 = __builtin_amdgcn_readfirstlane(pr.segs.end[2]);
+    const int gs0 = __builtin_amdgcn_readfirstlane(pr.segs.shift[0]), gs1 = __builtin_amdgcn_readfirstlane(pr.segs.shift[1]),
+              gs2 = __builtin_amdgcn_readfirstlane(pr.segs.shift[2]);
+    auto lslot = [&](int j) { return list_slot6(ge0, ge1, ge2, gs0, gs1, gs2, j); };
     // The list is worked through in chunks of kOStage points staged in LDS: every thread has five loads
     // of the (contiguous) list in flight, and the arithmetic of a pass reads LDS.  The usual list is
     // ONE chunk, staged once for all passes; a long one is re-staged by each pass.
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
       for (int h = 0; h < 2; h++) {  // five loads in flight per thread, twice
         float4 v[kHalf];
 #pragma unroll
-        for (int k = 0; k < kHalf; k++) v[k] = plist[list_slot(segs, c0 + min(tid + (h * kHalf + k) * NT, clen - 1))];
+        for (int k = 0; k < kHalf; k++) v[k] = plist[lslot(c0 + min(tid + (h * kHalf + k) * NT, clen - 1))];
 #pragma unroll
         for (int k = 0; k < kHalf; k++) {
           const int j = tid + (h * kHalf + k) * NT;
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     // e: lmaxy lminy lmaxz lminz rmaxy rminy rmaxz rminz
     auto emit = [&](int bpos, int jl, int jg) {  // member jl of the staged chunk = list entry jg
       const double p0 = (double)S.u.st.px[jl], p1 = (double)S.u.st.py[jl], p2 = (double)S.u.st.pz[jl];
-      const float4 nn = A.nrm[__float_as_int(plist[list_slot(segs, jg)].w)];  // hand_search.cpp:211, :394: the point's normal
+      const float4 nn = A.nrm[__float_as_int(plist[lslot(jg)].w)];  // hand_search.cpp:211, :394: the point's normal
       const double q0 = (double)nn.x, q1 = (double)nn.y, q2 = (double)nn.z;
       double X[3], Y[3], U[3];
 #pragma unroll
