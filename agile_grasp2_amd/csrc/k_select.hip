@@ -83,23 +83,52 @@ __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __r
     if (lane_id() >= o) inc += v;
   }
   if (lane_id() == 63) wsum[wave_id()] = inc;
-  if (st_hyp) {  // uniform
-    unsigned hc = 0, hm = 0;
-    unsigned long long hp = 0;
-    for (unsigned long long m = occ; m;) {  // four point counts requested at a time (few slots are occupied)
-      unsigned p[4];
+  __syncthreads();
+  unsigned woff = 0, all = 0;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        p[u] = m ? (unsigned)table[s0 + __ffsll((long long)m) - 1].n_points : 0u;
-        hc += m ? 1u : 0u;
-        m &= m - 1ull;  // (0 stays 0)
-      }
+  for (int w = 0; w < 16; w++) {
+    if (w < wave_id()) woff += wsum[w];
+    all += wsum[w];
+  }
+  unsigned pos = woff + inc - tot;
+  // ONE walk over the occupied slots of the thread's run, four at a time with their gathers in flight
+  // together (few slots are occupied; one slot per step was a chain of dependent round trips): the
+  // point count feeds the statistics, and for a listed slot the descriptor as well.
+  unsigned hc = 0, hm = 0;
+  unsigned long long hp = 0;
+  const unsigned long long walk = st_hyp ? occ : mask;
+  for (unsigned long long m = walk; m;) {
+    int sl[4];
+    unsigned p[4];
+    long long off[4];
+    bool listed[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < 4; u++) {
+      const int b = m ? __ffsll((long long)m) - 1 : 0;
+      sl[u] = m ? s0 + b : -1;
+      listed[u] = m && ((mask >> b) & 1ull);
+      p[u] = (sl[u] >= 0 && (st_hyp || desc_off)) ? (unsigned)table[sl[u]].n_points : 0u;
+      off[u] = (listed[u] && desc_off) ? tab_off[sl[u]] : 0ll;
+      m &= m - 1ull;  // (0 stays 0)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (sl[u] >= 0) {
+        hc++;
         hp += p[u];
         hm = max(hm, p[u]);
       }
+      if (listed[u]) {
+        list[pos] = sl[u];
+        if (desc_off) {
+          desc_off[pos] = off[u];
+          desc_cnt[pos] = (int)p[u];
+        }
+        pos++;
+      }
     }
+  }
+  if (st_hyp) {  // uniform
     hc = (unsigned)wave_sum_i((int)hc);
     const unsigned plo = (unsigned)wave_sum_i((int)(unsigned)(hp & 0xFFFFFFu));  // < 2^24 per lane: no overflow
     const unsigned phi = (unsigned)wave_sum_i((int)(unsigned)(hp >> 24));
@@ -109,40 +138,22 @@ __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __r
       wpts[wave_id()] = (unsigned long long)plo + ((unsigned long long)phi << 24);
       wmax[wave_id()] = hm;
     }
-  }
-  __syncthreads();
-  unsigned woff = 0, all = 0;
-#pragma unroll
-  for (int w = 0; w < 16; w++) {
-    if (w < wave_id()) woff += wsum[w];
-    all += wsum[w];
-  }
-  unsigned pos = woff + inc - tot;
-  while (mask) {
-    const int b = __ffsll((long long)mask) - 1;
-    mask &= mask - 1ull;
-    const int sl = s0 + b;
-    list[pos] = sl;
-    if (desc_off) {
-      desc_off[pos] = tab_off[sl];
-      desc_cnt[pos] = table[sl].n_points;
-    }
-    pos++;
+    __syncthreads();
   }
   if (t == 0) {
     *count = all;
     if (st_hyp) {
-      unsigned c = 0, m = 0;
-      unsigned long long p = 0;
+      unsigned c = 0, mx = 0;
+      unsigned long long pp = 0;
       for (int w = 0; w < 16; w++) {
         c += wcnt[w];
-        p += wpts[w];
-        m = max(m, wmax[w]);
+        pp += wpts[w];
+        mx = max(mx, wmax[w]);
       }
       if (c) {  // (added, like k_hyp_stats: the one-kernel sweep counts into the same fields itself)
         atomicAdd(&st_hyp->n_hyp, c);
-        atomicAdd(&st_hyp->sum_p, p);
-        atomicMax(&st_hyp->max_p, m);
+        atomicAdd(&st_hyp->sum_p, pp);
+        atomicMax(&st_hyp->max_p, mx);
       }
     }
   }
