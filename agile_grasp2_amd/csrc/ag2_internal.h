@@ -36,21 +36,24 @@ struct DevBuf {
 // Device-side counters / flags block (one per context, zeroed per call).
 struct DevStats {
   // --- zeroed before every hypothesis run (everything before `bounds`) ---
+  // The counters that thousands of workgroups hit with atomics during one kernel -- and whose return
+  // values some of them wait for -- sit on cache lines of their own: atomics on ONE line are served
+  // one after the other by the L2 channel that owns it, whatever their addresses within it.
   unsigned long long sum_k2, sum_kcrop, sum_p;
-  unsigned long long arena_top;      // in-box points reserved in the arena
-  unsigned int n_frames, n_hyp, n_overflow, n_pruned_keep;
+  unsigned int n_frames, n_hyp, n_pruned_keep;
   unsigned int err_flags;            // bit0 arena overflow, bit1 list arena overflow (split sweep), bit3 global sweep scratch overflow
   unsigned int n_list;               // hypotheses that go on to be scored (after the prune)
   unsigned int n_sel;                // scored hypotheses with score >= min_score_diff
   unsigned int n_clu;                // selected hypotheses that survive the clustering
   unsigned int max_p;                // largest in-box list of the run (picks the image renderers)
-  unsigned int work_next[3];         // k_sweep work queues, one per stage (items beyond the first grid)
   unsigned int max_k_over;           // longest cropped list that did not fit the sweep's global scratch
-  unsigned int n_pairs;              // split sweep: (sample, orientation) pairs queued for k_sweep_orient
-  unsigned int pad0[2];
-  unsigned long long list_top;       // split sweep: ints reserved in the list arena
+  alignas(128) unsigned long long arena_top;  // in-box points reserved in the arena (returning atomic per hypothesis)
+  alignas(128) unsigned long long list_top;   // split sweep: points reserved in the list arena (returning atomic per sample)
+  alignas(128) unsigned int n_pairs;          // split sweep: (sample, orientation) pairs queued for k_sweep_orient
+  alignas(128) unsigned int n_overflow;       // samples handed on to the long-list stage
+  alignas(128) unsigned int work_next[3];     // k_sweep work queues, one per stage (items beyond the first grid)
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
-  unsigned int bounds[7];            // ordered-int min xyz, max xyz, n_valid
+  alignas(128) unsigned int bounds[7];        // ordered-int min xyz, max xyz, n_valid
   unsigned int pad1;
   unsigned long long sum_k1;         // neighbours visited by k_normals
 };

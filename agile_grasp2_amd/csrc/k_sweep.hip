@@ -36,9 +36,9 @@ __global__ void k_sample_queries_idx(const int* __restrict__ idx, int s,
                                      float4* __restrict__ q, unsigned char* __restrict__ tab_keep,
                                      int R, DevStats* __restrict__ st) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tab_keep && i == 0) {
+  if (tab_keep && blockIdx.x == 0) {  // the per-run statistics: one word per thread
     unsigned* w = reinterpret_cast<unsigned*>(st);
-    for (int k = 0; k < (int)(offsetof(DevStats, bounds) / 4); k++) w[k] = 0u;
+    for (int k = threadIdx.x; k < (int)(offsetof(DevStats, bounds) / 4); k += blockDim.x) w[k] = 0u;
   }
   if (i >= s) return;
   if (tab_keep)
