@@ -115,25 +115,38 @@ __global__ void __launch_bounds__(64) k_frames(const float4* __restrict__ pts,
         row_first[lane] = inc - rl;
         row_begin[lane] = rb;
         __syncthreads();
-        for (int c0 = 0; c0 < total; c0 += 64) {
-          const int cidx = c0 + lane;
-          bool pred = false;
-          int j = 0;
+        // all (up to four) candidates of a lane are requested together, points and normals alike: one
+        // round trip instead of two per group of 64 (a normal is read whether or not its point turns
+        // out to lie within the radius -- a few bytes more for a shorter chain)
+        int jj[4];
+        float4 pp[4], nn4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int cidx = 64 * u + lane;
+          jj[u] = -1;
+          pp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          nn4[u] = pp[u];
           if (cidx < total) {
             int row = 0;
             for (int r = 1; r < nrows; r++) row = (row_first[r] <= cidx) ? r : row;
-            j = row_begin[row] + (cidx - row_first[row]);
-            const float4 p = pts[j];
-            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            if (d2 < r2) {
-              const float4 nn = nrm[j];
-              pred = finite3(nn.x, nn.y, nn.z);
-            }
+            jj[u] = row_begin[row] + (cidx - row_first[row]);
+            pp[u] = pts[jj[u]];
+            nn4[u] = nrm[jj[u]];
           }
-          const unsigned long long mask = __ballot(pred);
-          if (pred) nbuf[k1f + __popcll(mask & lt_mask)] = j;
-          k1f += __popcll(mask);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (64 * u < total) {  // uniform
+            bool pred = false;
+            if (jj[u] >= 0) {
+              const float dx = pp[u].x - q.x, dy = pp[u].y - q.y, dz = pp[u].z - q.z;
+              const float d2 = (dx * dx + dy * dy) + dz * dz;
+              pred = (d2 < r2) && finite3(nn4[u].x, nn4[u].y, nn4[u].z);
+            }
+            const unsigned long long mask = __ballot(pred);
+            if (pred) nbuf[k1f + __popcll(mask & lt_mask)] = jj[u];
+            k1f += __popcll(mask);
+          }
         }
         __syncthreads();
       }
