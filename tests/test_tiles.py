@@ -245,6 +245,56 @@ def test_merge_of_the_ranks_selected_lists_on_the_gpu(world):
     hip.hipFree(dbuf)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ties", "long", "not_a_float"])
+def test_device_top_k_order(case):
+    """The device top-k (merge, frame mode, ag2_detect's one-round-trip form) orders by score descending,
+    ties by position (grasp_detector.cpp:239-252 with a stable tie rule).  Crafted lists: equal scores,
+    +0.0 against -0.0, negative scores and infinities ("ties"); more records than the kernel's key stage
+    holds ("long": the general loop); a score that is not exactly a float ("not_a_float": the general
+    loop again) -- against the same order taken in numpy."""
+    import ctypes as C
+    from agile_grasp2_amd import capi
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(11)
+    world = 3
+    n_rank = {"ties": (200, 0, 317), "long": (2500, 2100, 1900), "not_a_float": (90, 40, 70)}[case]
+    cap = max(n_rank)
+    lists = []
+    for r, n in enumerate(n_rank):
+        rec = np.zeros(n, dtype=capi.HYP_DTYPE)
+        sc = rng.choice(np.float32([-3.5, -0.0, 0.0, 1.25, 1.25, 7.0, -1e30, 2.0 ** -130]), size=n).astype(np.float64)
+        if case == "long":
+            sc = rng.integers(-50, 50, size=n).astype(np.float64)       # many ties
+        if case == "ties" and n:
+            sc[:4] = [np.inf, -np.inf, 0.0, -0.0]
+        if case == "not_a_float" and r == 1:
+            sc[7] = 0.1                                                  # a double no float equals
+        rec["score"] = sc
+        rec["sample_slot"] = 1000 * r + np.arange(n)
+        rec["n_points"] = 1 + np.arange(n)
+        lists.append(rec)
+    per = sharding.compact_bytes(cap)
+    raw = np.concatenate([sharding.pack_compact(rec, cap) for rec in lists])
+    flat = np.concatenate(lists)
+    dbuf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dbuf), per * world) == 0
+    assert hip.hipMemcpy(dbuf, raw.ctypes.data_as(C.c_void_p), per * world, 1) == 0
+    ws = [0.0, 1.0, -1.0, 1.0, -1.0, 1.0]
+    for k in (1, 29, -1):
+        d = capi.Detector(**scene_params(ws, num_selected=k))
+        got, n_total = d.merge_selected_device(dbuf.value, world, cap)
+        order = sorted(range(len(flat)), key=lambda i: (-flat["score"][i], i))
+        want = flat[order if k < 0 else order[:k]]
+        assert n_total == len(flat)
+        assert got.tobytes() == want.tobytes(), (case, k)
+        d.close()
+    hip.hipFree(dbuf)
+
+
 def test_cost_balanced_bounds():
     rng = np.random.default_rng(0)
     costs = rng.integers(1, 100, size=1000).astype(np.float64)
