@@ -26,6 +26,7 @@ SYMBOLS = [
     "ag2_export_candidates_compact_device", "ag2_hand_constants",
     "ag2_stream_configure", "ag2_detect_frame", "ag2_get_frame_info",
     "ag2_export_selected_compact_device", "ag2_merge_selected_device",
+    "ag2_detect_frame_raw", "ag2_get_samples",
 ]
 
 
@@ -49,7 +50,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_points", "n_valid_points", "n_samples", "n_frames", "n_hypotheses", "n_pruned",
         "n_scored", "n_selected", "sum_k1", "sum_k2", "sum_kcrop", "sum_p", "n_overflow_samples",
-        "list_points")]
+        "list_points", "detect_one_trip", "detect_redone")]
 
 
 class FrameInfo(C.Structure):
@@ -372,6 +373,38 @@ class Detector:
                                          C.c_int(1 if do_prune else 0), _ptr(sel), C.c_size_t(cap),
                                          C.byref(ns), C.byref(na)))
         return sel[: ns.value].copy(), na.value
+
+    def detect_frame_raw(self, xyz=None, num_samples=0, sample_seed=0, seed=0, do_prune=True, dptr=None, n=None,
+                         stride=12, filter_workspace=True, voxel_size=0.003):
+        """One frame of the RAW cloud (ag2_detect_frame_raw): workspace filter, voxel grid and uniform
+        sub-sampling on the device in front of the frame.  Returns (selected, n_scored, n_voxels)."""
+        if dptr is None:
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+            n, stride, ptr, on_dev = xyz.shape[0], 12, _ptr(xyz), 0
+        else:
+            ptr, on_dev = C.c_void_p(dptr), 1
+        cap = max(1, int(num_samples) * int(self.params.num_orientations))
+        nsel = int(self.params.num_selected)
+        cap_sel = cap if nsel < 0 else max(1, min(cap, nsel))
+        if getattr(self, "_sel_buf", None) is None or len(self._sel_buf) < cap_sel:
+            self._sel_buf = np.zeros(cap_sel, dtype=HYP_DTYPE)
+        sel = self._sel_buf
+        ns, na, nv = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._ck(self.L.ag2_detect_frame_raw(self.h, ptr, C.c_int(on_dev), C.c_size_t(n), C.c_size_t(stride),
+                                             C.c_int(int(filter_workspace)), C.c_double(voxel_size),
+                                             C.c_size_t(num_samples), C.c_uint64(sample_seed), C.c_uint64(seed),
+                                             C.c_int(1 if do_prune else 0), _ptr(sel), C.c_size_t(cap_sel),
+                                             C.byref(ns), C.byref(na), C.byref(nv)))
+        self.n = int(nv.value)
+        return sel[: ns.value].copy(), na.value, nv.value
+
+    def get_samples(self):
+        """The sample indices the device drew last (subsample_uniformly / detect_frame_raw)."""
+        m = C.c_size_t(0)
+        cap = max(1, self.n)
+        out = np.zeros(cap, dtype=np.int32)
+        self._ck(self.L.ag2_get_samples(self.h, _ptr(out), C.c_size_t(cap), C.byref(m)))
+        return out[: m.value].copy()
 
     def frame_info(self) -> FrameInfo:
         fi = FrameInfo()

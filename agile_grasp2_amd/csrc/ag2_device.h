@@ -31,6 +31,8 @@ struct GridDesc {
 struct FrameArgs {
   unsigned long long seed;
   unsigned long long slot_base;
+  unsigned long long sample_seed;  // ag2_detect_frame_raw: seed of the uniform sub-sampling
+  unsigned long long pad;
 };
 
 // Per-context constants, built on the host (ag2_context.hip derive_constants) and read through a

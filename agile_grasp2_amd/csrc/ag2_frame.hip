@@ -25,6 +25,13 @@
 // A frame that does not fit the captured shapes (more points, samples or cells; arena or sweep
 // scratch too small) is detected from the flags that come back with the results and is repeated on
 // the step-by-step path, which sizes the buffers; the graph is captured again afterwards.
+//
+// ag2_detect_frame_raw starts one step earlier, at the RAW cloud of the sensor: the workspace filter,
+// the 3 mm voxel grid and the uniform sub-sampling (GraspDetector::preprocessPointCloud,
+// grasp_detector.cpp:285-335; CloudCamera::filterWorkspace / voxelizeCloud / subsampleUniformly,
+// cloud_camera.cpp:89-178) run on the device inside the same captured sequence (k_preprocess.hip:
+// enqueue_front_frame) -- the processed cloud, the search grid's description and the sample indices never
+// leave HBM, and there is still exactly one host synchronisation per frame.
 #include <math.h>
 #include <string.h>
 
@@ -57,6 +64,9 @@ struct ag2_frame_state {
   bool graph_valid = false;
   unsigned long long sig_at_capture = 0;  // addresses / sizes the captured graph holds
   ag2_frame_info info{};
+  // ag2_detect_frame_raw: the shapes of the front end (raw == false: frames arrive preprocessed)
+  bool raw = false;
+  ag2::FrontShapes fs{};
 };
 
 namespace ag2 {
@@ -72,7 +82,8 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
                                                        int k_want, int k_cap,
                                                        ag2_hypothesis* __restrict__ out, FrameOut* fo,
                                                        const DevStats* __restrict__ st,
-                                                       const GridDesc* __restrict__ gp) {
+                                                       const GridDesc* __restrict__ gp,
+                                                       const PreFrame* __restrict__ pfp) {
   // out / fo: page-locked host memory seen through its device view -- the last kernel of a frame
   // writes the results where the host reads them, no copy operation follows
   __shared__ double sc[kTopkThreads];
@@ -83,6 +94,7 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
     fo->n_out = (unsigned)min(k, k_cap);
     fo->st = *st;  // (every kernel that updates the statistics has finished)
     if (gp) fo->g = *gp;
+    if (pfp) fo->pre = *pfp;
   }
   k = min(k, k_cap);
   const int base = blockIdx.x * kTopkThreads;
@@ -114,10 +126,10 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
 }
 
 int launch_topk(ag2_ctx* c, const ag2_hypothesis* d_recs, const unsigned* d_n, size_t cap, size_t k_cap,
-                ag2_hypothesis* d_out, FrameOut* d_fo, const GridDesc* gp) {
+                ag2_hypothesis* d_out, FrameOut* d_fo, const GridDesc* gp, const PreFrame* pfp) {
   hipLaunchKernelGGL(k_topk, dim3((unsigned)((std::max<size_t>(cap, 1) + kTopkThreads - 1) / kTopkThreads)),
                      dim3(kTopkThreads), 0, c->stream, d_recs, d_n, (int)cap, c->p.num_selected, (int)k_cap, d_out,
-                     d_fo, c->d_stats.as<DevStats>(), gp);
+                     d_fo, c->d_stats.as<DevStats>(), gp, pfp);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
@@ -154,11 +166,16 @@ unsigned long long frame_signature(const ag2_ctx* c, const ag2_frame_state* f) {
                         c->d_overflow.p, c->d_gscratch.p, c->d_gpos.p, c->d_lists.p, c->d_pairs.p, c->d_list2.p, c->d_images.p,
                         c->d_logits.p, c->d_act1.p, c->d_fcpart.p, c->d_sel.p, c->d_flags.p, c->d_desc.p,
                         c->d_scan.p, f->h_pin, c->net.w1x.p, c->net.w2x.p, c->net.w3x.p,
-                        c->net.b1.p, c->net.b2.p, c->net.b3.p, c->net.w4.p, c->net.b4.p, (const void*)c->stream};
+                        c->net.b1.p, c->net.b2.p, c->net.b3.p, c->net.w4.p, c->net.b4.p, (const void*)c->stream,
+                        c->d_raw.p, c->d_bitmap.p, c->d_wrank.p, c->d_preframe.p, c->d_cand.p, c->d_samples.p};
+  unsigned cell_bits = 0;
+  memcpy(&cell_bits, &f->fs.cell, 4);
   const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points, c->list_ints, f->cap_img,
                                      (unsigned long long)c->sweep_gcap, (unsigned long long)c->sweep_g2,
                                      (unsigned long long)c->p.num_selected, f->k_cap, (unsigned long long)f->cap_p,
-                                     (unsigned long long)c->origin_set};
+                                     (unsigned long long)c->origin_set, (unsigned long long)f->raw, f->fs.raw_max,
+                                     f->fs.cap_words, f->fs.cand_cap, (unsigned long long)cell_bits,
+                                     (unsigned long long)f->fs.filter_workspace};
   unsigned long long h = 1469598103934665603ull;
   auto mix = [&h](unsigned long long v) {
     for (int b = 0; b < 8; b++) {
@@ -171,6 +188,11 @@ unsigned long long frame_signature(const ag2_ctx* c, const ag2_frame_state* f) {
   for (int a = 0; a < 3; a++) {
     unsigned u;
     memcpy(&u, &c->origin[a], 4);
+    mix(u);
+  }
+  for (int k = 0; k < 6; k++) {  // (the workspace is a by-value argument of the front end's kernels)
+    unsigned long long u;
+    memcpy(&u, &c->p.workspace[k], 8);
     mix(u);
   }
   return h;
@@ -192,8 +214,14 @@ int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
   const int R = c->p.num_orientations;
   const size_t n_slots = s_max * (size_t)R;
   DevStats* st = c->d_stats.as<DevStats>();
+  // -- the front end of a raw frame: workspace filter, voxel grid, uniform sub-sampling ---------------
+  if (f->raw) {
+    const int rc0 = enqueue_front_frame(c, f->fs);
+    if (rc0) return rc0;
+  }
   GridDesc* gp = c->d_griddesc.as<GridDesc>();
-  // -- K0 search grid (its description derived from the extent partials inside k_cell_count) --------
+  // -- K0 search grid (its description derived from the extent partials inside k_cell_count, or left
+  // in memory by the front end) ---------------------------------------------------------------------
   AG2_HIP(c, c->d_key.reserve(n_max * 8));
   const size_t cell_words = ((cap_cells + 1) + 3) & ~size_t(3);
   const size_t ctl_words = (scan_ctl_words((int)cap_cells + 1) + 3) & ~size_t(3);
@@ -213,7 +241,9 @@ int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
   AG2_HIP(c, c->d_frames.reserve(s_max * 12 * 8));
   AG2_HIP(c, c->d_frame_ok.reserve(s_max * 4));
   AG2_HIP(c, c->d_tab_keep.reserve(std::max<size_t>(n_slots, 1)));
-  rc = launch_sample_queries(c, (const int*)((const char*)c->fm_args_dev + f->off_idx), s_max, true);
+  // (a raw frame's sample indices were left in d_samples by the front end)
+  rc = launch_sample_queries(c, f->raw ? c->d_samples.as<int>() : (const int*)((const char*)c->fm_args_dev + f->off_idx),
+                             s_max, true);
   if (rc) return rc;
   rc = launch_frames(c, s_max, 0, 0);
   if (rc) return rc;
@@ -245,20 +275,264 @@ int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
   FrameOut* d_fo = (FrameOut*)((char*)c->fm_args_dev + f->off_out);
   hipLaunchKernelGGL(k_topk, dim3((unsigned)((cap_img + kTopkThreads - 1) / kTopkThreads)), dim3(kTopkThreads), 0,
                      c->stream, c->d_sel.as<ag2_hypothesis>(), &st->n_sel, (int)cap_img, c->p.num_selected,
-                     (int)f->k_cap, d_rec, d_fo, st, gp);
+                     (int)f->k_cap, d_rec, d_fo, st, gp,
+                     f->raw ? c->d_preframe.as<PreFrame>() : (const PreFrame*)nullptr);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
 
+// what one frame call asks for (either entry point)
+struct FrameIn {
+  const void* xyz = nullptr;
+  int on_device = 0;
+  size_t n = 0, stride = 12;
+  bool raw = false;  // ag2_detect_frame_raw
+  int filter_ws = 1;
+  double voxel_size = 0.003;
+  size_t num_samples = 0;
+  uint64_t sample_seed = 0;
+  const int32_t* sample_idx = nullptr;  // ag2_detect_frame
+  size_t s = 0;
+  uint64_t seed = 0;
+  int do_prune = 1;
+};
+
 // the step-by-step path for one frame (also what sizes the buffers and teaches the shapes)
-int frame_stepwise(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride, const int32_t* sample_idx, size_t s,
-                   uint64_t seed, int do_prune, ag2_hypothesis* selected, size_t cap, size_t* n_selected,
-                   size_t* n_scored) {
+int frame_stepwise(ag2_ctx* c, const void* d_xyz, const FrameIn& in, ag2_hypothesis* selected, size_t cap,
+                   size_t* n_selected, size_t* n_scored, size_t* n_voxels, size_t* s_used) {
   c->fm_on = false;
-  int rc = ag2_set_cloud_device(c, d_xyz, n, stride);
+  c->fm_grid_ready = false;
+  int rc = 0;
+  size_t s = in.s;
+  if (in.raw) {
+    size_t m = 0, k = 0;
+    rc = ag2_preprocess_cloud_device(c, d_xyz, in.n, in.stride, in.filter_ws, 1, in.voxel_size, &m);
+    if (!rc) rc = ag2_subsample_uniformly(c, in.num_samples, in.sample_seed, nullptr, 0, &k);  // indices stay on the device
+    if (n_voxels) *n_voxels = m;
+    s = k;
+  } else {
+    rc = ag2_set_cloud_device(c, d_xyz, in.n, in.stride);
+  }
+  if (s_used) *s_used = s;
   if (!rc) rc = ag2_compute_normals(c);
-  if (!rc) rc = ag2_detect(c, sample_idx, nullptr, s, 0, seed, do_prune, selected, cap, n_selected, nullptr, 0, n_scored);
+  if (!rc)
+    rc = ag2_detect(c, in.raw ? nullptr : in.sample_idx, nullptr, s, 0, in.seed, in.do_prune, selected, cap, n_selected,
+                    nullptr, 0, n_scored);
   return rc;
+}
+
+// clears the frame-mode switches of the context on every way out of the fixed-shape block
+struct FrameModeGuard {
+  ag2_ctx* c;
+  explicit FrameModeGuard(ag2_ctx* ctx) : c(ctx) {}
+  ~FrameModeGuard() {
+    c->fm_on = false;
+    c->fm_grid_ready = false;
+  }
+};
+
+int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, size_t cap, size_t* n_selected,
+                      size_t* n_scored, size_t* n_voxels) {
+  if (c->p.n_cams != 1) return set_err(c, AG2_ERR_ARG, "frames are single-camera clouds");
+  if (in.stride < 12 || in.stride % 4 != 0) return set_err(c, AG2_ERR_ARG, "bad stride");
+  if (in.n > (size_t)1 << 30) return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 points");
+  if (in.raw && !((float)in.voxel_size > 0.f)) return set_err(c, AG2_ERR_ARG, "voxel_size must be positive");
+  if (!c->net.loaded) return set_err(c, AG2_ERR_STATE, "lenet weights not loaded");
+  if (!c->fm) c->fm = new ag2_frame_state();
+  ag2_frame_state* f = c->fm;
+  const int R = c->p.num_orientations;
+  const size_t n = in.n;
+  // a cloud in host memory goes through a device staging buffer first
+  const void* d_xyz = in.xyz;
+  if (!in.on_device && n) {
+    AG2_HIP(c, f->d_raw.reserve(n * in.stride));
+    AG2_HIP(c, hipMemcpyAsync(f->d_raw.p, in.xyz, n * in.stride, hipMemcpyHostToDevice, c->stream));
+    d_xyz = f->d_raw.p;
+  }
+  f->info.frames++;
+  if (n_voxels) *n_voxels = in.raw ? 0 : n;
+  const size_t s_req = in.raw ? in.num_samples : in.s;
+  // Frames the captured sequence cannot take: clustering inside detect (k_cluster is not part of
+  // it), more than 65536 table slots, an empty frame, the f32-input LeNet kernels.
+  const bool unsupported = c->min_inliers > 0 || s_req * (size_t)R > 65536 || n == 0 || s_req == 0 || !c->net.use_x3;
+  if (f->shapes_known && f->raw != in.raw) {  // the stream changed its entry point: learn the shapes again
+    f->shapes_known = false;
+    drop_graph(f);
+  }
+  bool stepwise = unsupported || !f->shapes_known;
+  if (!stepwise) {
+    if (in.raw)
+      stepwise = n > f->fs.raw_max || in.num_samples != c->fm_s_max || (float)in.voxel_size != f->fs.cell ||
+                 (in.filter_ws ? 1 : 0) != f->fs.filter_workspace;
+    else
+      stepwise = n > c->fm_n_max || in.s > c->fm_s_max;
+  }
+  if (!stepwise) {
+    // ---- the frame at fixed shapes: pack + extent in front, then the sequence (graph or plain) ----
+    FrameModeGuard guard(c);
+    c->fm_on = true;
+    c->fm_grid_ready = in.raw;
+    int rc = frame_pin_reserve(c, f);
+    if (rc) return rc;
+    FrameArgs* fa = (FrameArgs*)f->h_pin;
+    fa->seed = in.seed;
+    fa->slot_base = 0;
+    fa->sample_seed = in.sample_seed;
+    if (!in.raw) {
+      int32_t* hidx = (int32_t*)(f->h_pin + f->off_idx);
+      memcpy(hidx, in.sample_idx, in.s * 4);
+      for (size_t i = in.s; i < c->fm_s_max; i++) hidx[i] = -1;
+    }
+    AG2_HIP(c, c->d_xyz_in.reserve(c->fm_n_max * 16));
+    AG2_HIP(c, c->d_bounds.reserve((size_t)128 * 8 * 4));
+    AG2_HIP(c, c->d_griddesc.reserve(sizeof(GridDesc)));
+    if (in.raw) rc = front_pack_raw(c, d_xyz, n, in.stride, f->fs);
+    else rc = pack_device_xyz(c, d_xyz, n, in.stride, c->d_xyz_in.as<float4>(), /*with_bounds=*/true, c->fm_n_max);
+    if (rc) return rc;
+    const bool replay = f->use_graph && f->graph_valid && f->do_prune == in.do_prune &&
+                        f->sig_at_capture == frame_signature(c, f);
+    if (replay) {
+      AG2_HIP(c, hipGraphLaunch(f->exec, c->stream));
+      f->info.graph_replays++;
+    } else {
+      drop_graph(f);
+      const int lvl = c->stage_timing;
+      c->stage_timing = 0;  // (events are not part of the sequence)
+      rc = enqueue_frame(c, f, in.do_prune);
+      c->stage_timing = lvl;
+      if (rc) return rc;
+      f->info.plain_runs++;
+    }
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+    const FrameOut* fo = (const FrameOut*)(f->h_pin + f->off_out);
+    const unsigned flags = fo->st.err_flags;
+    const bool bad = (flags & (1u | 2u | 8u)) != 0 || fo->g.ncells < 0 || fo->topk_overflow != 0 ||
+                     (size_t)fo->st.n_list > std::min(f->cap_img, c->fm_s_max * (size_t)R) ||
+                     (int)fo->st.max_p > render_capacity_for(f->cap_p) || (in.raw && fo->pre.flags != 0u);
+    if (bad) {
+      if (fo->g.ncells == -2)
+        return set_err(c, AG2_ERR_ARG, "a point lies below the grid origin given to ag2_set_grid_origin");
+      f->info.fallbacks++;
+      f->shapes_known = false;  // learn the shapes again from the step-by-step run below
+      stepwise = true;
+    } else {
+      // capture for the frames to come (right after the run that gave every buffer its size)
+      if (!replay && f->use_graph) {
+        if (c->stream == nullptr) {
+          f->info.capture_refused++;  // the legacy default stream cannot be captured
+        } else {
+          const unsigned long long sig0 = frame_signature(c, f);
+          const int lvl = c->stage_timing;
+          c->stage_timing = 0;
+          hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+          int rc2 = (e == hipSuccess) ? enqueue_frame(c, f, in.do_prune) : AG2_ERR_HIP;
+          hipGraph_t g = nullptr;
+          if (e == hipSuccess) e = hipStreamEndCapture(c->stream, &g);
+          c->stage_timing = lvl;
+          if (e == hipSuccess && rc2 == 0 && g && sig0 == frame_signature(c, f) &&
+              hipGraphInstantiate(&f->exec, g, nullptr, nullptr, 0) == hipSuccess) {
+            f->graph = g;
+            f->graph_valid = true;
+            f->sig_at_capture = sig0;
+            f->do_prune = in.do_prune;
+            f->info.captures++;
+          } else {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            f->info.capture_failed++;
+          }
+        }
+      }
+      // results
+      const size_t n_cloud = in.raw ? (size_t)fo->pre.n_vox : n;
+      const size_t s = in.raw ? in.num_samples : in.s;
+      c->n = n_cloud;
+      c->n_valid = (size_t)fo->g.n_valid;
+      c->grid = fo->g;
+      c->min_z = fo->g.min_z;
+      c->has_cloud = c->has_normals = true;
+      c->normals_pending = c->grid_pending = false;
+      c->bounds_known = false;
+      c->s = s;
+      c->slot_base = 0;
+      c->n_resident_samples = in.raw ? s : 0;
+      c->n_img = fo->st.n_list;
+      c->max_p = (int)fo->st.max_p;
+      memset(&c->cnt, 0, sizeof(c->cnt));
+      c->cnt.n_points = (int64_t)n_cloud;
+      c->cnt.n_valid_points = fo->g.n_valid;
+      c->cnt.n_samples = (int64_t)s;
+      c->cnt.n_frames = fo->st.n_frames;
+      c->cnt.n_hypotheses = fo->st.n_hyp;
+      c->cnt.n_pruned = fo->st.n_list;
+      c->cnt.n_scored = fo->st.n_list;
+      c->cnt.sum_k1 = (int64_t)fo->st.sum_k1;
+      c->cnt.sum_k2 = (int64_t)fo->st.sum_k2;
+      c->cnt.sum_kcrop = (int64_t)fo->st.sum_kcrop;
+      c->cnt.sum_p = (int64_t)fo->st.sum_p;
+      c->cnt.n_overflow_samples = fo->st.n_overflow;
+      c->cnt.list_points = (int64_t)fo->st.list_top;
+      const size_t k = fo->n_out;
+      c->cnt.n_selected = (int64_t)k;
+      *n_selected = k;
+      if (n_scored) *n_scored = fo->st.n_list;
+      if (n_voxels) *n_voxels = n_cloud;
+      if (k > cap) return set_err(c, AG2_ERR_CAPACITY, "detect_frame: output capacity too small");
+      if (k) memcpy(selected, f->h_pin + f->off_rec, k * sizeof(ag2_hypothesis));
+      return 0;
+    }
+  }
+  // ---- step-by-step path: the first frame, frames that outgrow the shapes, unsupported settings ----
+  f->info.stepwise_runs++;
+  size_t n_vox = n, s_used = in.s;
+  const int rc = frame_stepwise(c, d_xyz, in, selected, cap, n_selected, n_scored, &n_vox, &s_used);
+  if (n_voxels) *n_voxels = n_vox;
+  if (rc) return rc;
+  // a raw frame with no more voxels than num_samples takes every point as a sample (grasp_detector.cpp:322-330):
+  // that is not what the fixed-shape sub-sampling does, such frames stay on this path
+  if (!unsupported && !(in.raw && s_used != in.num_samples)) {
+    // shapes for the frames to come: this frame's, with room for the cloud to move and grow
+    if (f->raw != in.raw) {
+      c->fm_n_max = c->fm_s_max = 0;
+      f->fs = FrontShapes{};
+    }
+    f->raw = in.raw;
+    const size_t n_cloud = in.raw ? n_vox : n;
+    c->fm_n_max = std::max(c->fm_n_max, n_cloud + n_cloud / 8 + 1024);
+    c->fm_s_max = in.raw ? s_used : std::max(c->fm_s_max, s_used);
+    long long cells = 1;
+    for (int a = 0; a < 3; a++) cells *= (long long)(c->grid.dims[a] + 8);
+    cells = std::min<long long>(cells + cells / 2, 1ll << 30);
+    c->fm_cap_cells = std::max<size_t>(c->fm_cap_cells, (size_t)cells);
+    if (in.raw) {
+      f->fs.raw_max = std::max(f->fs.raw_max, n + n / 8 + 1024);
+      // bitmap of the voxel lattice: this frame's with 16 voxels (48 mm at 3 mm) of room per axis, but
+      // never more than the workspace can hold when it filters
+      double words = 1.0;
+      for (int a = 0; a < 3; a++) words *= (double)(c->last_vox_dims[a] + 16);
+      words = words / 32.0 + 2.0;
+      if (in.filter_ws) {
+        double wsw = 1.0;
+        for (int a = 0; a < 3; a++)
+          wsw *= floor((c->p.workspace[2 * a + 1] - c->p.workspace[2 * a]) / (double)(float)in.voxel_size) + 2.0;
+        if (wsw >= 1.0) words = std::min(words, wsw / 32.0 + 2.0);
+      }
+      f->fs.cap_words = std::max(f->fs.cap_words, (size_t)std::min(words, 1.0e9));
+      f->fs.n_max = c->fm_n_max;
+      f->fs.num_samples = s_used;
+      f->fs.cand_cap = cand_capacity(s_used);
+      f->fs.cell = (float)in.voxel_size;
+      f->fs.filter_workspace = in.filter_ws ? 1 : 0;
+    }
+    // images: twice what this frame scored, in whole batches of 256 (BASELINE.json configs[4]:
+    // batch_size 256), never below the shapes already in force
+    const size_t want_img = (((size_t)c->n_img * 2 + 512) + 255) / 256 * 256;
+    f->cap_p = std::max(f->cap_p, 2 * c->max_p);  // which renderers the sequence launches
+    f->cap_img = std::min(std::max(f->cap_img, want_img), c->fm_s_max * (size_t)R);
+    f->k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, f->cap_img) : f->cap_img;
+    f->shapes_known = c->fm_s_max * (size_t)R <= 65536;
+  }
+  return 0;
 }
 
 }  // namespace
@@ -291,6 +565,8 @@ int ag2_stream_configure(ag2_ctx* c, size_t max_points, size_t max_samples, int 
   c->fm_cap_cells = 0;
   f->cap_img = f->k_cap = 0;
   f->cap_p = 0;
+  f->raw = false;
+  f->fs = FrontShapes{};
   memset(&f->info, 0, sizeof(f->info));
   return 0;
 }
@@ -300,157 +576,37 @@ int ag2_detect_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, s
                      ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored) {
   if (!c || !n_selected || (s && !sample_idx) || (n && !xyz)) return AG2_ERR_ARG;
   (void)hipSetDevice(c->device);
-  if (c->p.n_cams != 1) return set_err(c, AG2_ERR_ARG, "frames are single-camera clouds");
-  if (stride_bytes < 12 || stride_bytes % 4 != 0) return set_err(c, AG2_ERR_ARG, "bad stride");
-  if (n > (size_t)1 << 30) return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 points");
-  if (!c->net.loaded) return set_err(c, AG2_ERR_STATE, "lenet weights not loaded");
-  if (!c->fm) c->fm = new ag2_frame_state();
-  ag2_frame_state* f = c->fm;
-  const int R = c->p.num_orientations;
-  // a cloud in host memory goes through a device staging buffer first
-  const void* d_xyz = xyz;
-  if (!xyz_on_device && n) {
-    AG2_HIP(c, f->d_raw.reserve(n * stride_bytes));
-    AG2_HIP(c, hipMemcpyAsync(f->d_raw.p, xyz, n * stride_bytes, hipMemcpyHostToDevice, c->stream));
-    d_xyz = f->d_raw.p;
-  }
-  f->info.frames++;
-  // Frames the captured sequence cannot take: clustering inside detect (k_cluster is not part of
-  // it), more than 65536 table slots, an empty frame, the f32-input LeNet kernels.
-  const bool unsupported = c->min_inliers > 0 || s * (size_t)R > 65536 || n == 0 || s == 0 || !c->net.use_x3;
-  bool stepwise = unsupported || !f->shapes_known || n > c->fm_n_max || s > c->fm_s_max;
-  if (!stepwise) {
-    // ---- the frame at fixed shapes: pack + extent in front, then the sequence (graph or plain) ----
-    c->fm_on = true;
-    int rc = frame_pin_reserve(c, f);
-    if (rc) return rc;
-    FrameArgs* fa = (FrameArgs*)f->h_pin;
-    fa->seed = seed;
-    fa->slot_base = 0;
-    int32_t* hidx = (int32_t*)(f->h_pin + f->off_idx);
-    memcpy(hidx, sample_idx, s * 4);
-    for (size_t i = s; i < c->fm_s_max; i++) hidx[i] = -1;
-    AG2_HIP(c, c->d_xyz_in.reserve(c->fm_n_max * 16));
-    AG2_HIP(c, c->d_bounds.reserve((size_t)128 * 8 * 4));
-    AG2_HIP(c, c->d_griddesc.reserve(sizeof(GridDesc)));
-    rc = pack_device_xyz(c, d_xyz, n, stride_bytes, c->d_xyz_in.as<float4>(), /*with_bounds=*/true, c->fm_n_max);
-    if (rc) return rc;
-    const bool replay = f->use_graph && f->graph_valid && f->do_prune == do_prune &&
-                        f->sig_at_capture == frame_signature(c, f);
-    if (replay) {
-      AG2_HIP(c, hipGraphLaunch(f->exec, c->stream));
-      f->info.graph_replays++;
-    } else {
-      drop_graph(f);
-      const int lvl = c->stage_timing;
-      c->stage_timing = 0;  // (events are not part of the sequence)
-      rc = enqueue_frame(c, f, do_prune);
-      c->stage_timing = lvl;
-      if (rc) {
-        c->fm_on = false;
-        return rc;
-      }
-      f->info.plain_runs++;
-    }
-    AG2_HIP(c, hipStreamSynchronize(c->stream));
-    const FrameOut* fo = (const FrameOut*)(f->h_pin + f->off_out);
-    const unsigned flags = fo->st.err_flags;
-    const bool bad = (flags & (1u | 2u | 8u)) != 0 || fo->g.ncells < 0 || fo->topk_overflow != 0 ||
-                     (size_t)fo->st.n_list > std::min(f->cap_img, c->fm_s_max * (size_t)R) ||
-                     (int)fo->st.max_p > render_capacity_for(f->cap_p);
-    if (bad) {
-      if (fo->g.ncells == -2) {
-        c->fm_on = false;
-        return set_err(c, AG2_ERR_ARG, "a point lies below the grid origin given to ag2_set_grid_origin");
-      }
-      f->info.fallbacks++;
-      f->shapes_known = false;  // learn the shapes again from the step-by-step run below
-      stepwise = true;
-    } else {
-      // capture for the frames to come (right after the run that gave every buffer its size)
-      if (!replay && f->use_graph) {
-        if (c->stream == nullptr) {
-          f->info.capture_refused++;  // the legacy default stream cannot be captured
-        } else {
-          const unsigned long long sig0 = frame_signature(c, f);
-          const int lvl = c->stage_timing;
-          c->stage_timing = 0;
-          hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
-          int rc2 = (e == hipSuccess) ? enqueue_frame(c, f, do_prune) : AG2_ERR_HIP;
-          hipGraph_t g = nullptr;
-          if (e == hipSuccess) e = hipStreamEndCapture(c->stream, &g);
-          c->stage_timing = lvl;
-          if (e == hipSuccess && rc2 == 0 && g && sig0 == frame_signature(c, f) &&
-              hipGraphInstantiate(&f->exec, g, nullptr, nullptr, 0) == hipSuccess) {
-            f->graph = g;
-            f->graph_valid = true;
-            f->sig_at_capture = sig0;
-            f->do_prune = do_prune;
-            f->info.captures++;
-          } else {
-            if (g) (void)hipGraphDestroy(g);
-            (void)hipGetLastError();
-            f->info.capture_failed++;
-          }
-        }
-      }
-      // results
-      c->n = n;
-      c->n_valid = (size_t)fo->g.n_valid;
-      c->grid = fo->g;
-      c->min_z = fo->g.min_z;
-      c->has_cloud = c->has_normals = true;
-      c->normals_pending = c->grid_pending = false;
-      c->s = s;
-      c->slot_base = 0;
-      c->n_img = fo->st.n_list;
-      c->max_p = (int)fo->st.max_p;
-      memset(&c->cnt, 0, sizeof(c->cnt));
-      c->cnt.n_points = (int64_t)n;
-      c->cnt.n_valid_points = fo->g.n_valid;
-      c->cnt.n_samples = (int64_t)s;
-      c->cnt.n_frames = fo->st.n_frames;
-      c->cnt.n_hypotheses = fo->st.n_hyp;
-      c->cnt.n_pruned = fo->st.n_list;
-      c->cnt.n_scored = fo->st.n_list;
-      c->cnt.sum_k1 = (int64_t)fo->st.sum_k1;
-      c->cnt.sum_k2 = (int64_t)fo->st.sum_k2;
-      c->cnt.sum_kcrop = (int64_t)fo->st.sum_kcrop;
-      c->cnt.sum_p = (int64_t)fo->st.sum_p;
-      c->cnt.n_overflow_samples = fo->st.n_overflow;
-      c->cnt.list_points = (int64_t)fo->st.list_top;
-      const size_t k = fo->n_out;
-      c->cnt.n_selected = (int64_t)k;
-      *n_selected = k;
-      if (n_scored) *n_scored = fo->st.n_list;
-      c->fm_on = false;
-      if (k > cap) return set_err(c, AG2_ERR_CAPACITY, "detect_frame: output capacity too small");
-      if (k) memcpy(selected, f->h_pin + f->off_rec, k * sizeof(ag2_hypothesis));
-      return 0;
-    }
-  }
-  // ---- step-by-step path: the first frame, frames that outgrow the shapes, unsupported settings ----
-  f->info.stepwise_runs++;
-  const int rc = frame_stepwise(c, d_xyz, n, stride_bytes, sample_idx, s, seed, do_prune, selected, cap,
-                                n_selected, n_scored);
-  if (rc) return rc;
-  if (!unsupported) {
-    // shapes for the frames to come: this frame's, with room for the cloud to move and grow
-    c->fm_n_max = std::max(c->fm_n_max, n + n / 8 + 1024);
-    c->fm_s_max = std::max(c->fm_s_max, s);
-    long long cells = 1;
-    for (int a = 0; a < 3; a++) cells *= (long long)(c->grid.dims[a] + 8);
-    cells = std::min<long long>(cells + cells / 2, 1ll << 30);
-    c->fm_cap_cells = std::max<size_t>(c->fm_cap_cells, (size_t)cells);
-    // images: twice what this frame scored, in whole batches of 256 (BASELINE.json configs[4]:
-    // batch_size 256), never below the shapes already in force
-    const size_t want_img = (((size_t)c->n_img * 2 + 512) + 255) / 256 * 256;
-    f->cap_p = std::max(f->cap_p, 2 * c->max_p);  // which renderers the sequence launches
-    f->cap_img = std::min(std::max(f->cap_img, want_img), c->fm_s_max * (size_t)R);
-    f->k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, f->cap_img) : f->cap_img;
-    f->shapes_known = c->fm_s_max * (size_t)R <= 65536;
-  }
-  return 0;
+  FrameIn in;
+  in.xyz = xyz;
+  in.on_device = xyz_on_device;
+  in.n = n;
+  in.stride = stride_bytes;
+  in.sample_idx = sample_idx;
+  in.s = s;
+  in.seed = seed;
+  in.do_prune = do_prune;
+  return detect_frame_impl(c, in, selected, cap, n_selected, n_scored, nullptr);
+}
+
+int ag2_detect_frame_raw(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                         int filter_workspace, double voxel_size, size_t num_samples, uint64_t sample_seed,
+                         uint64_t seed, int do_prune, ag2_hypothesis* selected, size_t cap, size_t* n_selected,
+                         size_t* n_scored, size_t* n_voxels) {
+  if (!c || !n_selected || (n && !xyz)) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  FrameIn in;
+  in.xyz = xyz;
+  in.on_device = xyz_on_device;
+  in.n = n;
+  in.stride = stride_bytes;
+  in.raw = true;
+  in.filter_ws = filter_workspace ? 1 : 0;
+  in.voxel_size = voxel_size;
+  in.num_samples = num_samples;
+  in.sample_seed = sample_seed;
+  in.seed = seed;
+  in.do_prune = do_prune;
+  return detect_frame_impl(c, in, selected, cap, n_selected, n_scored, n_voxels);
 }
 
 int ag2_get_frame_info(ag2_ctx* c, ag2_frame_info* out) {

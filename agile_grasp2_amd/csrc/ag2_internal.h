@@ -80,6 +80,42 @@ struct PreStats {
   unsigned int pad;
 };
 
+// Device-side record of one pass of the fixed-shape GPU front end (k_preprocess.hip: workspace filter,
+// voxel grid and uniform sub-sampling without a host round trip).  Written by its kernels, read by the
+// host together with the results.
+struct PreFrame {
+  float mn[3];                 // minimum of the points that pass the filter = origin of the voxel lattice
+  float cell;
+  int dims[3];
+  int words;                   // bitmap words the lattice needs (0: nothing to mark)
+  unsigned n_keep, n_vox, n_cand;
+  unsigned flags;              // kPre* below; non-zero: the caller repeats the step on the general path
+  unsigned long long thr;      // sub-sampling: hashes up to thr are candidates
+  unsigned long long kth_h;    // the num_samples-th smallest key (hash, index)
+  unsigned kth_i, pad;
+};
+constexpr unsigned kPreGridTooLarge = 1u;   // the voxel lattice needs more bitmap words than reserved (or is too fine)
+constexpr unsigned kPreTooManyVoxels = 2u;  // more voxels than the cloud buffer holds
+constexpr unsigned kPreCandOverflow = 4u;   // more sub-sampling candidates than the candidate list holds
+constexpr unsigned kPreCandShort = 8u;      // fewer candidates than samples (the hash filter missed: p < 1e-12)
+constexpr unsigned kPreAllPoints = 16u;     // no more voxels than num_samples: every point is a sample (general path)
+
+// Uniform sub-sampling = the num_samples smallest of the keys (draw_u64(seed, stream, i), i).  The keys are
+// uniform 64-bit hashes, so the num_samples-th smallest is close to num_samples / n x 2^64: hashes up to a
+// threshold eight standard deviations above that are collected as candidates (a few per cent more than
+// num_samples) and the exact selection runs over the candidates only.
+__host__ __device__ inline double cand_mean(unsigned k) { return (double)k + 8.0 * __builtin_sqrt((double)k) + 16.0; }
+__host__ __device__ inline unsigned long long cand_threshold(unsigned k, unsigned n) {
+  if (n == 0u || k == 0u) return 0ull;
+  const double p = cand_mean(k) / (double)n;
+  if (p >= 1.0) return ~0ull;
+  return (unsigned long long)(p * 18446744073709551616.0);
+}
+inline size_t cand_capacity(size_t k) {
+  const double mu = cand_mean((unsigned)k);
+  return (size_t)(mu + 8.0 * __builtin_sqrt(mu) + 64.0);
+}
+
 struct LeNetDev {
   bool loaded = false;
   DevBuf w1p, b1, w2p, b2, w3p, b3, w4, b4;  // packed for the MFMA lane layout (k_lenet.hip)
@@ -132,7 +168,10 @@ struct ag2_ctx {
   ag2::DevBuf d_prestats;  // PreStats
   ag2::DevBuf d_hist;      // 65536-bin digit histogram of the sub-sampling radix select
   ag2::DevBuf d_samples;   // int32 sample indices left resident by ag2_subsample_uniformly
+  ag2::DevBuf d_preframe;  // PreFrame
+  ag2::DevBuf d_cand;      // sub-sampling candidates: uint64 hash[cap] then uint32 index[cap]
   size_t n_resident_samples = 0;
+  int last_vox_dims[3] = {0, 0, 0};  // voxel lattice of the last ag2_preprocess_cloud* call (shapes of a raw stream)
   bool origin_set = false;    // ag2_set_grid_origin: grid origin (and cloud minimum) of the whole cloud
   float origin[3] = {0, 0, 0};
   bool bounds_known = false;  // set by the front end for the next grid build: extent of d_xyz_in
@@ -201,7 +240,8 @@ struct ag2_ctx {
   size_t fm_n_max = 0;       // points per frame (the cloud is padded with non-finite points up to it)
   size_t fm_s_max = 0;       // samples per frame (the index list is padded with -1 up to it)
   size_t fm_cap_cells = 0;   // grid cells
-  ag2::DevBuf d_griddesc;    // GridDesc written by k_grid_desc
+  ag2::DevBuf d_griddesc;    // GridDesc written by k_cell_count (from the extent partials) or by the front end
+  bool fm_grid_ready = false;  // frame mode behind the GPU front end: d_griddesc is written by k_vox_emit_frame
   const ag2::FrameArgs* fm_args_dev = nullptr;  // device view of the page-locked per-frame scalars
   struct ag2_frame_state* fm = nullptr;         // owned by ag2_frame.hip
 
@@ -265,6 +305,19 @@ int launch_grid_frame(ag2_ctx* c, unsigned* cell, unsigned* zeroed_ctl);
 void frame_release(ag2_ctx* c);
 size_t scan_ctl_words(int n);
 int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n, unsigned* zeroed_ctl = nullptr);
+int scan_popc_u32(ag2_ctx* c, const unsigned* bitmap, int words, unsigned* rank, unsigned* zeroed_ctl = nullptr);
+// k_preprocess.hip: the fixed-shape front end of a frame (ag2_frame.hip)
+struct FrontShapes {
+  size_t raw_max;     // raw points per frame (the raw cloud is padded with non-finite points up to it)
+  size_t cap_words;   // bitmap words of the voxel lattice
+  size_t n_max;       // voxels (= points of the processed cloud; padded with non-finite points up to it)
+  size_t num_samples;
+  size_t cand_cap;
+  float cell;
+  int filter_workspace;
+};
+int front_pack_raw(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, const FrontShapes& fs);
+int enqueue_front_frame(ag2_ctx* c, const FrontShapes& fs);
 // k_normals.hip
 int launch_normals(ag2_ctx* c);
 // k_sweep.hip
@@ -278,10 +331,11 @@ struct FrameOut {
   GridDesc g;
   unsigned n_out;  // records that follow (top-k)
   unsigned topk_overflow;
+  PreFrame pre;    // ag2_detect_frame_raw: what the front end of the frame found (voxels, flags)
 };
 // ag2_frame.hip: top num_selected of d_recs[0 .. min(*d_n, cap)) by (score desc, position asc) -> d_out, *d_fo
 int launch_topk(ag2_ctx* c, const ag2_hypothesis* d_recs, const unsigned* d_n, size_t cap, size_t k_cap,
-                ag2_hypothesis* d_out, FrameOut* d_fo, const GridDesc* gp);
+                ag2_hypothesis* d_out, FrameOut* d_fo, const GridDesc* gp, const PreFrame* pfp = nullptr);
 int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool run_cleared = false);
 int launch_hyp_stats(ag2_ctx* c, size_t n_slots);  // k_sweep_orient.hip: n_hyp, sum_p, max_p from the slot table
 // k_select.hip

@@ -457,17 +457,21 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   // 4b. grasp clusters (grasp_detector.cpp:228-236), only when HandleSearch::setMinInliers > 0
   const void* d_res = c->d_sel.p;
   const unsigned* d_nres = d_nsel;
-  if (c->min_inliers > 0) {
+  // What ag2_export_selected_compact_device puts on the wire is the list BEFORE the clustering: clusters
+  // count inliers over the hands of all ranks, so a multi-GPU job clusters in the merge
+  // (ag2_merge_selected_device), on the gathered list -- and a rank that only feeds the merge skips its own.
+  c->d_last_sel = c->d_sel.p;
+  c->d_last_nsel = d_nsel;
+  const bool merge_follows = !selected && cap == 0 && !(scored_all && cap_all);
+  if (c->min_inliers > 0 && !merge_follows) {
     unsigned* d_nclu = &c->d_stats.as<DevStats>()->n_clu;
     rc = cluster_async(c, c->d_sel.as<ag2_hypothesis>(), n_img, d_nsel, c->min_inliers, d_nclu);
     if (rc) return rc;
     d_res = c->d_cluster.p;
     d_nres = d_nclu;
   }
-  c->d_last_sel = d_res;    // for ag2_export_selected_compact_device
-  c->d_last_nsel = d_nres;
   AG2_HIP(c, stage_event(c, 7));
-  if (!selected && cap == 0 && !(scored_all && cap_all)) {
+  if (merge_follows) {
     // Multi-GPU use: the caller exports the selected list (ag2_export_selected_compact_device) and the
     // top-k happens in ag2_merge_selected_device over all ranks' lists -- no local read-back, no local
     // top-k, and this call returns with the tail of the pipeline still queued on the stream.

@@ -5,6 +5,7 @@
 // ties broken by original index, so a run of x-adjacent cells is one contiguous, coalesced span of
 // float4 points and "ascending sorted position" is the canonical neighbour order the oracle uses.
 #include "ag2_internal.h"
+#include "k_grid_common.h"
 
 namespace ag2 {
 
@@ -95,74 +96,13 @@ __global__ void __launch_bounds__(256) k_bounds(const char* __restrict__ src, si
   }
 }
 
-// Frame mode: the grid description is derived on the device from the extent partials of k_bounds (one
-// 32-B record per workgroup), the way build_grid derives it on the host -- same float expressions, so
-// the same cells.  ncells <= 0 tells every consumer "no grid": -1 more cells than the captured table
-// holds, -2 a point below the origin given to ag2_set_grid_origin, 0 no finite point.  Executed by
-// the first wave of EVERY workgroup of k_cell_count (4 KB of L2-resident partials: cheaper than a
-// launch of its own); workgroup 0 leaves the result in memory for the kernels that follow.
-struct GridFromParts {
-  const int* part;  // nullptr: not frame mode
-  int nb;
-  float inv;
-  int origin_set;
-  float org[3];
-  int cap_cells;
-  GridDesc* out;
-};
-__device__ __forceinline__ GridDesc grid_from_partials(const GridFromParts& f) {
-  const int lane = lane_id();
-  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-  int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-  int cnt = 0;
-  for (int b = lane; b < f.nb; b += 64) {
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      mn[a] = min(mn[a], f.part[b * 8 + a]);
-      mx[a] = max(mx[a], f.part[b * 8 + 3 + a]);
-    }
-    cnt += f.part[b * 8 + 6];
-  }
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
-      mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
-    }
-  }
-  cnt = wave_sum_i(cnt);
-  GridDesc g{};
-  g.inv = f.inv;
-  if (cnt > 0) {
-    long long ncells = 1;
-    bool below = false;
-    for (int a = 0; a < 3; a++) {
-      const float bmin = ord2f(mn[a]), bmax = ord2f(mx[a]);
-      if (f.origin_set && bmin < f.org[a]) below = true;
-      g.o[a] = f.origin_set ? f.org[a] : bmin;
-      g.dims[a] = (int)__builtin_floorf((bmax - g.o[a]) * g.inv) + 1;
-      ncells *= g.dims[a];
-      if (ncells > (1ll << 30)) ncells = (1ll << 30) + 1;
-    }
-    g.min_z = g.o[2];  // pcl::getMinMax3D of the (whole) cloud, grasp_detector.cpp:152-153
-    g.n_valid = cnt;
-    g.ncells = below ? -2 : (ncells > (long long)f.cap_cells ? -1 : (int)ncells);
-    if (g.ncells <= 0) {
-      g.n_valid = 0;
-      g.dims[0] = g.dims[1] = g.dims[2] = 0;
-    }
-  }
-  return g;
-}
-
 // key[i] = (cell key or -1, arrival rank inside the cell): the rank the counting atomic hands out
 // places the point in the scatter below without a second round of atomics.
 __global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ xyz, int n, GridDesc g_arg,
                                                     GridFromParts fp, int2* __restrict__ key,
                                                     unsigned* __restrict__ cell) {
   __shared__ GridDesc g_sh;
-  if (fp.part) {  // frame mode (uniform)
+  if (fp.part) {  // frame mode (uniform): the description from the extent partials of k_bounds
     if (wave_id() == 0) {
       const GridDesc gd = grid_from_partials(fp);
       if (lane_id() == 0) {
@@ -172,7 +112,8 @@ __global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ x
     }
     __syncthreads();
   }
-  const GridDesc g = fp.part ? g_sh : g_arg;
+  // (fp.ready: frame mode behind the GPU front end, which left the description in memory)
+  const GridDesc g = fp.part ? g_sh : (fp.ready ? *fp.ready : g_arg);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float4 p = (i < n) ? xyz[i] : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
   int k = -1, r = 0;
@@ -217,8 +158,13 @@ __global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ x
 // (state << 32 | value; state 1 = tile total, 2 = inclusive prefix), read and written with relaxed
 // device-scope atomics: state and value travel together, so no ordering against other memory is
 // needed.  ctl[0] = ticket, ctl[2 + 2 * t ...] = record of tile t; all zero before the launch.
+// POPC: the input is the population count of src[i] (i < n - 1; element n - 1 counts as zero, so
+// data[n - 1] receives the total) -- the voxel front end's rank-per-bitmap-word scan, without a pass that
+// writes the counts first.
+template <bool POPC>
 __global__ void __launch_bounds__(256) k_scan_chained(unsigned* __restrict__ data, int n,
-                                                      unsigned* __restrict__ ctl) {
+                                                      unsigned* __restrict__ ctl,
+                                                      const unsigned* __restrict__ src) {
   __shared__ unsigned wsum[4];
   __shared__ unsigned s_tile, s_prefix;
   unsigned long long* rec = reinterpret_cast<unsigned long long*>(ctl + 2);
@@ -230,7 +176,8 @@ __global__ void __launch_bounds__(256) k_scan_chained(unsigned* __restrict__ dat
   unsigned tot = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    v[k] = (base + k < n) ? data[base + k] : 0u;
+    if (POPC) v[k] = (base + k < n - 1) ? (unsigned)__popc(src[base + k]) : 0u;
+    else v[k] = (base + k < n) ? data[base + k] : 0u;
     tot += v[k];
   }
   unsigned inc = tot;
@@ -300,7 +247,23 @@ int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n, unsigned* zeroed_ctl) {
     AG2_HIP(c, hipMemsetAsync(c->d_scan.p, 0, words * sizeof(unsigned), c->stream));
     zeroed_ctl = c->d_scan.as<unsigned>();
   }
-  hipLaunchKernelGGL(k_scan_chained, dim3(nb), dim3(256), 0, c->stream, d, n, zeroed_ctl);
+  hipLaunchKernelGGL(k_scan_chained<false>, dim3(nb), dim3(256), 0, c->stream, d, n, zeroed_ctl,
+                     (const unsigned*)nullptr);
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+// rank[w] = number of set bits in bitmap[0 .. w), w = 0 .. words (rank[words] = all of them)
+int scan_popc_u32(ag2_ctx* c, const unsigned* bitmap, int words, unsigned* rank, unsigned* zeroed_ctl) {
+  const int n = words + 1;
+  const int nb = (n + 2047) / 2048;
+  if (!zeroed_ctl) {
+    const size_t w = scan_ctl_words(n);
+    AG2_HIP(c, c->d_scan.reserve(w * sizeof(unsigned)));
+    AG2_HIP(c, hipMemsetAsync(c->d_scan.p, 0, w * sizeof(unsigned), c->stream));
+    zeroed_ctl = c->d_scan.as<unsigned>();
+  }
+  hipLaunchKernelGGL(k_scan_chained<true>, dim3(nb), dim3(256), 0, c->stream, rank, n, zeroed_ctl, bitmap);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
@@ -444,7 +407,11 @@ int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes
 int launch_grid_frame(ag2_ctx* c, unsigned* cell, unsigned* zeroed_ctl) {
   const int n = (int)c->fm_n_max, cap = (int)c->fm_cap_cells;
   GridFromParts fp{};
-  fp.part = c->d_bounds.as<int>();
+  if (c->fm_grid_ready) {  // the GPU front end left the description in d_griddesc (k_vox_emit_frame)
+    fp.ready = c->d_griddesc.as<GridDesc>();
+  } else {
+    fp.part = c->d_bounds.as<int>();
+  }
   fp.nb = std::min((n + 255) / 256, kBoundsBlocks);  // as pack_device_xyz launched k_bounds for n_pad = n
   fp.inv = 1.0f / (float)c->p.grid_cell;
   fp.origin_set = c->origin_set ? 1 : 0;

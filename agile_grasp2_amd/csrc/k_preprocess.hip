@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "ag2_internal.h"
+#include "k_grid_common.h"
 
 namespace ag2 {
 
@@ -297,6 +298,457 @@ __global__ void k_iota(int n, int* __restrict__ out) {
   if (i < n) out[i] = i;
 }
 
+// ================================================================================================
+// The front end WITHOUT a host round trip (single-camera clouds, voxel grid on): what a frame of a
+// cloud stream runs inside its captured sequence (ag2_detect_frame_raw), and the fast path of
+// ag2_preprocess_cloud_device / ag2_subsample_uniformly.
+//   k_raw_filter_bounds   pack + workspace test + extent partials of the points that pass
+//   k_vox_mark_frame      voxel lattice derived from the partials by the first wave of every workgroup
+//                         (as k_cell_count derives the search grid), then one atomicOr per passing point.
+//                         No compaction: with one camera the voxel set does not depend on the order of
+//                         the points (cloud_camera.cpp:137-141 inserts into a std::set).
+//   k_scan_chained<POPC>  rank of every bitmap word (k_grid.hip)
+//   k_vox_emit_frame      voxels in ascending (ix, iy, iz) order + padding, the search grid's description,
+//                         and the sub-sampling candidates (hash of the voxel's index under the threshold)
+//   k_sel_rank / k_sel_emit   exact selection of the num_samples smallest keys among the candidates,
+//                         written in ascending index order
+// Every shape is a fixed maximum; what a frame does not fit is flagged in PreFrame and the caller repeats
+// the frame on the general path below.
+// ================================================================================================
+__device__ __forceinline__ bool ws_keep(const float4& p, const WsBox& ws, int do_filter) {
+  bool keep = finite3(p.x, p.y, p.z);
+  if (keep && do_filter)  // cloud_camera.cpp:94-95
+    keep = (double)p.x > ws.b[0] && (double)p.x < ws.b[1] && (double)p.y > ws.b[2] &&
+           (double)p.y < ws.b[3] && (double)p.z > ws.b[4] && (double)p.z < ws.b[5];
+  return keep;
+}
+
+constexpr int kRawBlocks = 128;  // extent partials (one 32-B record per workgroup)
+
+// PACK: read the caller's strided buffer, write float4 (w = camera mask 1), pad [n, n_pad) with
+// non-finite points; else the float4 cloud is already in `raw`.  st (optional): cleared by block 0.
+template <bool PACK>
+__global__ void __launch_bounds__(256) k_raw_filter_bounds(const char* __restrict__ src, size_t stride,
+                                                           float4* __restrict__ raw, int n, int n_pad,
+                                                           WsBox ws, int do_filter, int* __restrict__ part,
+                                                           DevStats* st) {
+  if (st && blockIdx.x == 0 && threadIdx.x == 0) *st = DevStats{};
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+  int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  int cnt = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
+    float4 p;
+    if (PACK) {
+      if (i < n) {
+        const float* q = (const float*)(src + (size_t)i * stride);
+        p = make_float4(q[0], q[1], q[2], __int_as_float(1));
+      } else {
+        p = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
+      }
+      raw[i] = p;
+    } else {
+      p = raw[i];
+    }
+    if (ws_keep(p, ws, do_filter)) {
+      cnt++;
+      const int a[3] = {f2ord(p.x), f2ord(p.y), f2ord(p.z)};
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        mn[k] = min(mn[k], a[k]);
+        mx[k] = max(mx[k], a[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[k] = min(mn[k], __shfl_xor(mn[k], o, 64));
+      mx[k] = max(mx[k], __shfl_xor(mx[k], o, 64));
+    }
+  }
+  cnt = wave_sum_i(cnt);
+  __shared__ int wpart[4][7];
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      wpart[wave_id()][k] = mn[k];
+      wpart[wave_id()][3 + k] = mx[k];
+    }
+    wpart[wave_id()][6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int k = threadIdx.x;
+    int v = wpart[0][k];
+    for (int w = 1; w < 4; w++) {
+      const int o = wpart[w][k];
+      v = (k < 3) ? min(v, o) : (k < 6 ? max(v, o) : v + o);
+    }
+    part[blockIdx.x * 8 + k] = v;
+  }
+}
+
+// The voxel lattice of the points that passed, from the extent partials: the float expressions of
+// preprocess_resident below (cloud_camera.cpp:127-139), evaluated by every lane of the first wave.
+__device__ __forceinline__ PreFrame vox_from_partials(const int* __restrict__ part, int nb, float cell,
+                                                      int cap_words) {
+  const int lane = lane_id();
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+  int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  int cnt = 0;
+  for (int b = lane; b < nb; b += 64) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      mn[a] = min(mn[a], part[b * 8 + a]);
+      mx[a] = max(mx[a], part[b * 8 + 3 + a]);
+    }
+    cnt += part[b * 8 + 6];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
+    }
+  }
+  cnt = wave_sum_i(cnt);
+  PreFrame f{};
+  f.cell = cell;
+  f.n_keep = (unsigned)cnt;
+  if (cnt > 0) {
+    long long ncells = 1;
+    bool bad = false;
+    for (int a = 0; a < 3; a++) {
+      f.mn[a] = ord2f(mn[a]);
+      const float top = __builtin_floorf((ord2f(mx[a]) - f.mn[a]) / cell);  // same expression as vox_key
+      if (!(top < 2.0e6f)) bad = true;
+      f.dims[a] = bad ? 1 : (int)top + 1;
+      ncells *= f.dims[a];
+      if (ncells > (1ll << 33)) bad = true;
+    }
+    const long long words = (ncells + 31) >> 5;
+    if (bad || words > (long long)cap_words) {
+      f.flags = kPreGridTooLarge;
+      f.dims[0] = f.dims[1] = f.dims[2] = 0;
+    } else {
+      f.words = (int)words;
+    }
+  }
+  return f;
+}
+
+__global__ void __launch_bounds__(256) k_vox_mark_frame(const float4* __restrict__ raw, int n_pad, WsBox ws,
+                                                        int do_filter, const int* __restrict__ part, int nb,
+                                                        float cell, int cap_words, PreFrame* __restrict__ pf,
+                                                        unsigned* __restrict__ bitmap) {
+  __shared__ PreFrame f_sh;
+  if (wave_id() == 0) {
+    const PreFrame f = vox_from_partials(part, nb, cell, cap_words);
+    if (lane_id() == 0) {
+      f_sh = f;
+      if (blockIdx.x == 0) *pf = f;  // (also clears n_vox, n_cand and the flags of the previous frame)
+    }
+  }
+  __syncthreads();
+  if (f_sh.words <= 0) return;  // uniform
+  VoxDesc v;
+  v.cell = f_sh.cell;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    v.mn[a] = f_sh.mn[a];
+    v.dims[a] = f_sh.dims[a];
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  const float4 p = raw[i];
+  if (!ws_keep(p, ws, do_filter)) return;
+  const long long key = vox_key(p, v);
+  atomicOr(&bitmap[key >> 5], 1u << (key & 31));
+}
+
+// exclusive prefix of v over the 256 threads of the workgroup; *total = the sum (uniform)
+__device__ __forceinline__ int block_excl_scan_256(int v, int* total) {
+  __shared__ int ws_[4];
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane_id() >= o) inc += t;
+  }
+  __syncthreads();  // (a previous use of ws_ has been read)
+  if (lane_id() == 63) ws_[wave_id()] = inc;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave_id(); w++) woff += ws_[w];
+  *total = ws_[0] + ws_[1] + ws_[2] + ws_[3];
+  return woff + inc - v;
+}
+
+// One thread per bitmap word.  Voxel value = index * cell + min (cloud_camera.cpp:155-157); the voxel's
+// position in the output (its rank) is its index in the processed cloud, so the sub-sampling key of that
+// index can be formed here.  gf.out != nullptr: thread 0 also leaves the search grid's description (the
+// lattice's extent is known: both end voxels of every axis are occupied, by the extreme points).
+__global__ void __launch_bounds__(256) k_vox_emit_frame(const unsigned* __restrict__ bitmap,
+                                                        const unsigned* __restrict__ wrank, int cap_words,
+                                                        PreFrame* __restrict__ pf, float4* __restrict__ out,
+                                                        int n_max, unsigned num_samples,
+                                                        unsigned long long seed_arg,
+                                                        const FrameArgs* __restrict__ fa,
+                                                        unsigned long long* __restrict__ cand_h,
+                                                        unsigned* __restrict__ cand_i, unsigned cand_cap,
+                                                        GridFromParts gf) {
+  VoxDesc v;
+  v.cell = pf->cell;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    v.mn[a] = pf->mn[a];
+    v.dims[a] = pf->dims[a];
+  }
+  const int words = pf->words;
+  const unsigned n_vox = wrank[cap_words];
+  const unsigned long long seed = fa ? fa->sample_seed : seed_arg;
+  const unsigned long long thr = cand_threshold(num_samples, n_vox);
+  const bool want_cand = num_samples > 0u && n_vox > num_samples && n_vox <= (unsigned)n_max;
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned bits0 = (w < words) ? bitmap[w] : 0u;
+  const unsigned r0 = (w < words) ? wrank[w] : 0u;
+  const long long plane = (long long)v.dims[1] * v.dims[2];
+  int my = 0;
+  {
+    unsigned bits = bits0, r = r0;
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      const long long key = ((long long)w << 5) + b;
+      const int ix = (int)(key / plane);
+      const long long rem = key - (long long)ix * plane;
+      const int iy = (int)(rem / v.dims[2]);
+      const int iz = (int)(rem - (long long)iy * v.dims[2]);
+      if (r < (unsigned)n_max)
+        out[r] = make_float4((float)ix * v.cell + v.mn[0], (float)iy * v.cell + v.mn[1],
+                             (float)iz * v.cell + v.mn[2], __int_as_float(1));
+      if (want_cand && draw_u64(seed, kSubsampleStream, (uint64_t)r) <= thr) my++;
+      r++;
+    }
+  }
+  // candidates: one returning atomic per workgroup
+  if (num_samples > 0u) {  // (uniform)
+    __shared__ unsigned s_base;
+    int total = 0;
+    const int off = block_excl_scan_256(my, &total);
+    if (total > 0) {  // (uniform)
+      if (threadIdx.x == 0) s_base = atomicAdd(&pf->n_cand, (unsigned)total);
+      __syncthreads();
+      unsigned dst = s_base + (unsigned)off;
+      unsigned bits = bits0, r = r0;
+      while (bits && my > 0) {
+        bits &= bits - 1u;
+        const unsigned long long h = draw_u64(seed, kSubsampleStream, (uint64_t)r);
+        if (h <= thr) {
+          if (dst < cand_cap) {
+            cand_h[dst] = h;
+            cand_i[dst] = r;
+          }
+          dst++;
+          my--;
+        }
+        r++;
+      }
+    }
+  }
+  // padding behind the cloud: non-finite points, which no later stage sees as points
+  const float nanv = __builtin_nanf("");
+  for (long long i = (long long)n_vox + blockIdx.x * blockDim.x + threadIdx.x; i < n_max;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = make_float4(nanv, nanv, nanv, 0.f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned fl = 0u;
+    if (n_vox > (unsigned)n_max) fl |= kPreTooManyVoxels;
+    if (num_samples > 0u && n_vox <= num_samples) fl |= kPreAllPoints;
+    if (fl) atomicOr(&pf->flags, fl);
+    pf->n_vox = n_vox;
+    pf->thr = thr;
+    if (gf.out) {
+      float bmin[3], bmax[3];
+      for (int a = 0; a < 3; a++) {
+        bmin[a] = v.mn[a];
+        bmax[a] = (float)(v.dims[a] - 1) * v.cell + v.mn[a];  // same float expression as the emit above
+      }
+      *gf.out = grid_from_extent(bmin, bmax, (fl & kPreTooManyVoxels) ? 0 : (int)n_vox, gf);
+    }
+  }
+}
+
+// candidates of the sub-sampling when the cloud already exists (ag2_subsample_uniformly)
+__global__ void __launch_bounds__(256) k_sel_candidates(int n, unsigned long long seed, unsigned long long thr,
+                                                        PreFrame* __restrict__ pf,
+                                                        unsigned long long* __restrict__ cand_h,
+                                                        unsigned* __restrict__ cand_i, unsigned cand_cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long h = (i < n) ? draw_u64(seed, kSubsampleStream, (uint64_t)i) : ~0ull;
+  const int my = (i < n && h <= thr) ? 1 : 0;
+  __shared__ unsigned s_base;
+  int total = 0;
+  const int off = block_excl_scan_256(my, &total);
+  if (total == 0) return;  // uniform
+  if (threadIdx.x == 0) s_base = atomicAdd(&pf->n_cand, (unsigned)total);
+  __syncthreads();
+  const unsigned dst = s_base + (unsigned)off;
+  if (my && dst < cand_cap) {
+    cand_h[dst] = h;
+    cand_i[dst] = (unsigned)i;
+  }
+}
+
+// rank of every candidate among the candidates by (hash, index); the one of rank k - 1 is the threshold
+constexpr int kSelStage = 1024;
+__global__ void __launch_bounds__(256) k_sel_rank(const unsigned long long* __restrict__ cand_h,
+                                                  const unsigned* __restrict__ cand_i, unsigned cand_cap,
+                                                  unsigned k, PreFrame* __restrict__ pf) {
+  __shared__ unsigned long long sh[kSelStage];
+  __shared__ unsigned si[kSelStage];
+  const unsigned n_cand = pf->n_cand;
+  const int M = (int)min(n_cand, cand_cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned fl = 0u;
+    if (n_cand > cand_cap) fl |= kPreCandOverflow;
+    if ((unsigned)M < k && !(pf->flags & kPreAllPoints)) fl |= kPreCandShort;
+    if (fl) atomicOr(&pf->flags, fl);
+  }
+  if ((int)(blockIdx.x * blockDim.x) >= M) return;  // uniform
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long hj = (j < M) ? cand_h[j] : ~0ull;
+  const unsigned ij = (j < M) ? cand_i[j] : 0xFFFFFFFFu;
+  unsigned rank = 0;
+  for (int c0 = 0; c0 < M; c0 += kSelStage) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < kSelStage; t += blockDim.x) {
+      const bool in = c0 + t < M;
+      sh[t] = in ? cand_h[c0 + t] : ~0ull;       // padding: never smaller than a real key
+      si[t] = in ? cand_i[c0 + t] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int t = 0; t < kSelStage; t += 4) {
+      unsigned long long h4[4];
+      unsigned i4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        h4[u] = sh[t + u];
+        i4[u] = si[t + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) rank += (unsigned)(h4[u] < hj) | ((unsigned)(h4[u] == hj) & (unsigned)(i4[u] < ij));
+    }
+  }
+  if (j < M && rank + 1u == k) {
+    pf->kth_h = hj;
+    pf->kth_i = ij;
+  }
+}
+
+// the selected indices in ascending order: position = number of selected candidates with a smaller index
+__global__ void __launch_bounds__(256) k_sel_emit(const unsigned long long* __restrict__ cand_h,
+                                                  const unsigned* __restrict__ cand_i, unsigned cand_cap,
+                                                  const PreFrame* __restrict__ pf, int* __restrict__ out) {
+  __shared__ unsigned si[kSelStage];
+  if (pf->flags != 0u) return;  // uniform: the caller repeats the step on the general path
+  const int M = (int)min(pf->n_cand, cand_cap);
+  if ((int)(blockIdx.x * blockDim.x) >= M) return;  // uniform
+  const unsigned long long kh = pf->kth_h;
+  const unsigned ki = pf->kth_i;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long hj = (j < M) ? cand_h[j] : ~0ull;
+  const unsigned ij = (j < M) ? cand_i[j] : 0xFFFFFFFFu;
+  const bool sel = j < M && (hj < kh || (hj == kh && ij <= ki));
+  unsigned pos = 0;
+  for (int c0 = 0; c0 < M; c0 += kSelStage) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < kSelStage; t += blockDim.x) {
+      unsigned v = 0xFFFFFFFFu;  // not selected / padding: never smaller than a real index
+      if (c0 + t < M) {
+        const unsigned long long h = cand_h[c0 + t];
+        const unsigned i = cand_i[c0 + t];
+        if (h < kh || (h == kh && i <= ki)) v = i;
+      }
+      si[t] = v;
+    }
+    __syncthreads();
+    for (int t = 0; t < kSelStage; t += 8) {
+      unsigned i8[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) i8[u] = si[t + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) pos += (unsigned)(i8[u] < ij);
+    }
+  }
+  if (sel) out[pos] = (int)ij;
+}
+
+static WsBox ws_of(const ag2_ctx* c) {
+  WsBox ws;
+  for (int k = 0; k < 6; k++) ws.b[k] = c->p.workspace[k];
+  return ws;
+}
+
+// the pack + workspace test + extent kernel of a frame: reads the caller's buffer, so it runs in front of
+// the captured sequence (its pointer and count change with every frame)
+int front_pack_raw(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes, const FrontShapes& fs) {
+  AG2_HIP(c, c->d_raw.reserve(std::max<size_t>(fs.raw_max, 1) * 16));
+  AG2_HIP(c, c->d_bounds.reserve((size_t)kRawBlocks * 8 * 4));
+  const int nb = std::min(((int)fs.raw_max + 255) / 256, kRawBlocks);
+  hipLaunchKernelGGL(k_raw_filter_bounds<true>, dim3(nb), dim3(256), 0, c->stream, (const char*)d_xyz,
+                     stride_bytes, c->d_raw.as<float4>(), (int)n, (int)fs.raw_max, ws_of(c),
+                     fs.filter_workspace, c->d_bounds.as<int>(), c->d_stats.as<DevStats>());
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
+// Everything of the front end behind that kernel, at the fixed shapes `fs`: voxel grid -> d_xyz_in
+// (padded to fs.n_max), search-grid description -> d_griddesc, sample indices -> d_samples.  No host round
+// trip, no allocation once the buffers have their size: capturable.
+int enqueue_front_frame(ag2_ctx* c, const FrontShapes& fs) {
+  const int cap_words = (int)fs.cap_words;
+  const size_t ctl_words = (scan_ctl_words(cap_words + 1) + 3) & ~size_t(3);
+  const size_t bm_words = ((size_t)cap_words + 3) & ~size_t(3);
+  // bitmap and the scan's control words share one buffer: one fill clears both
+  AG2_HIP(c, c->d_bitmap.reserve((bm_words + ctl_words) * 4));
+  AG2_HIP(c, c->d_wrank.reserve(((size_t)cap_words + 1) * 4));
+  AG2_HIP(c, c->d_preframe.reserve(sizeof(PreFrame)));
+  AG2_HIP(c, c->d_cand.reserve(std::max<size_t>(fs.cand_cap, 1) * 12));
+  AG2_HIP(c, c->d_samples.reserve(std::max<size_t>(fs.num_samples, 1) * 4));
+  AG2_HIP(c, c->d_xyz_in.reserve(std::max<size_t>(fs.n_max, 1) * 16));
+  AG2_HIP(c, c->d_griddesc.reserve(sizeof(GridDesc)));
+  unsigned* bitmap = c->d_bitmap.as<unsigned>();
+  PreFrame* pf = c->d_preframe.as<PreFrame>();
+  AG2_HIP(c, hipMemsetAsync(bitmap, 0, (bm_words + ctl_words) * 4, c->stream));
+  const int nb = std::min(((int)fs.raw_max + 255) / 256, kRawBlocks);
+  hipLaunchKernelGGL(k_vox_mark_frame, dim3(((unsigned)fs.raw_max + 255) / 256), dim3(256), 0, c->stream,
+                     c->d_raw.as<float4>(), (int)fs.raw_max, ws_of(c), fs.filter_workspace,
+                     c->d_bounds.as<int>(), nb, fs.cell, cap_words, pf, bitmap);
+  int rc = scan_popc_u32(c, bitmap, cap_words, c->d_wrank.as<unsigned>(), bitmap + bm_words);
+  if (rc) return rc;
+  GridFromParts gf{};
+  gf.inv = 1.0f / (float)c->p.grid_cell;
+  gf.origin_set = c->origin_set ? 1 : 0;
+  for (int a = 0; a < 3; a++) gf.org[a] = c->origin[a];
+  gf.cap_cells = (int)c->fm_cap_cells;
+  gf.out = c->d_griddesc.as<GridDesc>();
+  unsigned long long* cand_h = c->d_cand.as<unsigned long long>();
+  unsigned* cand_i = reinterpret_cast<unsigned*>(cand_h + std::max<size_t>(fs.cand_cap, 1));
+  hipLaunchKernelGGL(k_vox_emit_frame, dim3(((unsigned)cap_words + 255) / 256), dim3(256), 0, c->stream, bitmap,
+                     c->d_wrank.as<unsigned>(), cap_words, pf, c->d_xyz_in.as<float4>(), (int)fs.n_max,
+                     (unsigned)fs.num_samples, 0ull, c->fm_args_dev, cand_h, cand_i, (unsigned)fs.cand_cap, gf);
+  const unsigned sel_blocks = (unsigned)((std::max<size_t>(fs.cand_cap, 1) + 255) / 256);
+  hipLaunchKernelGGL(k_sel_rank, dim3(sel_blocks), dim3(256), 0, c->stream, cand_h, cand_i, (unsigned)fs.cand_cap,
+                     (unsigned)fs.num_samples, pf);
+  hipLaunchKernelGGL(k_sel_emit, dim3(sel_blocks), dim3(256), 0, c->stream, cand_h, cand_i, (unsigned)fs.cand_cap,
+                     pf, c->d_samples.as<int>());
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
 // d_raw (and d_raw_nrm when have_nrm) hold n points
 static int preprocess_resident(ag2_ctx* c, size_t n, bool have_cam, bool have_nrm,
                                int filter_workspace, int voxelize, double voxel_size, int flags,
@@ -323,6 +775,52 @@ static int preprocess_resident(ag2_ctx* c, size_t n, bool have_cam, bool have_nr
   };
   AG2_HIP(c, c->d_xyz_in.reserve(std::max<size_t>(n, 1) * 16));
   if (n == 0) return finish(0);
+  // Fast path (the usual call: one camera, voxel grid on, a bounded workspace): the kernels of the
+  // fixed-shape front end above, with ONE read-back at the end (the processed cloud's size) instead of
+  // two and no compaction pass.  The workspace bounds the voxel lattice, hence the bitmap.
+  static const bool fast_off = getenv("AG2_PRE_GENERAL") != nullptr;  // A/B and tests of the general path
+  if (!fast_off && voxelize && !have_cam && !have_nrm && filter_workspace) {
+    double cells = 1.0;
+    for (int a = 0; a < 3; a++)
+      cells *= floor((c->p.workspace[2 * a + 1] - c->p.workspace[2 * a]) / (double)(float)voxel_size) + 2.0;
+    if (cells >= 1.0 && cells < 4.0e9) {  // (<= 500 MB of bitmap; an unbounded workspace takes the general path)
+      FrontShapes fs{};
+      fs.raw_max = n;
+      fs.cap_words = (size_t)(cells / 32.0) + 2;
+      fs.n_max = n;
+      fs.num_samples = 0;
+      fs.cand_cap = 0;
+      fs.cell = (float)voxel_size;
+      fs.filter_workspace = 1;
+      AG2_HIP(c, c->d_bounds.reserve((size_t)kRawBlocks * 8 * 4));
+      const int nb = std::min(((int)n + 255) / 256, kRawBlocks);
+      hipLaunchKernelGGL(k_raw_filter_bounds<false>, dim3(nb), dim3(256), 0, c->stream, (const char*)nullptr,
+                         (size_t)0, c->d_raw.as<float4>(), (int)n, (int)n, ws_of(c), 1, c->d_bounds.as<int>(),
+                         (DevStats*)nullptr);
+      const size_t cap_cells_saved = c->fm_cap_cells;
+      const FrameArgs* fa_saved = c->fm_args_dev;
+      c->fm_args_dev = nullptr;
+      int rc = enqueue_front_frame(c, fs);  // (the grid description it leaves is not used on this path)
+      c->fm_args_dev = fa_saved;
+      c->fm_cap_cells = cap_cells_saved;
+      if (rc) return rc;
+      PreFrame hf;
+      AG2_HIP(c, hipMemcpyAsync(pin_small(c), c->d_preframe.p, sizeof(hf), hipMemcpyDeviceToHost, c->stream));
+      AG2_HIP(c, hipStreamSynchronize(c->stream));
+      __builtin_memcpy(&hf, pin_small(c), sizeof(hf));
+      if (!(hf.flags & (kPreGridTooLarge | kPreTooManyVoxels))) {
+        const size_t m = hf.n_vox;
+        for (int a = 0; a < 3; a++) c->last_vox_dims[a] = hf.dims[a];
+        for (int a = 0; a < 3 && m; a++) {
+          c->known_min[a] = hf.mn[a];
+          c->known_max[a] = (float)(hf.dims[a] - 1) * hf.cell + hf.mn[a];
+        }
+        c->bounds_known = m > 0;
+        return finish(m);
+      }
+      // (cannot happen with a lattice inside the workspace; the general path below decides)
+    }
+  }
   AG2_HIP(c, c->d_prestats.reserve(sizeof(PreStats)));
   AG2_HIP(c, c->d_pflags.reserve((n + 1) * 4));
   if (voxelize) AG2_HIP(c, c->d_pre.reserve(n * 16));
@@ -370,6 +868,7 @@ static int preprocess_resident(ag2_ctx* c, size_t n, bool have_cam, bool have_nr
     ncells *= v.dims[a];
     if (ncells > (1ll << 33)) return set_err(c, AG2_ERR_CAPACITY, "voxel grid has more than 2^33 cells");
   }
+  for (int a = 0; a < 3; a++) c->last_vox_dims[a] = v.dims[a];
   const int words = (int)((ncells + 31) >> 5);
   const int mi = (int)m, gm = (mi + 255) / 256, gw = (words + 256) / 256;
   AG2_HIP(c, c->d_bitmap.reserve((size_t)words * 4));
@@ -506,6 +1005,19 @@ int ag2_get_cloud(ag2_ctx* c, float* xyz_nx3, int32_t* cam_source, size_t cap, s
   return 0;
 }
 
+int ag2_get_samples(ag2_ctx* c, int32_t* idx, size_t cap, size_t* n) {
+  if (!c || !n) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  *n = c->n_resident_samples;
+  if (cap < c->n_resident_samples) return set_err(c, AG2_ERR_CAPACITY, "sample buffer too small");
+  if (c->n_resident_samples && !idx) return set_err(c, AG2_ERR_ARG, "idx is NULL");
+  if (c->n_resident_samples) {
+    AG2_HIP(c, hipMemcpyAsync(idx, c->d_samples.p, c->n_resident_samples * 4, hipMemcpyDeviceToHost, c->stream));
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
 int ag2_subsample_uniformly(ag2_ctx* c, size_t num_samples, uint64_t seed, int32_t* idx_out,
                             size_t cap, size_t* n_out) {
   if (!c || !n_out) return AG2_ERR_ARG;
@@ -519,6 +1031,37 @@ int ag2_subsample_uniformly(ag2_ctx* c, size_t num_samples, uint64_t seed, int32
   AG2_HIP(c, c->d_samples.reserve(k * 4));
   int* out = c->d_samples.as<int>();
   const int ni = (int)n, g256 = (ni + 255) / 256;
+  bool done = false;
+  static const bool fast_off = getenv("AG2_PRE_GENERAL") != nullptr;
+  if (k < n && !fast_off) {
+    // candidates under a hash threshold, then the exact selection among them (three small kernels); the
+    // record that comes back says whether the candidate list held what it had to -- if not (p < 1e-12)
+    // the radix select below decides
+    const size_t cap = cand_capacity(k);
+    AG2_HIP(c, c->d_preframe.reserve(sizeof(PreFrame)));
+    AG2_HIP(c, c->d_cand.reserve(cap * 12));
+    PreFrame* pf = c->d_preframe.as<PreFrame>();
+    unsigned long long* cand_h = c->d_cand.as<unsigned long long>();
+    unsigned* cand_i = reinterpret_cast<unsigned*>(cand_h + cap);
+    AG2_HIP(c, hipMemsetAsync(pf, 0, sizeof(PreFrame), c->stream));
+    hipLaunchKernelGGL(k_sel_candidates, dim3(g256), dim3(256), 0, c->stream, ni, (unsigned long long)seed,
+                       cand_threshold((unsigned)k, (unsigned)n), pf, cand_h, cand_i, (unsigned)cap);
+    const unsigned sel_blocks = (unsigned)((cap + 255) / 256);
+    hipLaunchKernelGGL(k_sel_rank, dim3(sel_blocks), dim3(256), 0, c->stream, cand_h, cand_i, (unsigned)cap,
+                       (unsigned)k, pf);
+    hipLaunchKernelGGL(k_sel_emit, dim3(sel_blocks), dim3(256), 0, c->stream, cand_h, cand_i, (unsigned)cap, pf, out);
+    AG2_HIP(c, hipGetLastError());
+    PreFrame hf;
+    AG2_HIP(c, hipMemcpyAsync(pin_small(c), pf, sizeof(hf), hipMemcpyDeviceToHost, c->stream));
+    if (idx_out) AG2_HIP(c, hipMemcpyAsync(idx_out, out, k * 4, hipMemcpyDeviceToHost, c->stream));
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+    __builtin_memcpy(&hf, pin_small(c), sizeof(hf));
+    done = hf.flags == 0u;
+    if (done) {
+      c->n_resident_samples = k;
+      return 0;
+    }
+  }
   if (k == n) {
     hipLaunchKernelGGL(k_iota, dim3(g256), dim3(256), 0, c->stream, ni, out);
   } else {

@@ -476,12 +476,17 @@ __global__ void __launch_bounds__(256) k_merge_flatten(const unsigned char* __re
                                                       ag2_hypothesis* __restrict__ flat, unsigned* __restrict__ total) {
   const size_t per = 16 + (size_t)cap * sizeof(ag2_hypothesis);
   const int r = blockIdx.y;
-  unsigned off = 0, mine = 0;
+  unsigned off = 0, mine = 0, cut = 0;
   for (int k = 0; k <= r; k++) {  // (a few ranks: every thread adds up the counts before its rank)
-    const unsigned cnt = min(*reinterpret_cast<const unsigned*>(g + (size_t)k * per), cap);
+    const unsigned hdr = *reinterpret_cast<const unsigned*>(g + (size_t)k * per);
+    const unsigned cnt = min(hdr, cap);
+    cut |= (hdr > cap) ? 1u : 0u;  // a rank's list was cut at the exchange capacity: the merge is void
     if (k < r) off += cnt; else mine = cnt;
   }
-  if (r == world - 1 && blockIdx.x == 0 && threadIdx.x == 0) *total = off + mine;
+  if (r == world - 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+    total[0] = off + mine;
+    total[1] = cut;
+  }
   constexpr unsigned kPer = (unsigned)(sizeof(ag2_hypothesis) / 16);
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i / kPer < mine)
@@ -534,11 +539,22 @@ int merge_selected(ag2_ctx* c, const void* d_gathered, size_t world, size_t cap_
   AG2_HIP(c, c->d_merge.reserve((n_max + k_cap + 1) * sizeof(ag2_hypothesis) + 64));
   ag2_hypothesis* flat = c->d_merge.as<ag2_hypothesis>();
   ag2_hypothesis* out = flat + n_max;
-  unsigned* counts = reinterpret_cast<unsigned*>(out + k_cap);  // {k, n}, then the flat total
+  unsigned* counts = reinterpret_cast<unsigned*>(out + k_cap);  // {k, n}, then {flat total, a list was cut}, then the clustered count
   const size_t threads = std::max<size_t>(cap_records, 1) * (sizeof(ag2_hypothesis) / 16);
   hipLaunchKernelGGL(k_merge_flatten, dim3((unsigned)((threads + 255) / 256), (unsigned)world), dim3(256), 0, c->stream,
                      (const unsigned char*)d_gathered, (int)world, (unsigned)cap_records, flat, counts + 2);
-  hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, c->stream, flat, counts + 2,
+  // Grasp clusters (grasp_detector.cpp:228-236) count inliers over ALL hands that passed the threshold,
+  // whichever rank found them: the ranks export their lists BEFORE the clustering and it runs here, on
+  // the gathered list (rank order = sample order = the order the unsplit run clusters in).
+  const ag2_hypothesis* recs = flat;
+  const unsigned* d_nrecs = counts + 2;
+  if (c->min_inliers > 0 && n_max > 0) {
+    const int rc = cluster_async(c, flat, n_max, counts + 2, c->min_inliers, counts + 4);
+    if (rc) return rc;
+    recs = c->d_cluster.as<ag2_hypothesis>();
+    d_nrecs = counts + 4;
+  }
+  hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, c->stream, recs, d_nrecs,
                      c->p.num_selected, (int)k_cap, out, counts);
   AG2_HIP(c, hipGetLastError());
   // one copy brings the top-k records and the counts behind them
@@ -547,10 +563,13 @@ int merge_selected(ag2_ctx* c, const void* d_gathered, size_t world, size_t cap_
   if (rc) return rc;
   AG2_HIP(c, hipMemcpyAsync(pin_bulk(c), out, bytes, hipMemcpyDeviceToHost, c->stream));
   AG2_HIP(c, hipStreamSynchronize(c->stream));
-  unsigned kn[2];
-  __builtin_memcpy(kn, pin_bulk(c) + k_cap * sizeof(ag2_hypothesis), 8);
+  unsigned kn[4];
+  __builtin_memcpy(kn, pin_bulk(c) + k_cap * sizeof(ag2_hypothesis), 16);
   *n_selected = kn[0];
-  if (n_total) *n_total = kn[1];
+  if (n_total) *n_total = kn[2];  // records that took part (before the clustering)
+  if (kn[3])
+    return set_err(c, AG2_ERR_CAPACITY, "merge: a rank's list is longer than the exchange capacity (header count > "
+                                        "cap_records): the global top-k would be wrong; exchange with a larger capacity");
   if (kn[0] > cap) return set_err(c, AG2_ERR_CAPACITY, "merge: output capacity too small");
   if (kn[0] && selected) __builtin_memcpy(selected, pin_bulk(c), (size_t)kn[0] * sizeof(ag2_hypothesis));
   return 0;

@@ -407,9 +407,10 @@ static_assert(kGposCap <= 65536, "in-box indices are 16 bits");
 //   STAGE 1: the samples stage 0 handed on (dense clouds); centred coordinates + positions of the
 //            cropped list in a per-workgroup global scratch (four 256-thread workgroups per CU)
 // RMAX: compile-time bound on num_orientations (8, 16 or 32) for the per-orientation registers
-// SPLIT: stop at the gates -- the sample's list goes to the list arena, its passing orientations to
-// the pair queue of k_sweep_orient (k_sweep_orient.hip); !SPLIT: the per-orientation passes run here
-template <int STAGE, int RMAX, bool SPLIT>
+// The kernel stops at the gates: the sample's list goes to the list arena, its passing orientations to
+// the pair queue of k_sweep_orient (k_sweep_orient.hip).  (The one-kernel form of rounds 1-2, which ran
+// the per-orientation passes here, lives on in tools/experiments/ only.)
+template <int STAGE, int RMAX>
 __global__ void __launch_bounds__(sweep_threads(STAGE),
                                   (STAGE == 0 ? kStage0WgPerCu : 4) * sweep_threads(STAGE) / 256)
 k_sweep(SweepArgs A) {
@@ -424,42 +425,30 @@ k_sweep(SweepArgs A) {
   // Split sweep, stage 1: the cropped list is written ONCE, in the form k_sweep_orient reads (one
   // float4 per point in the list arena), and pass A streams it from there -- no per-workgroup scratch,
   // no copy at the gates, and no bound on the list length other than the arena's (which grows).
-  constexpr bool ARENA = SPLIT && STAGE == 1;
+  constexpr bool ARENA = STAGE == 1;
   const int CAP = LITE ? kGposCap : (LDS_STORE ? kCapL : (ARENA ? 0x7fffffff : A.gcap));
   float4* L = nullptr;  // ARENA: this sample's list
   float* pbase;
-  unsigned short* box16 = nullptr;
-  int* box32 = nullptr;
-  // staged cropped list: centred xyz (float) + sorted position of the point (its normal is fetched
-  // from L2 only for the few points that end up inside a closing region) = 16 B per point
+  // stage 0: sorted positions of the cropped list in LDS; stage 1: the list arena (L)
   if (LDS_STORE) {
     pbase = reinterpret_cast<float*>(smem_raw + sweep_ctl_bytes(STAGE));
-    box16 = reinterpret_cast<unsigned short*>(pbase + (LITE ? 1 : 4) * kCapL);
   } else {
     pbase = ARENA ? nullptr : A.gscratch + (size_t)blockIdx.x * 5 * (size_t)A.gcap;
-    box32 = ARENA ? nullptr : reinterpret_cast<int*>(pbase + 4 * (size_t)A.gcap);
   }
   float* PX = pbase;
   float* PY = pbase + CAP;
   float* PZ = pbase + 2 * (size_t)CAP;
   int* POS = reinterpret_cast<int*>(pbase + (LITE ? 0 : 3) * (size_t)(LITE ? kCapL : CAP));
   int* gpos = nullptr;
-  unsigned short* gbox = nullptr;
-  if (LITE) {
-    gpos = A.gpos + (size_t)blockIdx.x * kGposCap;
-    gbox = reinterpret_cast<unsigned short*>(A.gpos + (size_t)gridDim.x * kGposCap) + (size_t)blockIdx.x * kGposCap;
-  }
+  if (LITE) gpos = A.gpos + (size_t)blockIdx.x * kGposCap;
 
   const HandConst& hc = *A.hc;
   // frame mode: grid description, cloud minimum and slot base come from memory (uniform loads)
   const GridDesc G = A.gp ? *A.gp : A.g;
-  const float cloud_min_z = A.gp ? G.min_z : A.min_z;
-  const int slot_base = A.fa ? (int)A.fa->slot_base : A.slot_base;
   const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int R = hc.R;
   const double hh = hc.hand_height;
-  int red_sel = 0;
   const int n_work = (STAGE == 0) ? A.n_samples : (int)A.st->n_overflow;
   if (STAGE != 0 && n_work == 0) return;
   if (tid < 20) {
@@ -473,8 +462,6 @@ k_sweep(SweepArgs A) {
     S.cosf_t[tid] = (float)hc.cos_t[tid];
     S.sinf_t[tid] = (float)hc.sin_t[tid];
   }
-  const int n_depths = hc.n_depths;
-  const double hand_depth = hc.hand_depth;
   const double slot_inv_step = hc.slot_inv_step, slot_step = hc.slot_step;
   const double hand_od = hc.hand_outer_diameter, finger_w = hc.finger_width;
   const double slot_ratio = hc.finger_width * hc.slot_inv_step;  // finger width in slot spacings
@@ -532,7 +519,6 @@ k_sweep(SweepArgs A) {
       }
     };
     const double* fr = A.frames + (size_t)t * 12;
-    const double smp[3] = {fr[0], fr[1], fr[2]};
     // frame = [normal binormal curvature_axis] as columns, hand_search.cpp:325-326
     const double F[3][3] = {{fr[3], fr[6], fr[9]}, {fr[4], fr[7], fr[10]}, {fr[5], fr[8], fr[11]}};
 
@@ -1200,7 +1186,7 @@ k_sweep(SweepArgs A) {
       hand_l = open ? (free_ & (free_ >> 10) & 0x3FFu) : 0u;        // finger_hand.cpp:313-325
     }
     unsigned long long todo = __ballot(hand_l != 0u);               // hand_search.cpp:370
-    if constexpr (SPLIT) {
+    {
       if (todo) {  // (uniform: every wave holds the same gates)
         if (!ARENA) {
           if (tid == 0) {
@@ -1239,315 +1225,6 @@ k_sweep(SweepArgs A) {
           }
         }
       }
-    }
-    if constexpr (!SPLIT)
-    while (todo) {
-      AG2_PROF(7);
-      const int oi = __ffsll((long long)todo) - 1;
-      todo &= todo - 1ull;
-      const unsigned hand = (unsigned)__builtin_amdgcn_readlane((int)hand_l, oi);
-      const int nvalid = __popc(hand);
-      // From here on everything is the reference's f64 arithmetic, for the few orientations that
-      // pass the gates.  rot = [c -s 0; s c 0; 0 0 1], frame_rot = frame * rot, hand_search.cpp:356-357
-      const double cs = S.cosd[oi], sn = S.sind[oi];
-      double Fr[3][3];
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        Fr[a][0] = (F[a][0] * cs + F[a][1] * sn) + F[a][2] * 0.0;
-        Fr[a][1] = (F[a][0] * (-1.0 * sn) + F[a][1] * cs) + F[a][2] * 0.0;
-        Fr[a][2] = (F[a][0] * 0.0 + F[a][1] * 0.0) + F[a][2] * 1.0;
-      }
-      // deepenHand, finger_hand.cpp:96-134: middle valid hand = valid[ceil(n/2) - 1]
-      int idx = 0;
-      {
-        const int want = (nvalid + 1) / 2 - 1;
-        int seen = 0;
-        for (int k = 0; k < 10; k++)
-          if (hand & (1u << k)) {
-            if (seen == want) idx = k;
-            seen++;
-          }
-      }
-      const double fl0 = S.fs[idx], fl1 = S.fsr[idx], fr0 = S.fs[10 + idx], fr1 = S.fsr[10 + idx];
-      // pass B: first depth step that fails (some point under the finger pads or behind the hand)
-      // (the same pass yields surface = min y over ALL rotated points, finger_hand.cpp:158)
-      int kfail = n_depths;
-      double miny = __builtin_inf();
-      {
-        float qx, qy, qz;  // next iteration's point, requested one iteration ahead (as in pass A)
-        ldp(min(tid, K - 1), qx, qy, qz);
-        for (int j0 = 0; j0 < K; j0 += NT) {
-          const int j = j0 + tid;
-          const float fx_ = qx, fy_ = qy, fz_ = qz;
-          ldp(min(j + NT, K - 1), qx, qy, qz);
-          if (j < K) {
-            const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
-            const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
-            const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
-            miny = (y < miny) ? y : miny;
-            const bool zone = (x > fl0 && x < fl1) || (x > fr0 && x < fr1);
-            for (int di = 0; di < kfail; di++) {
-              const double d = S.depths[di];
-              if (y < d && (zone || y < d - hand_depth)) {
-                kfail = di;
-                break;
-              }
-            }
-          }
-        }
-      }
-      kfail = wave_min_i(kfail);
-      miny = wave_min_d(miny);
-      red_sel ^= 1;
-      if (lane == 0) {
-        S.red.i[red_sel][wid][0] = kfail;
-        S.red.d[red_sel][wid][0] = miny;
-      }
-      __syncthreads();
-      kfail = n_depths;
-      double surface = __builtin_inf();
-#pragma unroll
-      for (int k = 0; k < NW; k++) {
-        kfail = min(kfail, S.red.i[red_sel][k][0]);
-        const double v = S.red.d[red_sel][k][0];
-        surface = (v < surface) ? v : surface;
-      }
-      double top = top0, bottom = bottom0;
-      if (kfail > 0) {  // last successful step, finger_hand.cpp:128-129
-        top = S.depths[kfail - 1];
-        bottom = top - hand_depth;
-      }
-      AG2_PROF(4);
-      // closing region, finger_hand.cpp:137-180
-      const double left = fl0 + hc.finger_width;
-      const double right = fr0;
-      const double center = 0.5 * (left + right);
-      // pass C: in-box points, ordered compaction (each wave a contiguous quarter of the list)
-      const int segk = (((K + NW - 1) / NW) + 63) & ~63;
-      const int jb = min(wid * segk, K), je = min(jb + segk, K);
-      int cnt = 0;
-      double mnx = __builtin_inf(), mxx = -__builtin_inf();
-      // The membership masks of this pass are kept (one 64-bit ballot per step, in the piece-mask
-      // area the crop no longer needs) so that the writing pass below expands them instead of
-      // rotating every point a second time; a segment with more steps than fit recomputes.
-      unsigned long long* inmask = reinterpret_cast<unsigned long long*>(S.piece_mask) + wid * (kMaxPieces / 2 / NW);
-      const bool keep_masks = segk / 64 <= kMaxPieces / 2 / NW;
-      {
-        float qx, qy, qz;  // next step's point, requested one step ahead
-        ldp(min(jb + lane, K - 1), qx, qy, qz);
-        for (int j0 = jb; j0 < je; j0 += 64) {
-          const int j = j0 + lane;
-          bool in = false;
-          const float fx_ = qx, fy_ = qy, fz_ = qz;
-          ldp(min(j + 64, K - 1), qx, qy, qz);
-          if (j < je) {
-            const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
-            const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
-            const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
-            in = (y < top && x > left && x < right);
-            if (in) {
-              mnx = (x < mnx) ? x : mnx;
-              mxx = (x > mxx) ? x : mxx;
-            }
-          }
-          const unsigned long long mask = __ballot(in);
-          if (keep_masks && lane == 0) inmask[(j0 - jb) >> 6] = mask;
-          cnt += __popcll(mask);
-        }
-      }
-      mnx = wave_min_d(mnx);
-      mxx = wave_max_d(mxx);
-      red_sel ^= 1;
-      if (lane == 0) {
-        S.red.i[red_sel][wid][0] = cnt;
-        S.red.d[red_sel][wid][0] = mnx;
-        S.red.d[red_sel][wid][1] = mxx;
-      }
-      __syncthreads();
-      int P = 0, pbase_w = 0;
-      mnx = __builtin_inf();
-      mxx = -__builtin_inf();
-#pragma unroll
-      for (int k = 0; k < NW; k++) {
-        const int ck = S.red.i[red_sel][k][0];
-        if (k < wid) pbase_w += ck;
-        P += ck;
-        const double a = S.red.d[red_sel][k][0], b = S.red.d[red_sel][k][1];
-        mnx = (a < mnx) ? a : mnx;
-        mxx = (b > mxx) ? b : mxx;
-      }
-      if (P == 0) continue;                                         // hand_search.cpp:377-381
-      {
-        int run = pbase_w;
-        for (int j0 = jb; j0 < je; j0 += 64) {
-          const int j = j0 + lane;
-          bool in = false;
-          unsigned long long mask;
-          if (keep_masks) {  // (uniform) the masks of the counting pass: written and read by this wave only
-            mask = inmask[(j0 - jb) >> 6];
-            in = (mask >> lane) & 1ull;
-          } else {
-            if (j < je) {
-              float fx_, fy_, fz_;
-              ldp(j, fx_, fy_, fz_);
-              const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
-              const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
-              const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
-              in = (y < top && x > left && x < right);
-            }
-            mask = __ballot(in);
-          }
-          if (in) {
-            const int dst = run + __popcll(mask & lt_mask);
-            if (LITE && gmode) gbox[dst] = (unsigned short)j;
-            else if (LDS_STORE) box16[dst] = (unsigned short)j;
-            else box32[dst] = j;
-          }
-          run += __popcll(mask);
-        }
-      }
-      AG2_PROF(5);
-      const int slot = t * R + oi;
-      if (tid == 0) {
-        long long off = -1;
-        if (A.emit_lists) {
-          off = (long long)atomicAdd(&A.st->arena_top, (unsigned long long)P);
-          if (off + P > A.arena_cap) {
-            atomicOr(&A.st->err_flags, 1u);
-            off = -1;
-          }
-        }
-        S.arena_off = off;
-      }
-      __syncthreads();
-      const long long off = S.arena_off;
-      // pass D: unit-box scaling (hand_search.cpp:399-409), list emission, antipodal extents
-      const double baseline = 0.1;
-      const double left_const = left - 0.5 * (baseline - (right - left));
-      const double lower[3] = {left_const, bottom, -1.0 * hh};
-      const double scales[3] = {1.0 / baseline, 1.0 / (top - bottom), 1.0 / (2.0 * hh)};
-      const double lt = scales[0] * (mnx - lower[0]) + 0.003;       // antipodal.cpp:16
-      const double rt = scales[0] * (mxx - lower[0]) - 0.003;       // antipodal.cpp:17
-      int nl = 0, nr = 0;
-      double e[8] = {-__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf(),
-                     -__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf()};
-      // e: lmaxy lminy lmaxz lminz rmaxy rminy rmaxz rminz
-      for (int b = tid; b < P; b += NT) {
-        const int j = (LITE && gmode) ? (int)gbox[b] : (LDS_STORE ? (int)box16[b] : box32[b]);
-        float fx_, fy_, fz_;
-        ldp(j, fx_, fy_, fz_);
-        const double p0 = (double)fx_, p1 = (double)fy_, p2 = (double)fz_;
-        const float4 nn = A.nrm[pos_at(j)];  // hand_search.cpp:211, :394: the point's normal
-        const double q0 = (double)nn.x, q1 = (double)nn.y, q2 = (double)nn.z;
-        double X[3], Y[3], U[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-          X[a] = (Fr[0][a] * p0 + Fr[1][a] * p1) + Fr[2][a] * p2;
-          Y[a] = (Fr[0][a] * q0 + Fr[1][a] * q1) + Fr[2][a] * q2;
-          U[a] = scales[a] * (X[a] - lower[a]);
-        }
-        if (off >= 0) {
-          double* dst = A.arena + (size_t)(off + b) * 6;
-          dst[0] = U[0]; dst[1] = U[1]; dst[2] = U[2];
-          dst[3] = Y[0]; dst[4] = Y[1]; dst[5] = Y[2];
-        }
-        const double ldot = (-1.0 * Y[0] + 0.0 * Y[1]) + 0.0 * Y[2];  // antipodal.cpp:20-25
-        const double rdot = (1.0 * Y[0] + 0.0 * Y[1]) + 0.0 * Y[2];
-        if (ldot > hc.cos_fc && U[0] < lt) {
-          nl++;
-          e[0] = (U[1] > e[0]) ? U[1] : e[0]; e[1] = (U[1] < e[1]) ? U[1] : e[1];
-          e[2] = (U[2] > e[2]) ? U[2] : e[2]; e[3] = (U[2] < e[3]) ? U[2] : e[3];
-        }
-        if (rdot > hc.cos_fc && U[0] > rt) {
-          nr++;
-          e[4] = (U[1] > e[4]) ? U[1] : e[4]; e[5] = (U[1] < e[5]) ? U[1] : e[5];
-          e[6] = (U[2] > e[6]) ? U[2] : e[6]; e[7] = (U[2] < e[7]) ? U[2] : e[7];
-        }
-      }
-      nl = wave_sum_i(nl);
-      nr = wave_sum_i(nr);
-#pragma unroll
-      for (int k = 0; k < 8; k += 2) {
-        e[k] = wave_max_d(e[k]);
-        e[k + 1] = wave_min_d(e[k + 1]);
-      }
-      red_sel ^= 1;
-      if (lane == 0) {
-        S.red.i[red_sel][wid][0] = nl;
-        S.red.i[red_sel][wid][1] = nr;
-#pragma unroll
-        for (int k = 0; k < 8; k++) S.red.d[red_sel][wid][k] = e[k];
-      }
-      __syncthreads();
-      if (tid == 0) {
-        nl = nr = 0;
-        for (int k = 0; k < 8; k += 2) {
-          e[k] = -__builtin_inf();
-          e[k + 1] = __builtin_inf();
-        }
-        for (int wv = 0; wv < NW; wv++) {
-          nl += S.red.i[red_sel][wv][0];
-          nr += S.red.i[red_sel][wv][1];
-          for (int k = 0; k < 8; k += 2) {
-            const double a = S.red.d[red_sel][wv][k], b = S.red.d[red_sel][wv][k + 1];
-            e[k] = (a > e[k]) ? a : e[k];
-            e[k + 1] = (b < e[k + 1]) ? b : e[k + 1];
-          }
-        }
-        int label = 0;
-        if (nl > 0 || nr > 0) label = 1;                              // antipodal.cpp:48-51
-        if (nl > 0 && nr > 0) {                                       // :54-81
-          const double top_y = (e[0] < e[4]) ? e[0] : e[4], bot_y = (e[1] > e[5]) ? e[1] : e[5];
-          const double top_z = (e[2] < e[6]) ? e[2] : e[6], bot_z = (e[3] > e[7]) ? e[3] : e[7];
-          if (top_y > bot_y && top_z > bot_z) label = 2;
-        }
-        ag2_hypothesis h;
-        const double ys[3] = {surface, bottom, top};
-        double* dstv[3] = {h.surface, h.bottom, h.top};
-        for (int k = 0; k < 3; k++)                                   // finger_hand.cpp:189-199
-          for (int a = 0; a < 3; a++)
-            dstv[k][a] = ((Fr[a][0] * center + Fr[a][1] * ys[k]) + Fr[a][2] * 0.0) + smp[a];
-        for (int a = 0; a < 3; a++) {                                 // hand_search.cpp:383-385
-          h.binormal[a] = Fr[a][0];
-          h.approach[a] = Fr[a][1];
-          h.axis[a] = Fr[a][2];
-        }
-        h.width = mxx - mnx;                                          // hand_search.cpp:397
-        h.score = 0.0;
-        h.sample_slot = slot_base + t;
-        h.orientation = oi;
-        h.half_antipodal = (label >= 1) ? 1 : 0;                      // hand_search.cpp:417-418
-        h.full_antipodal = (label == 2) ? 1 : 0;
-        h.reserved = 0;
-        h.n_points = P;
-        // pruneGraspsOnHandParameters, grasp_detector.cpp:363-395
-        bool keep = !(hc.filter_half && !h.half_antipodal);
-        if (keep) {
-          const double hw = 0.5 * hc.hand_outer_diameter;
-          double mn[3], mx[3];
-          for (int a = 0; a < 3; a++) {
-            const double c5[5] = {h.bottom[a] + hw * h.binormal[a], h.bottom[a] - hw * h.binormal[a],
-                                  h.top[a] + hw * h.binormal[a], h.top[a] - hw * h.binormal[a],
-                                  h.bottom[a] - 0.10 * h.approach[a]};
-            mn[a] = mx[a] = c5[0];
-            for (int k = 1; k < 5; k++) {
-              mn[a] = (c5[k] < mn[a]) ? c5[k] : mn[a];
-              mx[a] = (c5[k] > mx[a]) ? c5[k] : mx[a];
-            }
-          }
-          keep = h.width >= hc.min_aperture && h.width <= hc.max_aperture &&
-                 mn[2] >= (double)cloud_min_z && mn[1] >= (double)hc.ws_min_y &&
-                 mx[1] <= (double)hc.ws_max_y && mn[0] >= (double)hc.ws_min_x &&
-                 mx[0] <= (double)hc.ws_max_x;
-        }
-        A.table[slot] = h;
-        A.tab_off[slot] = off;
-        A.tab_keep[slot] = keep ? 1 : 4;  // slot state: 0 empty, 1 survives the prune, 4 pruned away
-        atomicAdd(&A.st->n_hyp, 1u);
-        atomicAdd(&A.st->sum_p, (unsigned long long)P);
-        atomicMax(&A.st->max_p, (unsigned)P);
-      }
-      AG2_PROF(6);
     }
     AG2_PROF(7);
   }
@@ -1672,36 +1349,21 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   }
   const size_t lds = sweep_lds_bytes(0);
   typedef void (*SweepFn)(SweepArgs);
-  // one-kernel sweep (AG2_SWEEP_MONO=1, A/B) or split at the gates (default)
-  static const bool split = getenv("AG2_SWEEP_MONO") == nullptr;
-  const SweepFn fn_lds = split ? ((R <= 8) ? k_sweep<0, 8, true> : (R <= 16 ? k_sweep<0, 16, true> : k_sweep<0, 32, true>))
-                               : ((R <= 8) ? k_sweep<0, 8, false> : (R <= 16 ? k_sweep<0, 16, false> : k_sweep<0, 32, false>));
-  const SweepFn fn_glb = split ? ((R <= 8) ? k_sweep<1, 8, true> : (R <= 16 ? k_sweep<1, 16, true> : k_sweep<1, 32, true>))
-                               : ((R <= 8) ? k_sweep<1, 8, false> : (R <= 16 ? k_sweep<1, 16, false> : k_sweep<1, 32, false>));
-  if (split) {
-    if (c->list_ints == 0)  // 16 Mi points = 256 MiB, grown on demand (debug_flags bit 1: start tiny, to exercise that)
-      c->list_ints = (c->p.debug_flags & 2) ? (size_t)4096 : (size_t)16 << 20;
-    AG2_HIP(c, c->d_lists.reserve(c->list_ints * 16));
-    AG2_HIP(c, c->d_pairs.reserve(std::max<size_t>(n_slots, 1) * sizeof(SweepPair)));
-    A.lists = c->d_lists.as<float4>();
-    A.list_cap = (long long)c->list_ints;
-    A.pairs = c->d_pairs.as<SweepPair>();
-  }
+  const SweepFn fn_lds = (R <= 8) ? k_sweep<0, 8> : (R <= 16 ? k_sweep<0, 16> : k_sweep<0, 32>);
+  const SweepFn fn_glb = (R <= 8) ? k_sweep<1, 8> : (R <= 16 ? k_sweep<1, 16> : k_sweep<1, 32>);
+  if (c->list_ints == 0)  // 16 Mi points = 256 MiB, grown on demand (debug_flags bit 1: start tiny, to exercise that)
+    c->list_ints = (c->p.debug_flags & 2) ? (size_t)4096 : (size_t)16 << 20;
+  AG2_HIP(c, c->d_lists.reserve(c->list_ints * 16));
+  AG2_HIP(c, c->d_pairs.reserve(std::max<size_t>(n_slots, 1) * sizeof(SweepPair)));
+  A.lists = c->d_lists.as<float4>();
+  A.list_cap = (long long)c->list_ints;
+  A.pairs = c->d_pairs.as<SweepPair>();
   const int grid = (int)std::min<size_t>(s, 256 * kStage0WgPerCu);
-  // first stage: one workgroup per sample, or -- AG2_SWEEP_WAVE=1 -- one wave per sample
-  // (k_sweep_wave.hip: the same results; measured slower at configuration 2)
-  static const bool use_wave = getenv("AG2_SWEEP_WAVE") != nullptr;
-  if (use_wave) {
-    AG2_HIP(c, c->d_gpos.reserve(sweep_wave_gpos_ints(1024) * 4));
-    A.gpos = c->d_gpos.as<int>();
-    const int rc = launch_sweep_wave(c, A, s, R);
-    if (rc) return rc;
-  } else {
-    AG2_HIP(c, c->d_gpos.reserve((size_t)256 * kStage0WgPerCu * kGposCap * 6));
-    A.gpos = c->d_gpos.as<int>();
-    hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads0), lds, c->stream, A);
-    AG2_HIP(c, hipGetLastError());
-  }
+  // first stage: one workgroup per sample
+  AG2_HIP(c, c->d_gpos.reserve((size_t)256 * kStage0WgPerCu * kGposCap * 6));
+  A.gpos = c->d_gpos.as<int>();
+  hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads0), lds, c->stream, A);
+  AG2_HIP(c, hipGetLastError());
   AG2_HIP(c, stage_event(c, 2));
   if (want_prof) {
     unsigned long long h[8];
@@ -1718,12 +1380,11 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   // (default: four workgroups per CU x 5 x 64 Ki words = 1.3 GB of scratch; run_hypotheses resizes
   // it when a list of the run is longer)
   const int gcap = c->sweep_gcap, g2 = c->sweep_g2;
-  if (!split) AG2_HIP(c, c->d_gscratch.reserve((size_t)g2 * 5 * (size_t)gcap * 4));  // (split: lists go to the arena)
   A.gscratch = c->d_gscratch.as<float>();
   A.gcap = gcap;
   hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads1), sweep_lds_bytes(1), c->stream, A);
   AG2_HIP(c, hipGetLastError());
-  if (split) {
+  {
     const int rc = launch_sweep_orient(c, A, n_slots);
     if (rc) return rc;
   }

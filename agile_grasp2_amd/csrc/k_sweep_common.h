@@ -143,8 +143,5 @@ __device__ __forceinline__ void tighten_row(const GridDesc& G, const HandConst& 
 
 // k_sweep_orient.hip
 int launch_sweep_orient(ag2_ctx* c, const SweepArgs& A, size_t n_slots);
-// k_sweep_wave.hip
-size_t sweep_wave_gpos_ints(int grid);
-int launch_sweep_wave(ag2_ctx* c, const SweepArgs& A, size_t s, int R);
 
 }  // namespace ag2

@@ -1069,7 +1069,9 @@ std::vector<GraspHypothesis> GraspDetector::detectImpl(const CloudCamera& cloud_
           if (sel) recs[m++] = recs[h];
         }
         n = m;
-        if (min_inliers > 0 && n) {  // 4. grasp clusters, :228-236
+        // antipodal_mode NONE returns the pruned hypotheses as they are -- no clustering, no top-k
+        // (grasp_detector.cpp:170-176 returns hands_filtered before steps 4 and 5)
+        if (p_.antipodal_mode != NONE && min_inliers > 0 && n) {  // 4. grasp clusters, :228-236
           std::vector<ag2_hypothesis> clustered(n);
           size_t k = 0;
           rc = ag2_find_clusters(c, recs.data(), n, min_inliers, clustered.data(), n, &k);

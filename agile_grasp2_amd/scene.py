@@ -158,15 +158,18 @@ def draw_samples(seed: int, n_points: int, num_samples: int) -> np.ndarray:
     return np.sort(rng.choice(n_points, size=k, replace=False)).astype(np.int32)
 
 
-def make_stream(seed: int, n_target: int, n_frames: int, motion: float = 0.004, voxel: float = VOXEL,
-                noise: float = 0.001):
+def make_stream(seed: int, n_target: int, n_frames: int, motion: float = 0.004, voxel: float | None = VOXEL,
+                noise: float = 0.001, spacing: float = 0.0015):
     """BASELINE.json configuration 5: n_frames clouds of ONE tabletop scene whose objects drift by
     about `motion` metres per frame (each object its own direction in the table plane), seen by the
     same camera with fresh sensor noise every frame, voxelised like make_scene.  Returns
-    (list of xyz float32 [N_k, 3], workspace[6]); N_k is within one per cent of n_target."""
+    (list of xyz float32 [N_k, 3], workspace[6]); N_k is within one per cent of n_target.
+    voxel=None: the RAW frames of the sensor (mean sample spacing `spacing`, n_target raw points) -- what
+    ag2_detect_frame_raw takes; 765 000 raw points at 1.5 mm give about 300 000 voxels of 3 mm."""
     rng = np.random.default_rng(seed)
-    per_pt = voxel * voxel
-    density = 4.0 / per_pt
+    cell = spacing if voxel is None else voxel
+    per_pt = cell * cell
+    density = (4.0 if voxel is not None else 1.05) / per_pt
     area_table = 0.55 * n_target * per_pt
     asp = 1.5
     wx = max(np.sqrt(max(area_table, 1e-4) / asp), 0.25)
@@ -196,7 +199,7 @@ def make_stream(seed: int, n_target: int, n_frames: int, motion: float = 0.004, 
         p = np.concatenate(chunks)
         frng = np.random.default_rng([seed, f, 7])
         p = p + frng.normal(scale=noise, size=p.shape)
-        cloud = voxelize(p.astype(np.float32), voxel)
+        cloud = voxelize(p.astype(np.float32), voxel) if voxel is not None else p.astype(np.float32)
         # as make_scene: a random subset brings the count to the target -- here the target +- 0.7 %,
         # a different count every frame
         want = n_target + (f * 7919) % (n_target // 70 + 1) - n_target // 140

@@ -89,6 +89,11 @@ typedef struct ag2_counters {
   int64_t n_overflow_samples;                /* samples whose cropped list did not fit the first sweep stage */
   int64_t list_points;                       /* split sweep: room taken in the list arena, points of 16 B (long lists
                                                 reserve their candidate count, about 1.7 x their length) */
+  int64_t detect_one_trip;                   /* ag2_detect calls of this context served in ONE host round trip (tail
+                                                launched at the shapes the previous call left) ... */
+  int64_t detect_redone;                     /* ... and those whose shapes did not hold (more images, a larger
+                                                in-box list, a buffer too small) and that ran again step by step.
+                                                Both are per context, not per cloud. */
 } ag2_counters;
 
 /* Device time of the last call per stage, milliseconds (HIP events on the context's stream).
@@ -217,17 +222,37 @@ int ag2_stream_configure(ag2_ctx* c, size_t max_points, size_t max_samples, int 
 int ag2_detect_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
                      const int32_t* sample_idx, size_t s, uint64_t seed, int do_prune,
                      ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored);
+/* The same, one step earlier: a frame of the RAW sensor cloud.  Replaces, per frame,
+ * GraspDetector::preprocessPointCloud (grasp_detector.cpp:285-335: CloudCamera::filterWorkspace,
+ * cloud_camera.cpp:89-121 -- bounds = ag2_params.workspace, when filter_workspace != 0 --, voxelizeCloud
+ * :124-168 with voxel_size, subsampleUniformly :171-178 with num_samples and sample_seed) followed by
+ * GraspDetector::detectGraspPoses (:84-282), i.e. what the node does for a cloud it loads
+ * (grasp_detection_node.cpp:97-121) and what a live topic has to do for every frame (:123-143).
+ * Same results byte for byte as ag2_preprocess_cloud_device + ag2_subsample_uniformly (indices left on the
+ * device) + ag2_compute_normals + ag2_detect.  Filter, voxel grid and sub-sampling run on the device inside
+ * the captured sequence: the processed cloud, the search grid and the sample indices never leave HBM and
+ * the host synchronises once per frame.  A frame with no more voxels than num_samples (every point becomes
+ * a sample, grasp_detector.cpp:322-330) and any frame that outgrows the shapes run step by step.
+ * n_voxels (may be NULL): size of the processed cloud, which is the context's cloud afterwards
+ * (ag2_get_cloud, ag2_get_normals; ag2_get_samples for the indices drawn). */
+int ag2_detect_frame_raw(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                         int filter_workspace, double voxel_size, size_t num_samples, uint64_t sample_seed,
+                         uint64_t seed, int do_prune, ag2_hypothesis* selected, size_t cap,
+                         size_t* n_selected, size_t* n_scored, size_t* n_voxels);
 int ag2_get_frame_info(ag2_ctx* c, ag2_frame_info* out);
 
 int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes);
 /* Multi-GPU merge of the detect results (no counterpart in the single-process reference; this is the
  * step grasp_detector.cpp:239-252 -- top num_selected by score -- becomes when the samples are sharded):
- * ag2_export_selected_compact_device leaves what the last ag2_detect selected FROM (scored records
- * with score >= min_score_diff, after the clustering if it is on; list order) in d_dst as a 16-byte
- * header {count, cap, 0, 0} + min(count, cap) records; the ranks all-gather these buffers (RCCL) and
- * every rank calls ag2_merge_selected_device on the gathered world x (16 + cap x 176) bytes: the
- * lists concatenated in rank order (= sample order) and the top num_selected by score, ties by
- * position.  n_total (may be NULL): records that took part. */
+ * ag2_export_selected_compact_device leaves the scored records of the last ag2_detect with score >=
+ * min_score_diff (list order; BEFORE the clustering, also when ag2_set_min_inliers > 0) in d_dst as a
+ * 16-byte header {count, cap, 0, 0} + min(count, cap) records; the ranks all-gather these buffers
+ * (RCCL) and every rank calls ag2_merge_selected_device on the gathered world x (16 + cap x 176)
+ * bytes: the lists concatenated in rank order (= sample order), then -- when ag2_set_min_inliers > 0 --
+ * HandleSearch::findClusters over the WHOLE gathered list (handle_search.cpp:4-80 counts inliers over
+ * all hands, whichever rank found them; grasp_detector.cpp:228-236), then the top num_selected by
+ * score, ties by position.  n_total (may be NULL): records that took part (before the clustering).
+ * A header whose count exceeds cap (a rank's list was cut) makes the merge return AG2_ERR_CAPACITY. */
 int ag2_export_selected_compact_device(ag2_ctx* c, void* d_dst, size_t bytes, size_t cap_records);
 /* (ag2_detect with selected == NULL and cap == 0 skips the local read-back and top-k and returns with the
  * tail of the pipeline still queued: what a rank calls when the merge follows.) */
@@ -288,6 +313,10 @@ int ag2_get_cloud(ag2_ctx* c, float* xyz_nx3, int32_t* cam_source, size_t cap, s
  * s <= *n_out uses the first s of them.  idx_out may be NULL. */
 int ag2_subsample_uniformly(ag2_ctx* c, size_t num_samples, uint64_t seed, int32_t* idx_out,
                             size_t cap, size_t* n_out);
+
+/* CloudCamera::getSampleIndices of the indices the device drew last (ag2_subsample_uniformly,
+ * ag2_detect_frame_raw) and still holds: *n of them, ascending. */
+int ag2_get_samples(ag2_ctx* c, int32_t* idx, size_t cap, size_t* n);
 
 /* ---- the step behind the scoring: HandleSearch::findClusters(hand_list, remove_inliers = false),
  * handle_search.cpp:4-80 ----

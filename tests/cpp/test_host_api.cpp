@@ -189,7 +189,53 @@ static int run_constants(const char* out_path) {
   return 0;
 }
 
+// test_host_api --modes cloud.f32 idx.i32 params.txt out.bin: GraspDetector::detectGraspPoses in the
+// antipodal_mode / min_inliers the parameter file gives (grasp_detector.cpp:163-252: NONE returns the
+// pruned hypotheses before the clustering and the selection, GEOMETRIC keeps the full-antipodal ones,
+// clusters them when min_inliers > 0 and takes num_selected).  Output: int64 n, then per hand
+// {int32 slot, int32 orientation, int32 full_antipodal, int32 half_antipodal, double score, double bottom[3]}.
+static int run_modes(const char* cloud_path, const char* idx_path, const char* params_path, const char* out_path) {
+  const std::vector<float> xyz = read_all<float>(cloud_path);
+  const std::vector<int32_t> idx = read_all<int32_t>(idx_path);
+  std::ifstream pf(params_path);
+  const std::string ptext((std::istreambuf_iterator<char>(pf)), std::istreambuf_iterator<char>());
+  GraspDetector::Params prm;
+  std::string err;
+  if (!GraspDetector::Params::fromKeyValueText(ptext, &prm, &err)) {
+    fprintf(stderr, "params: %s\n", err.c_str());
+    return 2;
+  }
+  PointCloudRGB::Ptr cloud(new PointCloudRGB);
+  cloud->points.resize(xyz.size() / 3);
+  for (size_t i = 0; i < cloud->size(); i++) {
+    cloud->points[i].x = xyz[3 * i];
+    cloud->points[i].y = xyz[3 * i + 1];
+    cloud->points[i].z = xyz[3 * i + 2];
+  }
+  CloudCamera cc(cloud, (int)cloud->size());
+  cc.setSampleIndices(std::vector<int>(idx.begin(), idx.end()));
+  GraspDetector det(prm);
+  const std::vector<GraspHypothesis> hands = det.detectGraspPoses(cc);
+  if (!det.lastError().empty()) {
+    fprintf(stderr, "detect: %s\n", det.lastError().c_str());
+    return 3;
+  }
+  std::ofstream out(out_path, std::ios::binary);
+  const int64_t n = (int64_t)hands.size();
+  put(out, &n, 1);
+  for (const GraspHypothesis& h : hands) {
+    const int32_t ids[4] = {h.getSampleSlot(), h.getOrientation(), h.isFullAntipodal() ? 1 : 0,
+                            h.isHalfAntipodal() ? 1 : 0};
+    put(out, ids, 4);
+    const double v[4] = {h.getScore(), h.getGraspBottom()(0), h.getGraspBottom()(1), h.getGraspBottom()(2)};
+    put(out, v, 4);
+  }
+  printf("modes ok: mode %d, min_inliers %d, %lld hands\n", prm.antipodal_mode, prm.min_inliers, (long long)n);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 6 && std::string(argv[1]) == "--modes") return run_modes(argv[2], argv[3], argv[4], argv[5]);
   if (argc == 3 && std::string(argv[1]) == "--constants") return run_constants(argv[2]);
   if (argc == 5 && std::string(argv[1]) == "--preprocess") return run_preprocess(argv[2], argv[3], argv[4]);
   if (argc == 4 && std::string(argv[1]) == "--caffemodel") return run_caffemodel(argv[2], argv[3]);

@@ -46,7 +46,7 @@ def test_struct_layouts_match_header(built):
     assert ctypes.sizeof(capi.Params) == ctypes.sizeof(api.Params)
     # ag2_params: 9 doubles, 4 int32, 2x3 + 6 doubles, 3 doubles, 2 int32
     assert ctypes.sizeof(capi.Params) == 9 * 8 + 4 * 4 + 6 * 8 + 6 * 8 + 3 * 8 + 2 * 4
-    assert ctypes.sizeof(capi.Counters) == 14 * 8
+    assert ctypes.sizeof(capi.Counters) == 16 * 8
     assert ctypes.sizeof(capi.Times) == 12 * 4
     p = capi.default_params()
     assert p.finger_width == 0.01 and p.hand_outer_diameter == 0.09 and p.num_orientations == 8

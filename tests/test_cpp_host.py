@@ -191,6 +191,55 @@ def test_cpp_host_matches_oracle(tmp_path, small_scene, weights_format):
         assert abs(f[1] - np.float32(h["score"])) <= 2 * tol
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,min_inliers", [(0, 0), (0, 1), (2, 0), (2, 1)])
+def test_cpp_detect_modes_none_and_geometric(tmp_path, small_scene, mode, min_inliers):
+    """GraspDetector::detectGraspPoses with antipodal_mode NONE / GEOMETRIC (grasp_detector.cpp:163-252).
+    NONE returns the pruned hypotheses as they are -- BEFORE the clustering and the selection (:170-176),
+    whatever min_inliers says; GEOMETRIC keeps the full-antipodal ones (:214-221), clusters them when
+    min_inliers > 0 (:228-236) and takes the first num_selected (scores are all equal: list order)."""
+    from oracle import api
+    tmp = str(tmp_path)
+    exe = build_driver(tmp)
+    xyz, ws, idx = small_scene
+    xyz.astype("<f4").tofile(os.path.join(tmp, "cloud.f32"))
+    idx.astype("<i4").tofile(os.path.join(tmp, "idx.i32"))
+    seed, num_selected = 5, 7
+    text = params_text(ws, "", "", seed).replace("antipodal_mode = 1", f"antipodal_mode = {mode}")
+    text = text.replace("num_selected = 1000", f"num_selected = {num_selected}") + f"min_inliers = {min_inliers}\n"
+    open(os.path.join(tmp, "params.txt"), "w").write(text)
+    outp = os.path.join(tmp, "out.bin")
+    r = subprocess.run([exe, "--modes", os.path.join(tmp, "cloud.f32"), os.path.join(tmp, "idx.i32"),
+                        os.path.join(tmp, "params.txt"), outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert f"modes ok: mode {mode}, min_inliers {min_inliers}" in r.stdout
+
+    o = api.Oracle(**dict(scene_params(ws, min_score_diff=-1e30, num_selected=num_selected), num_threads=4))
+    o.set_cloud(xyz)
+    o.compute_normals()
+    hyps = o.generate_hypotheses(sample_idx=idx, seed=seed)
+    keep = o.prune(len(hyps)).astype(bool)
+    want = hyps[keep]
+    assert len(want) > num_selected
+    if mode == 2:
+        want = want[want["full_antipodal"] == 1]
+        assert len(want) > 0
+        if min_inliers > 0:
+            want = o.find_clusters(want, min_inliers)
+        want = want[:num_selected]
+    rec = np.frombuffer(open(outp, "rb").read(), dtype=np.dtype(
+        [("slot", "<i4"), ("orient", "<i4"), ("full", "<i4"), ("half", "<i4"), ("score", "<f8"), ("bottom", "<f8", 3)]),
+        offset=8)
+    (n,) = struct.unpack_from("<q", open(outp, "rb").read(), 0)
+    assert n == len(rec) == len(want) and n > 0
+    assert np.array_equal(rec["slot"], want["sample_slot"])       # same hands in the same order
+    assert np.array_equal(rec["orient"], want["orientation"])
+    assert np.array_equal(rec["full"], want["full_antipodal"])
+    assert np.array_equal(rec["half"], want["half_antipodal"])
+    assert np.array_equal(rec["bottom"], want["bottom"])          # (moved by the clustering where it ran)
+    assert np.array_equal(rec["score"], want["score"])
+
+
 def test_launch_xml_and_keyvalue_readers(tmp_path):
     """Params readers accept the reference's own launch file text (parameter NAMES are the
     contract; the file is read at test time from /root/reference when present, else a literal

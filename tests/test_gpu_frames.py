@@ -123,3 +123,128 @@ def test_device_resident_frames():
     hip.hipFree(dptr)
     df.close()
     ds.close()
+
+
+# ---- frames of the RAW sensor cloud: ag2_detect_frame_raw (filter + voxel grid + sub-sampling inside) ----
+REC_FIELDS = ("sample_slot", "orientation", "half_antipodal", "full_antipodal", "n_points", "axis",
+              "approach", "binormal", "surface", "bottom", "top", "width")
+
+
+def _oracle_raw_frame(o, raw, num_samples, sample_seed, seed, do_prune=True):
+    """GraspDetector::preprocessPointCloud + detectGraspPoses on the oracle (grasp_detector.cpp:285-335, :84-282)."""
+    m = o.preprocess_cloud(raw, voxel_size=scene.VOXEL)
+    cloud, _ = o.get_cloud()
+    idx = o.subsample_uniformly(num_samples, seed=sample_seed)
+    o.compute_normals()
+    sel, allh = o.detect(sample_idx=idx, seed=seed, do_prune=do_prune)
+    return m, cloud, idx, sel, allh
+
+
+def check_raw_frame_against_oracle(got, n_scored, n_vox, d, oracle_out, tag=""):
+    """every scored record of a frame (the detector selects everything: num_selected < 0, no threshold)
+    against the oracle's: bytes of every field but the score, scores within the LeNet tolerance; the
+    processed cloud and the drawn sample indices byte-equal."""
+    m, cloud, idx, _, allh = oracle_out
+    assert n_vox == m, (tag, n_vox, m)
+    assert n_scored == len(allh) == len(got), (tag, n_scored, len(allh), len(got))
+    gx, _ = d.get_cloud()
+    assert gx.tobytes() == cloud.tobytes(), tag
+    assert np.array_equal(d.get_samples(), idx), tag
+    if len(allh) == 0:
+        return 0.0
+    kg = np.lexsort((got["orientation"], got["sample_slot"]))
+    kw = np.lexsort((allh["orientation"], allh["sample_slot"]))
+    g, w = got[kg], allh[kw]
+    for f in REC_FIELDS:
+        assert np.array_equal(g[f], w[f]), (tag, f)
+    tol = 2e-4 * np.abs(w["score"]).max() + 2e-3
+    assert np.abs(g["score"] - w["score"]).max() <= tol, tag
+    assert np.all(np.diff(got["score"]) <= 0), tag     # the frame's own order: score descending
+    return tol
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_raw_frames_equal_the_oracle_and_the_stepwise_path(use_graph):
+    from agile_grasp2_amd import capi
+    from oracle import api
+    frames = [scene.make_scene(seed=40 + k, n_target=50000 + 977 * (k % 3), voxel=None, spacing=0.0015)
+              for k in range(6)]
+    ws = np.array(frames[0][1], dtype=np.float64)
+    ws[1] -= 0.03   # the workspace filter has something to cut (a strip of the table)
+    ws[3] -= 0.02
+    prm = scene_params(ws, min_score_diff=-1e30, num_selected=-1)
+    w = make_lenet_weights(7)
+    df, ds = capi.Detector(**prm), capi.Detector(**prm)
+    o = api.Oracle(**dict(prm, num_threads=8))
+    for x in (df, ds, o):
+        x.lenet_load(w)
+    df.stream_configure(0, 0, use_graph)
+    ns, total = 250, 0
+    for k, (raw, _) in enumerate(frames):
+        got, n_sc, n_vox = df.detect_frame_raw(raw, num_samples=ns, sample_seed=100 + k, seed=k)
+        assert 0 < n_vox < raw.shape[0]
+        # the step-by-step calls on a second context: same bytes
+        m = ds.preprocess_cloud(raw, voxel_size=scene.VOXEL)
+        k_s = ds.subsample_uniformly(ns, seed=100 + k, want_indices=False)
+        ds.compute_normals()
+        want, wn = ds.detect(n_resident=k_s, seed=k, do_prune=True, want_all=False)
+        assert m == n_vox and wn == n_sc and got.tobytes() == want.tobytes(), k
+        check_raw_frame_against_oracle(got, n_sc, n_vox, df, _oracle_raw_frame(o, raw, ns, 100 + k, k), tag=k)
+        total += n_sc
+    assert total > 100
+    fi = df.frame_info()
+    assert fi.frames == 6 and fi.stepwise_runs == 1 and fi.fallbacks == 0, [(f, getattr(fi, f)) for f, _ in fi._fields_]
+    if use_graph:
+        assert fi.captures == 1 and fi.graph_replays == 4 and fi.plain_runs == 1 and fi.capture_failed == 0
+    else:
+        assert fi.graph_replays == 0 and fi.plain_runs == 5
+    # the context is left as after preprocess + subsample + normals + detect of the last frame
+    assert np.array_equal(df.get_normals().view(np.uint64), ds.get_normals().view(np.uint64))
+    for x in (df, ds):
+        x.close()
+
+
+def test_raw_frames_that_leave_the_shapes():
+    """a raw frame with more points, a frame whose lattice outgrows the bitmap (an object far above the
+    scene), a cloud with fewer voxels than num_samples (every point is a sample, grasp_detector.cpp:322-330),
+    a switch between the two entry points: each runs step by step (or is repeated so) with the same bytes."""
+    from agile_grasp2_amd import capi
+    small = [scene.make_scene(seed=60 + k, n_target=30000, voxel=None, spacing=0.0015) for k in range(3)]
+    big, _ = scene.make_scene(seed=70, n_target=90000, voxel=None, spacing=0.0015)
+    ws = np.array(small[0][1], dtype=np.float64)
+    ws[5] = 5.0
+    tall = np.concatenate([small[1][0], small[1][0][:2000] + np.float32([0.0, 0.0, 2.5])]).astype(np.float32)
+    tiny = small[2][0][::400].copy()
+    prm = scene_params(ws, min_score_diff=-1e30, num_selected=40)
+    w = make_lenet_weights(7)
+    df, ds = capi.Detector(**prm), capi.Detector(**prm)
+    for x in (df, ds):
+        x.lenet_load(w)
+    ns = 150
+    seq = [small[0][0], small[1][0], small[2][0], big, small[0][0], tall, small[1][0], tiny, small[2][0]]
+    for k, raw in enumerate(seq):
+        got, n_sc, n_vox = df.detect_frame_raw(raw, num_samples=ns, sample_seed=7, seed=k)
+        m = ds.preprocess_cloud(raw, voxel_size=scene.VOXEL)
+        k_s = ds.subsample_uniformly(ns, seed=7, want_indices=False)
+        ds.compute_normals()
+        want, wn = ds.detect(n_resident=k_s, seed=k, do_prune=True, want_all=False)
+        assert m == n_vox and wn == n_sc and got.tobytes() == want.tobytes(), k
+        assert np.array_equal(df.get_samples(), ds.get_samples()), k
+    fi = df.frame_info()
+    assert fi.fallbacks >= 1 and fi.graph_replays >= 2 and fi.stepwise_runs >= 4, [(f, getattr(fi, f)) for f, _ in fi._fields_]
+    # the other entry point on the same context, and back
+    xyz, _, idx = _clouds(1, 9000, 100)[0]
+    ds2 = capi.Detector(**prm)
+    ds2.lenet_load(w)
+    for k in range(3):
+        got, gn = df.detect_frame(xyz, idx, seed=k)
+        want, wn = _stepwise(ds2, xyz, idx, seed=k)
+        assert gn == wn and got.tobytes() == want.tobytes(), k
+    got, n_sc, n_vox = df.detect_frame_raw(small[0][0], num_samples=ns, sample_seed=7, seed=0)
+    m = ds.preprocess_cloud(small[0][0], voxel_size=scene.VOXEL)
+    k_s = ds.subsample_uniformly(ns, seed=7, want_indices=False)
+    ds.compute_normals()
+    want, wn = ds.detect(n_resident=k_s, seed=0, do_prune=True, want_all=False)
+    assert m == n_vox and wn == n_sc and got.tobytes() == want.tobytes()
+    for x in (df, ds, ds2):
+        x.close()

@@ -124,3 +124,117 @@ def test_cfg3_full_size_hypotheses_match_oracle():
         wp, wq = o.hyp_points(k, p)
         assert np.array_equal(gp, wp) and np.array_equal(gq, wq, equal_nan=True), k
     d.close()
+
+
+def test_cfg5_stream_size_raw_frames_match_oracle():
+    """BASELINE.json configuration 5 at ITS size: frames of ~765 000 raw points (~300 000 voxels of 3 mm),
+    2 000 samples per frame, 8 orientations, the per-frame pipeline captured in a hipGraph and started from
+    the RAW cloud (ag2_detect_frame_raw: workspace filter + voxel grid + uniform sub-sampling on the device).
+    EVERY frame -- the step-by-step first one, the fixed-shape one and all graph replays -- against the
+    oracle's preprocess_cloud -> subsample_uniformly -> compute_normals -> detect
+    (grasp_detector.cpp:285-335, cloud_camera.cpp:89-178, grasp_detection_node.cpp:123-143): processed cloud
+    and sample indices byte-equal, every scored record byte-equal apart from the score, scores within
+    2e-4 * max|score| + 2e-3."""
+    import bench
+    from agile_grasp2_amd import capi
+    from oracle import api
+    from test_gpu_frames import _oracle_raw_frame, check_raw_frame_against_oracle
+    n_points, S, R, _, _ = bench.CONFIGS["cfg5"]
+    n_frames = 12
+    raws, ws = scene.make_stream(1, int(2.55 * n_points), n_frames, voxel=None)
+    prm = _bench_params(ws, R, min_score_diff=-1e30, num_selected=-1)
+    w = make_lenet_weights(7)
+    d = capi.Detector(**prm)
+    o = api.Oracle(**dict(prm, num_threads=16))
+    for x in (d, o):
+        x.lenet_load(w)
+    d.stream_configure(0, 0, True)
+    scored = 0
+    for k, raw in enumerate(raws):
+        got, n_sc, n_vox = d.detect_frame_raw(raw, num_samples=S, sample_seed=1000 + k, seed=k)
+        assert abs(n_vox - n_points) <= 0.03 * n_points, n_vox
+        check_raw_frame_against_oracle(got, n_sc, n_vox, d, _oracle_raw_frame(o, raw, S, 1000 + k, k), tag=k)
+        scored += n_sc
+    assert scored > 100 * n_frames
+    fi = d.frame_info()
+    assert fi.frames == n_frames and fi.stepwise_runs == 1 and fi.fallbacks == 0 and fi.captures == 1
+    assert fi.graph_replays == n_frames - 2, [(f, getattr(fi, f)) for f, _ in fi._fields_]
+    d.close()
+
+
+def test_cfg4_eight_tiles_of_the_cfg2_cloud_match_the_unsplit_oracle():
+    """BASELINE.json configuration 4 at full size on ONE GPU: the 300 000-point cfg2 cloud cut into 8
+    spatial tiles (sharding.tile_points, cut on the samples' neighbour counts), 5 000 samples per tile as
+    `bench.py --gpus 8` gives every rank, each tile run in turn; ag2_export_selected_compact_device of every
+    tile -> concatenation (what the RCCL all-gather leaves) -> ag2_merge_selected_device.  Against the UNSPLIT
+    oracle over all 40 000 samples: every scored record of every tile byte-equal apart from the score
+    (hand_search.cpp:194-228: samples are independent, results concatenate in sample order), the merged
+    top-30 equal to the oracle's selection (grasp_detector.cpp:239-252) unless a score sits within the LeNet
+    tolerance of the threshold or of the cut."""
+    import ctypes as C
+    import bench
+    from agile_grasp2_amd import capi, sharding
+    from oracle import api
+    world = 8
+    n_points, S, R, _, kind = bench.CONFIGS["cfg2"]
+    xyz, ws = scene.make_scene(1, n_points, kind=kind, voxel=scene.VOXEL)
+    prm = _bench_params(ws, R)
+    axis = sharding.longest_axis(xyz)
+    ordered = sharding.order_samples_by_x(xyz, scene.draw_samples(1, xyz.shape[0], S * world), axis)
+    halo = sharding.tile_halo(prm["nn_radius_hands"], prm["nn_radius_taubin"], 0.01)
+    bounds = sharding.balanced_bounds(sharding.sample_costs(xyz, ordered, prm["nn_radius_hands"], axis), world)
+    origin = sharding.cloud_origin(xyz)
+    w = make_lenet_weights(7)
+    o = api.Oracle(**dict(prm, num_threads=16))
+    o.set_cloud(xyz)
+    o.compute_normals()
+    o.lenet_load(w)
+    osel, oall = o.detect(sample_idx=ordered, seed=1, do_prune=True)
+    assert len(oall) > 4000
+    tol = 2e-4 * np.abs(oall["score"]).max() + 2e-3
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    cap = 4096
+    per = sharding.compact_bytes(cap)
+    dbuf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dbuf), per * world) == 0
+    d = capi.Detector(**prm)
+    d.lenet_load(w)
+    d.set_grid_origin(origin)
+    pos = 0
+    for rank in range(world):
+        keep, local, base = sharding.tile_points(xyz, ordered, rank, world, halo, axis, bounds)
+        d.set_cloud(xyz[keep])
+        d.compute_normals()
+        _, tall = d.detect(sample_idx=local, slot_base=base, seed=1, do_prune=True)   # (with every scored record)
+        want = oall[pos: pos + len(tall)]
+        assert len(want) == len(tall) and (len(tall) == 0 or int(tall["sample_slot"].min()) >= base), rank
+        for f in REC_FIELDS:
+            assert np.array_equal(tall[f], want[f]), (rank, f)
+        assert len(tall) == 0 or np.abs(tall["score"] - want["score"]).max() <= tol, rank
+        pos += len(tall)
+        d.detect(sample_idx=local, slot_base=base, seed=1, do_prune=True, want_all=False, local_select=False)
+        d.export_selected_compact_device(dbuf.value + rank * per, per, cap)
+    assert pos == len(oall)
+    got, n_total = d.merge_selected_device(dbuf.value, world, cap)
+    thr = float(prm["min_score_diff"])
+    passing = oall["score"] >= thr
+    near_thr = np.abs(oall["score"] - thr).min() <= 2 * tol
+    srt = np.sort(oall["score"][passing])[::-1]
+    k = int(prm["num_selected"])
+    near_cut = len(srt) > k and abs(srt[k - 1] - srt[k]) <= 2 * tol
+    if not near_thr:
+        assert n_total == int(passing.sum())
+    assert len(got) == len(osel) == k
+    if not (near_thr or near_cut):
+        assert sorted(zip(got["sample_slot"], got["orientation"])) == sorted(zip(osel["sample_slot"], osel["orientation"]))
+    key = {(int(h["sample_slot"]), int(h["orientation"])): h for h in oall}
+    for h in got:   # whatever was selected is one of the oracle's records, field for field
+        ref = key[(int(h["sample_slot"]), int(h["orientation"]))]
+        for f in REC_FIELDS:
+            assert np.array_equal(h[f], ref[f]), f
+        assert abs(h["score"] - ref["score"]) <= tol
+    hip.hipFree(dbuf)
+    d.close()

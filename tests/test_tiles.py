@@ -175,8 +175,8 @@ def test_gpu_origin_above_a_point_is_an_error():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [1, 3])
-def test_merge_of_the_ranks_selected_lists_on_the_gpu(world):
+@pytest.mark.parametrize("world,min_inliers", [(1, 0), (3, 0), (1, 1), (3, 1)])
+def test_merge_of_the_ranks_selected_lists_on_the_gpu(world, min_inliers):
     """The multi-GPU merge (ag2_export_selected_compact_device on every rank, all-gather,
     ag2_merge_selected_device): the ranks' selected lists concatenated in rank order and the top
     num_selected by score, ties by position -- checked against the same merge done in numpy on the
@@ -217,22 +217,35 @@ def test_merge_of_the_ranks_selected_lists_on_the_gpu(world):
         d.set_grid_origin(sharding.cloud_origin(xyz))
         d.set_cloud(xyz[keep])
         d.compute_normals()
-        d.detect(sample_idx=local, slot_base=base, seed=3, do_prune=False, want_all=False)
+        d.set_min_inliers(min_inliers)
+        # a rank of a multi-GPU run (no local selection), or -- rank 0 -- a caller that also selects locally
+        d.detect(sample_idx=local, slot_base=base, seed=3, do_prune=False, want_all=False, local_select=rank == 0)
         d.export_selected_compact_device(dbuf.value + rank * per, per, cap)
         dets.append(d)
     raw = np.zeros(per * world, dtype=np.uint8)
     assert hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), dbuf, per * world, 2) == 0
     flat, cut = sharding.unpack_compact(raw, world, cap, capi.HYP_DTYPE)
     assert not cut and len(flat) > 17
-    order = sorted(range(len(flat)), key=lambda i: (-flat["score"][i], i))[:17]
-    want = flat[order]
+    pool = flat
+    if min_inliers > 0:
+        pool = api.Oracle(**prm).find_clusters(flat, min_inliers)
+        assert 0 < len(pool) <= len(flat)
+    order = sorted(range(len(pool)), key=lambda i: (-pool["score"][i], i))[:17]
+    want = pool[order]
     got, n_total = dets[0].merge_selected_device(dbuf.value, world, cap)
     assert n_total == len(flat) and got.tobytes() == want.tobytes()
+    # a rank's list longer than the exchange capacity voids the merge: an error, not a silent cut
+    small = max(1, int(raw[:4].view(np.uint32)[0]) // 2)
+    per_s = sharding.compact_bytes(small)
+    dets[0].export_selected_compact_device(dbuf.value, per_s, small)
+    with pytest.raises(RuntimeError, match="exchange capacity"):
+        dets[0].merge_selected_device(dbuf.value, 1, small)
     # the unsplit run selects from the same hypotheses
     d0 = capi.Detector(**prm)
     d0.lenet_load(w)
     d0.set_cloud(xyz)
     d0.compute_normals()
+    d0.set_min_inliers(min_inliers)
     sel0, all0 = d0.detect(sample_idx=ordered, seed=3, do_prune=False)
     thr_margin = np.abs(all0["score"] - thr).min()
     if thr_margin > 1e-2:
