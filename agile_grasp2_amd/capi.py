@@ -56,7 +56,8 @@ class Counters(C.Structure):
 class FrameInfo(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "frames", "graph_replays", "plain_runs", "stepwise_runs", "captures", "capture_failed",
-        "capture_refused", "fallbacks", "max_points", "max_samples", "max_cells", "max_images", "graph_ready")]
+        "capture_refused", "fallbacks", "max_points", "max_samples", "max_cells", "max_images", "graph_ready",
+        "last_fallback")]
 
 
 class Times(C.Structure):

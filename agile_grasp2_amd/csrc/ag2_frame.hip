@@ -413,6 +413,11 @@ int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, s
       if (fo->g.ncells == -2)
         return set_err(c, AG2_ERR_ARG, "a point lies below the grid origin given to ag2_set_grid_origin");
       f->info.fallbacks++;
+      f->info.last_fallback = (int64_t)(flags & (1u | 2u | 8u)) | (fo->g.ncells < 0 ? 16 : 0) |
+                              (fo->topk_overflow ? 32 : 0) |
+                              ((size_t)fo->st.n_list > std::min(f->cap_img, c->fm_s_max * (size_t)R) ? 64 : 0) |
+                              ((int)fo->st.max_p > render_capacity_for(f->cap_p) ? 128 : 0) |
+                              (in.raw ? ((int64_t)fo->pre.flags << 8) : 0);
       f->shapes_known = false;  // learn the shapes again from the step-by-step run below
       stepwise = true;
     } else {
@@ -506,10 +511,11 @@ int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, s
     c->fm_cap_cells = std::max<size_t>(c->fm_cap_cells, (size_t)cells);
     if (in.raw) {
       f->fs.raw_max = std::max(f->fs.raw_max, n + n / 8 + 1024);
-      // bitmap of the voxel lattice: this frame's with 16 voxels (48 mm at 3 mm) of room per axis, but
-      // never more than the workspace can hold when it filters
+      // bitmap of the voxel lattice: this frame's with half as much again (at least 16 voxels) of room per
+      // axis -- an object taller than anything seen so far must not cost a frame --, but never more than the
+      // workspace can hold when it filters
       double words = 1.0;
-      for (int a = 0; a < 3; a++) words *= (double)(c->last_vox_dims[a] + 16);
+      for (int a = 0; a < 3; a++) words *= (double)(c->last_vox_dims[a] + std::max(16, c->last_vox_dims[a] / 2));
       words = words / 32.0 + 2.0;
       if (in.filter_ws) {
         double wsw = 1.0;

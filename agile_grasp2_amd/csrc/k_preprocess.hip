@@ -323,7 +323,7 @@ __device__ __forceinline__ bool ws_keep(const float4& p, const WsBox& ws, int do
   return keep;
 }
 
-constexpr int kRawBlocks = 128;  // extent partials (one 32-B record per workgroup)
+constexpr int kRawBlocks = 512;  // extent partials (one 32-B record per workgroup): two waves per SIMD keep HBM busy
 
 // PACK: read the caller's strided buffer, write float4 (w = camera mask 1), pad [n, n_pad) with
 // non-finite points; else the float4 cloud is already in `raw`.  st (optional): cleared by block 0.
@@ -514,18 +514,41 @@ __global__ void __launch_bounds__(256) k_vox_emit_frame(const unsigned* __restri
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned bits0 = (w < words) ? bitmap[w] : 0u;
   const unsigned r0 = (w < words) ? wrank[w] : 0u;
-  const long long plane = (long long)v.dims[1] * v.dims[2];
+  // (ix, iy, iz) of the word's first voxel by division once per word (32-bit when the lattice allows);
+  // the set bits are then walked with carries: two 64-bit divisions per VOXEL were most of this kernel
+  int bx = 0, by = 0, bz = 0;
+  if (bits0) {
+    const long long plane = (long long)v.dims[1] * v.dims[2];
+    const long long key0 = (long long)w << 5;
+    if (((long long)words << 5) < (1ll << 31)) {
+      const unsigned k0 = (unsigned)key0, pl = (unsigned)plane, dz = (unsigned)v.dims[2];
+      bx = (int)(k0 / pl);
+      const unsigned rem = k0 - (unsigned)bx * pl;
+      by = (int)(rem / dz);
+      bz = (int)(rem - (unsigned)by * dz);
+    } else {
+      bx = (int)(key0 / plane);
+      const long long rem = key0 - (long long)bx * plane;
+      by = (int)(rem / v.dims[2]);
+      bz = (int)(rem - (long long)by * v.dims[2]);
+    }
+  }
   int my = 0;
   {
     unsigned bits = bits0, r = r0;
+    int ix = bx, iy = by, iz = bz, at = 0;
     while (bits) {
       const int b = __ffs((int)bits) - 1;
       bits &= bits - 1u;
-      const long long key = ((long long)w << 5) + b;
-      const int ix = (int)(key / plane);
-      const long long rem = key - (long long)ix * plane;
-      const int iy = (int)(rem / v.dims[2]);
-      const int iz = (int)(rem - (long long)iy * v.dims[2]);
+      iz += b - at;
+      at = b;
+      while (iz >= v.dims[2]) {
+        iz -= v.dims[2];
+        if (++iy >= v.dims[1]) {
+          iy = 0;
+          ix++;
+        }
+      }
       if (r < (unsigned)n_max)
         out[r] = make_float4((float)ix * v.cell + v.mn[0], (float)iy * v.cell + v.mn[1],
                              (float)iz * v.cell + v.mn[2], __int_as_float(1));
@@ -587,6 +610,10 @@ __global__ void __launch_bounds__(256) k_sel_candidates(int n, unsigned long lon
                                                         unsigned long long* __restrict__ cand_h,
                                                         unsigned* __restrict__ cand_i, unsigned cand_cap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    pf->thr = thr;
+    pf->n_vox = (unsigned)n;
+  }
   const unsigned long long h = (i < n) ? draw_u64(seed, kSubsampleStream, (uint64_t)i) : ~0ull;
   const int my = (i < n && h <= thr) ? 1 : 0;
   __shared__ unsigned s_base;
@@ -686,6 +713,192 @@ __global__ void __launch_bounds__(256) k_sel_emit(const unsigned long long* __re
   if (sel) out[pos] = (int)ij;
 }
 
+// ---- the usual case (candidate list <= 8192 entries): the whole selection in ONE workgroup, O(M) ----
+// The two kernels above cost M^2 compares (M ~ 2 400 for 2 000 samples: 80 + 25 us).  Hashes and indices are
+// both uniform, so linear buckets sort them: (1) 2048 buckets over the hash range [0, thr] locate the
+// bucket of the k-th smallest key, whose few members are ranked exactly; (2) the selected candidates are
+// bucketed by index, each bucket (about one entry) is put in order by its owner thread, and the list goes
+// out in ascending index order.  Same result as k_sel_rank + k_sel_emit.
+constexpr int kSelThreads = 1024;
+constexpr int kSelBins = 2048;
+constexpr int kSelCapMax = 8192;   // candidates this kernel takes (8 per thread)
+constexpr int kSelMembers = 128;   // members of the threshold bucket it can rank (expected: one or two)
+__device__ __forceinline__ unsigned sel_block_scan(unsigned v, unsigned* total, unsigned* wsum /* 16 words of LDS */) {
+  unsigned inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = (unsigned)__shfl_up((int)inc, o, 64);
+    if (lane_id() >= o) inc += t;
+  }
+  __syncthreads();
+  if (lane_id() == 63) wsum[wave_id()] = inc;
+  __syncthreads();
+  unsigned woff = 0, tot = 0;
+  for (int w = 0; w < kSelThreads / 64; w++) {
+    const unsigned x = wsum[w];
+    if (w < wave_id()) woff += x;
+    tot += x;
+  }
+  *total = tot;
+  return woff + inc - v;  // exclusive
+}
+
+__global__ void __launch_bounds__(kSelThreads) k_sel_small(const unsigned long long* __restrict__ cand_h,
+                                                          const unsigned* __restrict__ cand_i, unsigned cand_cap,
+                                                          unsigned k, unsigned n_arg, PreFrame* __restrict__ pf,
+                                                          int* __restrict__ out) {
+  // (the candidates themselves live in registers, eight per thread; LDS holds the histograms and the output)
+  __shared__ unsigned long long mh[kSelMembers];
+  __shared__ unsigned mi[kSelMembers];
+  __shared__ unsigned hist[kSelBins];
+  __shared__ unsigned start[kSelBins + 1];
+  __shared__ unsigned wsum[kSelThreads / 64];
+  __shared__ unsigned ctl[4];               // threshold bucket, rank inside it, its members, -
+  __shared__ unsigned sorted[kSelCapMax];   // the selected indices, bucket by bucket
+  const int tid = threadIdx.x;
+  const unsigned n_cand = pf->n_cand;
+  const unsigned M = min(n_cand, cand_cap);
+  const unsigned flags_in = pf->flags;
+  unsigned fl = 0u;
+  if (n_cand > cand_cap) fl |= kPreCandOverflow;
+  if (M < k && !(flags_in & kPreAllPoints)) fl |= kPreCandShort;
+  if (fl && tid == 0) atomicOr(&pf->flags, fl);
+  if (fl || flags_in) return;  // uniform: the caller repeats the step on the general path
+  const unsigned long long thr = pf->thr;
+  const unsigned n = n_arg ? n_arg : pf->n_vox;
+  // buckets: hash >> hshift < kSelBins for every hash <= thr; index >> ishift < kSelBins for every index < n
+  int hshift = 0, ishift = 0;
+  while ((thr >> hshift) >= (unsigned long long)kSelBins) hshift++;
+  while (((n - 1u) >> ishift) >= (unsigned)kSelBins) ishift++;
+  for (int b = tid; b < kSelBins; b += kSelThreads) hist[b] = 0u;
+  if (tid < 4) ctl[tid] = 0u;
+  __syncthreads();
+  unsigned long long myh[kSelCapMax / kSelThreads];
+  unsigned myi[kSelCapMax / kSelThreads];
+#pragma unroll
+  for (int u = 0; u < kSelCapMax / kSelThreads; u++) {
+    const unsigned j = (unsigned)tid + (unsigned)u * kSelThreads;
+    myh[u] = ~0ull;
+    myi[u] = 0xFFFFFFFFu;
+    if (j < M) {
+      myh[u] = cand_h[j];
+      myi[u] = cand_i[j];
+      atomicAdd(&hist[(unsigned)(myh[u] >> hshift)], 1u);
+    }
+  }
+  __syncthreads();
+  // (1) the bucket that holds the k-th smallest hash
+  {
+    const unsigned a = hist[2 * tid], b = hist[2 * tid + 1];
+    unsigned total = 0;
+    const unsigned before = sel_block_scan(a + b, &total, wsum);
+    if (k > before && k <= before + a) {
+      ctl[0] = 2u * tid;
+      ctl[1] = k - before;
+    } else if (k > before + a && k <= before + a + b) {
+      ctl[0] = 2u * tid + 1u;
+      ctl[1] = k - before - a;
+    }
+  }
+  __syncthreads();
+  const unsigned B = ctl[0], rB = ctl[1];
+#pragma unroll
+  for (int u = 0; u < kSelCapMax / kSelThreads; u++) {
+    if (myi[u] != 0xFFFFFFFFu && (unsigned)(myh[u] >> hshift) == B) {
+      const unsigned m = atomicAdd(&ctl[2], 1u);
+      if (m < (unsigned)kSelMembers) {
+        mh[m] = myh[u];
+        mi[m] = myi[u];
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned nm = ctl[2];
+  if (nm > (unsigned)kSelMembers) {  // (uniform) hashes that do not spread: leave it to the general path
+    if (tid == 0) atomicOr(&pf->flags, kPreCandShort);
+    return;
+  }
+  // the member of rank rB (1-based) by (hash, index): every thread finds it (nm is tiny)
+  unsigned long long kh = 0ull;
+  unsigned ki = 0u;
+  for (unsigned a = 0; a < nm; a++) {
+    unsigned r = 1u;
+    for (unsigned b = 0; b < nm; b++) r += (unsigned)(mh[b] < mh[a]) | ((unsigned)(mh[b] == mh[a]) & (unsigned)(mi[b] < mi[a]));
+    if (r == rB) {
+      kh = mh[a];
+      ki = mi[a];
+    }
+  }
+  if (tid == 0) {
+    pf->kth_h = kh;
+    pf->kth_i = ki;
+  }
+  // (2) the selected candidates by index bucket
+  for (int b = tid; b < kSelBins; b += kSelThreads) hist[b] = 0u;
+  __syncthreads();
+  unsigned selmask = 0u;
+#pragma unroll
+  for (int u = 0; u < kSelCapMax / kSelThreads; u++) {
+    const bool sel = myi[u] != 0xFFFFFFFFu && (myh[u] < kh || (myh[u] == kh && myi[u] <= ki));
+    if (sel) {
+      selmask |= 1u << u;
+      atomicAdd(&hist[myi[u] >> ishift], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    const unsigned a = hist[2 * tid], b = hist[2 * tid + 1];
+    unsigned total = 0;
+    const unsigned before = sel_block_scan(a + b, &total, wsum);
+    start[2 * tid] = before;
+    start[2 * tid + 1] = before + a;
+    if (tid == kSelThreads - 1) start[kSelBins] = before + a + b;  // == k
+  }
+  __syncthreads();
+  for (int b = tid; b < kSelBins; b += kSelThreads) hist[b] = 0u;  // now: entries placed per bucket
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kSelCapMax / kSelThreads; u++) {
+    if (selmask & (1u << u)) {
+      const unsigned b = myi[u] >> ishift;
+      sorted[start[b] + atomicAdd(&hist[b], 1u)] = myi[u];
+    }
+  }
+  __syncthreads();
+  for (int b = tid; b < kSelBins; b += kSelThreads) {  // order inside a bucket: insertion sort over a handful
+    const unsigned lo = start[b], hi = start[b + 1];
+    for (unsigned x = lo + 1; x < hi; x++) {
+      const unsigned v = sorted[x];
+      unsigned y = x;
+      while (y > lo && sorted[y - 1] > v) {
+        sorted[y] = sorted[y - 1];
+        y--;
+      }
+      sorted[y] = v;
+    }
+  }
+  __syncthreads();
+  const unsigned n_sel = start[kSelBins];
+  for (unsigned x = tid; x < n_sel; x += kSelThreads) out[x] = (int)sorted[x];
+}
+
+// the exact selection among the candidates: one workgroup when the list fits it, else the two M^2 kernels
+static int launch_selection(ag2_ctx* c, unsigned long long* cand_h, unsigned* cand_i, size_t cand_cap, size_t k,
+                            size_t n_arg, PreFrame* pf, int* out) {
+  static const bool pair_only = getenv("AG2_SEL_PAIR") != nullptr;  // A/B and tests of the two-kernel form
+  if (cand_cap <= (size_t)kSelCapMax && cand_cap > 0 && !pair_only) {
+    hipLaunchKernelGGL(k_sel_small, dim3(1), dim3(kSelThreads), 0, c->stream, cand_h, cand_i, (unsigned)cand_cap,
+                       (unsigned)k, (unsigned)n_arg, pf, out);
+  } else {
+    const unsigned sel_blocks = (unsigned)((std::max<size_t>(cand_cap, 1) + 255) / 256);
+    hipLaunchKernelGGL(k_sel_rank, dim3(sel_blocks), dim3(256), 0, c->stream, cand_h, cand_i, (unsigned)cand_cap,
+                       (unsigned)k, pf);
+    hipLaunchKernelGGL(k_sel_emit, dim3(sel_blocks), dim3(256), 0, c->stream, cand_h, cand_i, (unsigned)cand_cap, pf, out);
+  }
+  AG2_HIP(c, hipGetLastError());
+  return 0;
+}
+
 static WsBox ws_of(const ag2_ctx* c) {
   WsBox ws;
   for (int k = 0; k < 6; k++) ws.b[k] = c->p.workspace[k];
@@ -740,13 +953,9 @@ int enqueue_front_frame(ag2_ctx* c, const FrontShapes& fs) {
   hipLaunchKernelGGL(k_vox_emit_frame, dim3(((unsigned)cap_words + 255) / 256), dim3(256), 0, c->stream, bitmap,
                      c->d_wrank.as<unsigned>(), cap_words, pf, c->d_xyz_in.as<float4>(), (int)fs.n_max,
                      (unsigned)fs.num_samples, 0ull, c->fm_args_dev, cand_h, cand_i, (unsigned)fs.cand_cap, gf);
-  const unsigned sel_blocks = (unsigned)((std::max<size_t>(fs.cand_cap, 1) + 255) / 256);
-  hipLaunchKernelGGL(k_sel_rank, dim3(sel_blocks), dim3(256), 0, c->stream, cand_h, cand_i, (unsigned)fs.cand_cap,
-                     (unsigned)fs.num_samples, pf);
-  hipLaunchKernelGGL(k_sel_emit, dim3(sel_blocks), dim3(256), 0, c->stream, cand_h, cand_i, (unsigned)fs.cand_cap,
-                     pf, c->d_samples.as<int>());
   AG2_HIP(c, hipGetLastError());
-  return 0;
+  if (fs.num_samples == 0) return 0;  // (ag2_preprocess_cloud*: no sub-sampling)
+  return launch_selection(c, cand_h, cand_i, fs.cand_cap, fs.num_samples, 0, pf, c->d_samples.as<int>());
 }
 
 // d_raw (and d_raw_nrm when have_nrm) hold n points
@@ -1046,11 +1255,11 @@ int ag2_subsample_uniformly(ag2_ctx* c, size_t num_samples, uint64_t seed, int32
     AG2_HIP(c, hipMemsetAsync(pf, 0, sizeof(PreFrame), c->stream));
     hipLaunchKernelGGL(k_sel_candidates, dim3(g256), dim3(256), 0, c->stream, ni, (unsigned long long)seed,
                        cand_threshold((unsigned)k, (unsigned)n), pf, cand_h, cand_i, (unsigned)cap);
-    const unsigned sel_blocks = (unsigned)((cap + 255) / 256);
-    hipLaunchKernelGGL(k_sel_rank, dim3(sel_blocks), dim3(256), 0, c->stream, cand_h, cand_i, (unsigned)cap,
-                       (unsigned)k, pf);
-    hipLaunchKernelGGL(k_sel_emit, dim3(sel_blocks), dim3(256), 0, c->stream, cand_h, cand_i, (unsigned)cap, pf, out);
     AG2_HIP(c, hipGetLastError());
+    {
+      const int rc = launch_selection(c, cand_h, cand_i, cap, k, n, pf, out);
+      if (rc) return rc;
+    }
     PreFrame hf;
     AG2_HIP(c, hipMemcpyAsync(pin_small(c), pf, sizeof(hf), hipMemcpyDeviceToHost, c->stream));
     if (idx_out) AG2_HIP(c, hipMemcpyAsync(idx_out, out, k * 4, hipMemcpyDeviceToHost, c->stream));

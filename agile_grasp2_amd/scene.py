@@ -150,6 +150,28 @@ def make_scene(seed: int, n_target: int, kind: str = "tabletop", voxel: float | 
     return np.ascontiguousarray(cloud, dtype=np.float32), ws
 
 
+def raw_from_voxels(vox: np.ndarray, seed: int, per_voxel: float = 2.55, cell: float = VOXEL) -> np.ndarray:
+    """A raw "sensor" cloud whose voxelisation (CloudCamera::voxelizeCloud, cloud_camera.cpp:124-168) is the
+    voxel cloud `vox` again: two or three points per voxel (per_voxel on average), each well inside its voxel,
+    in random order; on every axis one point of a voxel with index 0 sits exactly on the lattice origin so that
+    the minimum -- the origin the voxel indices are counted from -- is the same.  Lets a run WITH the front end
+    be compared with the run on `vox` itself."""
+    rng = np.random.default_rng(seed)
+    vox = np.ascontiguousarray(vox, dtype=np.float32)
+    mn = vox.min(axis=0)
+    cellf = np.float32(cell)
+    idx = np.rint((vox - mn) / cellf).astype(np.int64)
+    reps = np.where(rng.uniform(size=len(vox)) < per_voxel - 2.0, 3, 2)
+    owner = np.repeat(np.arange(len(vox)), reps)
+    u = rng.uniform(0.25, 0.75, size=(len(owner), 3))
+    pts = mn.astype(np.float64) + (idx[owner] + u) * float(cellf)
+    for a in range(3):
+        j = np.flatnonzero(idx[owner][:, a] == 0)[0]
+        pts[j, a] = float(mn[a])
+    raw = pts.astype(np.float32)
+    return np.ascontiguousarray(raw[rng.permutation(len(raw))])
+
+
 def draw_samples(seed: int, n_points: int, num_samples: int) -> np.ndarray:
     """Seeded stand-in for pcl::RandomSample (cloud_camera.cpp:171-178): num_samples indices
     without replacement, ascending."""

@@ -117,27 +117,24 @@ def cpu_baseline(xyz, ws, idx, R, weights, budget_s=12.0, max_reps=400, threads=
     }
 
 
-def bench_stream(args):
-    """--config cfg5: `steps` frames of a drifting tabletop scene through ag2_detect_frame.
-
-    value = hypotheses scored per second over the timed frames with the frames resident in HBM
-    (graph replay); latency = host time of one ag2_detect_frame call (cloud in HBM -> selected
-    grasps in host memory).  The step-by-step path (ag2_set_cloud_device + ag2_compute_normals +
-    ag2_detect on a second context) runs the same frames for comparison and -- untimed -- must return
-    the same bytes."""
+def stream_legs(seed, n_frames, n_warm, S=None, only=None, host_leg=True):
+    """BASELINE.json configuration 5: `n_frames` (+ n_warm untimed) RAW frames of one drifting tabletop scene
+    (~765 000 points each, ~300 000 voxels of 3 mm) through ag2_detect_frame_raw -- workspace filter, voxel
+    grid and uniform sub-sampling on the device inside the per-frame pipeline, which is captured in a
+    hipGraph -- beside the same fixed-shape sequence without a graph, the step-by-step calls
+    (ag2_preprocess_cloud_device + ag2_subsample_uniformly + ag2_compute_normals + ag2_detect on a second
+    context; must return the same bytes) and, for the front end's share, frames that arrive already
+    preprocessed (ag2_detect_frame).  Latency = host time of one call: raw cloud in HBM -> selected grasps
+    in host memory."""
     import torch
     from agile_grasp2_amd import capi, scene
     from agile_grasp2_amd.weights import make_lenet_weights
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
-    n_points, S, R, _, _ = CONFIGS["cfg5"]
-    S = int(os.environ.get("AG2_STREAM_S", S))   # experiment aid: other sample counts on the same stream
-    n_frames, n_warm = args.steps, max(3, args.warmup)   # warm-up: step-by-step, plain run + capture, first replay
-    clouds, ws = scene.make_stream(args.seed, n_points, n_frames + n_warm)
-    samples = [scene.draw_samples(args.seed + k, c.shape[0], S) for k, c in enumerate(clouds)]
+    n_points, S0, R, _, _ = CONFIGS["cfg5"]
+    S = int(S or S0)
+    raws, ws = scene.make_stream(seed, int(2.55 * n_points), n_frames + n_warm, voxel=None)
     prm = launch_params(ws, R)
     weights = make_lenet_weights(7)
-    dev = [torch.from_numpy(c).cuda() for c in clouds]
+    dev = [torch.from_numpy(c).cuda() for c in raws]
     torch.cuda.synchronize()
 
     def make():
@@ -146,77 +143,172 @@ def bench_stream(args):
         d.set_stage_timing(0)
         return d
 
-    legs, results = {}, {}
-    only = os.environ.get("AG2_STREAM_LEG")   # profiling aid: run one leg only
-    for name in ("graph", "plain", "stepwise"):
+    legs, results, pre = {}, {}, {}
+    for name in ("graph", "plain", "stepwise", "graph_preprocessed"):
         if only and name != only:
+            continue
+        if name == "graph_preprocessed" and "stepwise" not in results:
             continue
         d = make()
         if name != "stepwise":
-            d.stream_configure(0, 0, name == "graph")
-        lat, scored, out = [], 0, []
+            d.stream_configure(0, 0, name != "plain")
+        lat, scored, out, vox = [], 0, [], 0
         for k in range(n_frames + n_warm):
+            if name == "graph_preprocessed":   # the frames as the stepwise leg's front end left them, resident in HBM
+                cloud, idx = pre[k]
             t0 = time.perf_counter()
             if name == "stepwise":
-                d.set_cloud_device(dev[k].data_ptr(), clouds[k].shape[0], 12)
+                vox = d.preprocess_cloud_device(dev[k].data_ptr(), raws[k].shape[0], 12, voxel_size=scene.VOXEL)
+                ns = d.subsample_uniformly(S, seed=seed + k, want_indices=False)
                 d.compute_normals()
-                sel, n_sc = d.detect(sample_idx=samples[k], seed=args.seed, do_prune=True, want_all=False)
+                sel, n_sc = d.detect(n_resident=ns, seed=seed, do_prune=True, want_all=False)
+            elif name == "graph_preprocessed":
+                sel, n_sc = d.detect_frame(sample_idx=idx, seed=seed, do_prune=True, dptr=cloud.data_ptr(),
+                                           n=cloud.shape[0], stride=12)
             else:
-                sel, n_sc = d.detect_frame(sample_idx=samples[k], seed=args.seed, do_prune=True,
-                                           dptr=dev[k].data_ptr(), n=clouds[k].shape[0], stride=12)
+                sel, n_sc, vox = d.detect_frame_raw(num_samples=S, sample_seed=seed + k, seed=seed, do_prune=True,
+                                                    dptr=dev[k].data_ptr(), n=raws[k].shape[0], stride=12,
+                                                    voxel_size=scene.VOXEL)
             dt = time.perf_counter() - t0
             out.append(sel.tobytes())
+            if name == "stepwise" and not only:
+                pre[k] = (torch.from_numpy(d.get_cloud()[0]).cuda(), d.get_samples())
             if k >= n_warm:
                 lat.append(dt * 1e3)
                 scored += n_sc
         lat = np.array(lat)
         legs[name] = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
                       "max_ms": float(lat.max()), "mean_ms": float(lat.mean()),
-                      "scored_per_s": scored / (lat.sum() * 1e-3), "scored_per_frame": scored / n_frames}
+                      "scored_per_s": scored / (lat.sum() * 1e-3), "scored_per_frame": scored / n_frames,
+                      "voxels_last_frame": int(vox)}
         if name != "stepwise":
             fi = d.frame_info()
             legs[name]["frame_info"] = {f: int(getattr(fi, f)) for f, _ in fi._fields_}
         results[name] = out
-        c = d.counters()
-        legs[name]["hypotheses_last_frame"] = int(c.n_hypotheses)
+        legs[name]["hypotheses_last_frame"] = int(d.counters().n_hypotheses)
         d.close()
     if only:
-        print(json.dumps({"leg": only, **legs[only]}), flush=True)
-        return
-    same = results["graph"] == results["stepwise"] and results["plain"] == results["stepwise"]
-    # frames handed over in HOST memory (the PCIe-inclusive figure, never `value`)
-    d = make()
-    d.stream_configure(0, 0, True)
-    lat = []
-    for k in range(n_frames + n_warm):
-        t0 = time.perf_counter()
-        d.detect_frame(clouds[k], samples[k], seed=args.seed, do_prune=True)
-        if k >= n_warm:
-            lat.append((time.perf_counter() - t0) * 1e3)
-    d.close()
+        return {"leg": only, **legs[only]}
+    same = (results["graph"] == results["stepwise"] and results["plain"] == results["stepwise"]
+            and results["graph_preprocessed"] == results["stepwise"])
+    host = None
+    if host_leg:   # frames handed over in HOST memory (the PCIe-inclusive figure, never `value`)
+        d = make()
+        d.stream_configure(0, 0, True)
+        lat = []
+        for k in range(n_frames + n_warm):
+            t0 = time.perf_counter()
+            d.detect_frame_raw(raws[k], num_samples=S, sample_seed=seed + k, seed=seed, do_prune=True,
+                               voxel_size=scene.VOXEL)
+            if k >= n_warm:
+                lat.append((time.perf_counter() - t0) * 1e3)
+        d.close()
+        host = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+                "note": f"raw frames handed over in pageable host memory ({raws[0].nbytes / 1e6:.1f} MB H2D per frame)"}
     g = legs["graph"]
+    return {"budget_ms": FRAME_BUDGET_MS, "graph": g, "plain_fixed_shape": legs["plain"], "stepwise": legs["stepwise"],
+            "graph_preprocessed_frames": legs["graph_preprocessed"], "graph_host_frames": host,
+            "front_end_ms_p50": g["p50_ms"] - legs["graph_preprocessed"]["p50_ms"],
+            "within_budget": bool(g["p99_ms"] <= FRAME_BUDGET_MS), "same_bytes_as_stepwise": bool(same),
+            "raw_points_per_frame": [int(c.shape[0]) for c in raws[n_warm:n_warm + 4]] + ["..."],
+            "num_samples_per_frame": S, "num_orientations": R, "frames": n_frames, "warmup_frames": n_warm}
+
+
+def bench_stream(args):
+    """--config cfg5: the frame stream as its own bench line (see stream_legs)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    n_points, S, R, _, _ = CONFIGS["cfg5"]
+    S = int(os.environ.get("AG2_STREAM_S", S))   # experiment aid: other sample counts on the same stream
+    n_frames, n_warm = args.steps, max(3, args.warmup)   # warm-up: step-by-step, plain run + capture, first replay
+    only = os.environ.get("AG2_STREAM_LEG")   # profiling aid: run one leg only
+    lat = stream_legs(args.seed, n_frames, n_warm, S=S, only=only)
+    if only:
+        print(json.dumps(lat), flush=True)
+        return
+    g = lat["graph"]
     out = {
         "metric": "grasp hypotheses scored/sec on 300k-pt cloud; end-to-end detect latency",
         "value": g["scored_per_s"], "unit": "hypotheses/s", "n_gpus": 1, "steps": n_frames, "warmup": n_warm,
         "ms_per_step": g["mean_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 geometry + f32 LeNet (3 x bf16 operand split on bf16 MFMA, fp32 accumulate)",
-        "data": "synthetic", "span": "hbm-resident",
-        "config": {"workload": (f"cfg5: stream of {n_frames} frames, ~{n_points}-pt voxelised (3 mm) tabletop scene whose "
-                                f"objects drift 4 mm per frame, num_samples={S} per frame, {R} orientations, launch-file "
-                                f"hand geometry, seeded LeNet weights; LeNet list padded to whole batches of 256 images; "
-                                f"per-frame pipeline captured in a hipGraph (ag2_detect_frame)"),
-                   "n_points_per_frame": [int(c.shape[0]) for c in clouds[n_warm:n_warm + 4]] + ["..."],
+        "data": "synthetic", "span": "hbm-resident (RAW frames: workspace filter + voxel grid + sub-sampling inside the frame)",
+        "config": {"workload": (f"cfg5: stream of {n_frames} RAW frames (~{int(2.55 * n_points)} points, ~{n_points} voxels of 3 mm) of "
+                                f"a tabletop scene whose objects drift 4 mm per frame, num_samples={S} per frame, {R} "
+                                f"orientations, launch-file hand geometry, seeded LeNet weights; LeNet list padded to "
+                                f"whole batches of 256 images; filter + voxel grid + sub-sampling + detect captured in "
+                                f"one hipGraph (ag2_detect_frame_raw)"),
+                   "raw_points_per_frame": lat["raw_points_per_frame"],
                    "num_samples_per_frame": S, "num_orientations": R, "batch_size": 256},
-        "latency": {"budget_ms": FRAME_BUDGET_MS, "graph": g, "plain_fixed_shape": legs["plain"],
-                    "stepwise": legs["stepwise"],
-                    "graph_host_frames": {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
-                                          "note": "frames handed over in pageable host memory (3.6 MB H2D per frame)"},
-                    "within_budget": bool(g["p99_ms"] <= FRAME_BUDGET_MS),
-                    "same_bytes_as_stepwise": bool(same)},
+        "latency": lat,
         "roofline": None, "cpu_baseline": None,
         "note": "roofline / cpu_baseline are reported on the headline configuration (python bench.py); this line is the streaming latency",
     }
     print(json.dumps(out), flush=True)
+
+
+def side_cfg3(args, weights, local_rank, steps=5):
+    """BASELINE.json configuration 3 (1 M un-voxelised points, 20 000 samples, 16 orientations) as a side leg of
+    the default line: `steps` timed steps, the sweep's roofline from its HIP events and the committed counter
+    passes (profiles/pmc_traffic.json)."""
+    import torch
+    from agile_grasp2_amd import capi, scene
+    n_points, S, R, voxelised, kind = CONFIGS["cfg3"]
+    xyz, ws = scene.make_scene(args.seed, n_points, kind=kind, voxel=None)
+    idx = scene.draw_samples(args.seed, xyz.shape[0], S)
+    d = capi.Detector(device=local_rank, **launch_params(ws, R))
+    d.set_stream(torch.cuda.current_stream().cuda_stream)
+    d.lenet_load(weights)
+    d.set_stage_timing(1)
+    xyz_dev = torch.from_numpy(xyz).cuda()
+    torch.cuda.synchronize()
+
+    def step():
+        d.set_cloud_device(xyz_dev.data_ptr(), xyz.shape[0], 12)
+        d.compute_normals()
+        return d.detect(sample_idx=idx, seed=args.seed, do_prune=True, want_all=False)[1]
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0, scored, sweep_ms = time.perf_counter(), 0, 0.0
+    for _ in range(steps):
+        scored += step()
+        t = d.times()
+        sweep_ms += t.sweep_ms + t.sweep_overflow_ms
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    sweep_ms /= steps
+    c = d.counters()
+    d.close()
+    dd = capi.Detector(device=local_rank, **dict(launch_params(ws, R), debug_flags=1))   # exact K2 (no row culling)
+    dd.set_stream(torch.cuda.current_stream().cuda_stream)
+    dd.lenet_load(weights)
+    dd.set_cloud_device(xyz_dev.data_ptr(), xyz.shape[0], 12)
+    dd.compute_normals()
+    dd.detect(sample_idx=idx, seed=args.seed, do_prune=True, want_all=False)
+    sum_k2 = dd.counters().sum_k2
+    dd.close()
+    work = sum_k2 * 24 + c.n_hypotheses * 176 + c.sum_p * 24
+    achieved = work / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    traffic, src = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pk = pmc.get("cfg3", {})
+        if "k_sweep" in pk:
+            traffic = pk.get("k_sweep", 0) + pk.get("k_sweep_overflow", 0) + pk.get("k_sweep_orient", 0)
+            src = f"profiles/{pmc.get('_profile', {}).get('cfg3', '?')} (committed rocprofv3 counter passes, not this run)"
+    except Exception:
+        pass
+    return {"value": scored / steps / dt, "unit": "hypotheses/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "workload": f"cfg3: {xyz.shape[0]}-pt un-voxelised tabletop cloud, num_samples={S}, {R} orientations",
+            "roofline": {"kernel": "k_sweep", "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": src,
+                         "launch_ms": sweep_ms, "algorithmic_work_per_launch": work},
+            "counters": {"hypotheses": int(c.n_hypotheses), "scored": int(c.n_scored), "overflow_samples": int(c.n_overflow_samples),
+                         "mean_K2": sum_k2 / max(1, c.n_frames), "mean_Kcrop": c.sum_kcrop / max(1, c.n_frames),
+                         "mean_P": c.sum_p / max(1, c.n_hypotheses), "list_points": int(c.list_points)}}
 
 
 def main():
@@ -466,6 +558,15 @@ def main():
             k["achieved"] = k["work"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
             k["peak"], k["unit"] = k.get("peak", PEAK_F32_MFMA_TFLOPS), "TFLOP/s"
         k["frac"] = k["achieved"] / k["peak"]
+        if "fp32_equivalent_tflops" in k:
+            # The three-term split issues about 6 bf16 multiply-adds (padding included: 7.5) per useful fp32
+            # one.  `frac` counts USEFUL flops only (fp32-equivalent rate / dense bf16 peak of the pipes the
+            # kernel runs on); the pipes' own utilisation is issued_frac; useful_vs_f32_mfma_peak compares with
+            # what the f32-input matrix instructions could do at best.
+            k["issued_tflops"], k["issued_frac"] = k["achieved"], k["frac"]
+            k["achieved"] = k["fp32_equivalent_tflops"]
+            k["frac"] = k["achieved"] / k["peak"]
+            k["useful_vs_f32_mfma_peak"] = k["achieved"] / PEAK_F32_MFMA_TFLOPS
     dom = max(kernels, key=lambda n: kernels[n]["ms"])
     # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of the same command
     # (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
@@ -511,7 +612,9 @@ def main():
                 "algorithmic_work_per_launch": kernels[dom]["work"],
                 "all_kernels": {n: dict({"ms": round(k["ms"], 4), "achieved": round(k["achieved"], 3),
                                          "unit": k["unit"], "peak": k["peak"], "frac": round(k["frac"], 4)},
-                                        **({"fp32_equivalent_tflops": round(k["fp32_equivalent_tflops"], 2)}
+                                        **({"issued_tflops": round(k["issued_tflops"], 2),
+                                            "issued_frac": round(k["issued_frac"], 4),
+                                            "useful_vs_f32_mfma_peak": round(k["useful_vs_f32_mfma_peak"], 4)}
                                            if "fp32_equivalent_tflops" in k else {}),
                                         **({"mfma_busy": k["mfma_busy"]} if "mfma_busy" in k else {}),
                                         **({"write_amplification": k["write_amplification"], "traffic": k["traffic"]}
@@ -542,6 +645,7 @@ def main():
             "mean_K1": c.sum_k1 / max(1, c.n_valid_points), "mean_K2": sum_k2 / max(1, c.n_frames),
             "mean_Kcrop": c.sum_kcrop / max(1, c.n_frames), "mean_P": c.sum_p / max(1, c.n_hypotheses),
             "overflow_samples": int(c.n_overflow_samples),
+            "detect_one_trip": int(c.detect_one_trip), "detect_redone": int(c.detect_redone),
             "parallelism": ("single GPU" if not dist_on else
                             f"{world} spatial tiles along the cloud's longest axis, cut so that the summed "
                             f"neighbour counts of their samples are equal (interval of the rank's samples + 0.11 m "
@@ -578,31 +682,78 @@ def main():
         dt, sc = timed(host_step)
         out["pcie_inclusive"] = {"value": sc / dt, "unit": "hypotheses/s", "ms_per_step": dt * 1e3,
                                  "note": f"cloud ({xyz.nbytes / 1e6:.1f} MB) uploaded from pageable host memory every step"}
-        # (2) the step with the GPU front end in front of it: raw (un-voxelised) cloud resident in
-        # HBM -> workspace filter + 3 mm voxel grid + uniform sub-sampling -> normals -> detect with
-        # the sample indices never leaving the device.
+        # (2) the step with the GPU front end in front of it: RAW (un-voxelised) cloud resident in HBM ->
+        # workspace filter + 3 mm voxel grid + uniform sub-sampling -> normals -> detect, the processed
+        # cloud and the sample indices never leaving the device -- through
+        # ag2_detect_frame_raw (everything in one captured sequence, one host synchronisation), and through
+        # the separate calls for comparison.
         if voxelised:
-            raw, ws_raw = scene.make_scene(args.seed, int(2.55 * n_points), kind=kind, voxel=None, spacing=0.0015)
-            df = capi.Detector(device=local_rank, **launch_params(ws_raw, R))
-            df.set_stream(torch.cuda.current_stream().cuda_stream)
+            # The raw cloud: 2 - 3 points inside every voxel of the headline cloud (those inside the workspace: the
+            # front end filters), shuffled -- its voxelisation is the headline cloud again, so this leg differs
+            # from the headline step by the front end (and by which samples the device draws).
+            xd = xyz.astype(np.float64)
+            inside = ((xd[:, 0] > ws[0]) & (xd[:, 0] < ws[1]) & (xd[:, 1] > ws[2]) & (xd[:, 1] < ws[3]) &
+                      (xd[:, 2] > ws[4]) & (xd[:, 2] < ws[5]))
+            raw, ws_raw = scene.raw_from_voxels(xyz[inside], args.seed), ws
+            df = capi.Detector(**launch_params(ws_raw, R))   # own stream: the sequence is captured in a hipGraph
             df.lenet_load(weights)
+            df.set_stage_timing(0)
             raw_dev = torch.from_numpy(raw).cuda()
             torch.cuda.synchronize()
             fe = {}
 
-            def front_step():
-                fe["n_vox"] = df.preprocess_cloud_device(raw_dev.data_ptr(), raw.shape[0], 12,
-                                                         voxel_size=scene.VOXEL)
-                ns = df.subsample_uniformly(S, seed=args.seed, want_indices=False)
-                df.compute_normals()
-                n_sc = df.detect(n_resident=ns, seed=args.seed, do_prune=True, want_all=False)[1]
-                fe["pre_ms"] = df.times().preprocess_ms
+            def raw_frame_step():
+                _, n_sc, fe["n_vox"] = df.detect_frame_raw(num_samples=S, sample_seed=args.seed, seed=args.seed,
+                                                           do_prune=True, dptr=raw_dev.data_ptr(), n=raw.shape[0],
+                                                           stride=12, voxel_size=scene.VOXEL)
                 return n_sc
 
-            dt, sc = timed(front_step)
+            for _ in range(3):   # step by step, fixed shapes + capture, first replay
+                raw_frame_step()
+            dt, sc = timed(raw_frame_step)
+            fi = df.frame_info()
+            # the same workload without the front end: the processed cloud and the drawn samples handed to the
+            # plain step (set_cloud_device + normals + detect) of the headline measurement
+            cloud_dev = torch.from_numpy(df.get_cloud()[0]).cuda()
+            idx_fe = df.get_samples()
+            dp = capi.Detector(device=local_rank, **launch_params(ws_raw, R))
+            dp.set_stream(torch.cuda.current_stream().cuda_stream)
+            dp.lenet_load(weights)
+            dp.set_stage_timing(1)
+            torch.cuda.synchronize()
+
+            def plain_step_same_cloud():
+                dp.set_cloud_device(cloud_dev.data_ptr(), cloud_dev.shape[0], 12)
+                dp.compute_normals()
+                return dp.detect(sample_idx=idx_fe, seed=args.seed, do_prune=True, want_all=False)[1]
+
+            dt0, sc0 = timed(plain_step_same_cloud)
+            dp.close()
+            assert sc0 == sc, (sc0, sc)   # the same hypotheses scored with and without the front end
             out["with_front_end"] = {"value": sc / dt, "unit": "hypotheses/s", "ms_per_step": dt * 1e3,
                                      "raw_points": int(raw.shape[0]), "voxels": int(fe["n_vox"]),
-                                     "preprocess_ms": round(fe["pre_ms"], 4)}
+                                     "headline_cloud_points_inside_workspace": int(inside.sum()),
+                                     "scored_per_step": sc, "graph_replays": int(fi.graph_replays),
+                                     "fallbacks": int(fi.fallbacks),
+                                     "same_cloud_without_front_end_ms": dt0 * 1e3,
+                                     "front_end_cost_ms": (dt - dt0) * 1e3,
+                                     "minus_headline_ms_per_step": dt * 1e3 - elapsed / K * 1e3,
+                                     "note": ("ag2_detect_frame_raw: filter + voxel grid + sub-sampling + detect in one "
+                                              "captured sequence, on a raw cloud (2.55 points per voxel, shuffled) whose "
+                                              "voxelisation is the headline cloud; front_end_cost_ms = against the plain "
+                                              "step on the very cloud and samples the front end produced; "
+                                              "minus_headline_ms_per_step = against the headline step (the samples differ: "
+                                              "drawn on the device here)")}
+
+            def front_step():
+                fe["n_vox2"] = df.preprocess_cloud_device(raw_dev.data_ptr(), raw.shape[0], 12,
+                                                          voxel_size=scene.VOXEL)
+                ns = df.subsample_uniformly(S, seed=args.seed, want_indices=False)
+                df.compute_normals()
+                return df.detect(n_resident=ns, seed=args.seed, do_prune=True, want_all=False)[1]
+
+            dt, sc = timed(front_step)
+            out["with_front_end"]["separate_calls_ms_per_step"] = dt * 1e3
             df.close()
         # (3) two independent clouds in flight at once (a streaming deployment): two contexts, each on
         # its own HIP stream and driven by its own host thread (ctypes releases the GIL inside the
@@ -658,6 +809,23 @@ def main():
         out["with_min_inliers_5"] = {"value": sc / dt, "unit": "hypotheses/s", "ms_per_step": dt * 1e3,
                                      "note": "launch-file min_inliers=5: k_cluster between threshold and top-k; never `value`"}
         out["value_pcie_inclusive"] = out["pcie_inclusive"]["value"]
+        if args.config == "cfg2" and not os.environ.get("AG2_BENCH_NO_SIDE_CONFIGS"):
+            # (5) BASELINE.json configurations 3 and 5 beside the headline (never `value`): a few steps each
+            out["cfg3"] = side_cfg3(args, weights, local_rank)
+            lat5 = stream_legs(args.seed, 20, 3, host_leg=False)
+            out["cfg5"] = {"p50_ms": lat5["graph"]["p50_ms"], "p99_ms": lat5["graph"]["p99_ms"],
+                           "within_budget": lat5["within_budget"], "same_bytes_as_stepwise": lat5["same_bytes_as_stepwise"],
+                           "budget_ms": FRAME_BUDGET_MS, "value": lat5["graph"]["scored_per_s"], "unit": "hypotheses/s",
+                           "scored_per_frame": lat5["graph"]["scored_per_frame"],
+                           "stepwise_p50_ms": lat5["stepwise"]["p50_ms"], "stepwise_p99_ms": lat5["stepwise"]["p99_ms"],
+                           "plain_fixed_shape_p50_ms": lat5["plain_fixed_shape"]["p50_ms"],
+                           "preprocessed_frames_p50_ms": lat5["graph_preprocessed_frames"]["p50_ms"],
+                           "front_end_ms_p50": lat5["front_end_ms_p50"],
+                           "frame_info": lat5["graph"]["frame_info"], "raw_points_per_frame": lat5["raw_points_per_frame"],
+                           "workload": ("cfg5: 20 RAW frames (~765 k points -> ~300 k voxels of 3 mm) of a drifting tabletop "
+                                        "scene, 2 000 samples per frame, ag2_detect_frame_raw (filter + voxel grid + "
+                                        "sub-sampling + detect in one hipGraph); latency of one call, raw cloud in HBM -> "
+                                        "selected grasps on the host")}
         out["cpu_baseline"] = cpu_baseline(xyz, ws, idx, R, weights)
         # BASELINE.json configs[0] ("PR1 ref"): the launch file's own case -- num_samples = 500, ONE thread
         # (launch/file_detect_grasps.launch:18-19) -- on a 50 k-point scene (the reference bundles no .pcd)

@@ -126,6 +126,12 @@ typedef struct ag2_frame_info {
   int64_t fallbacks;        /* fixed-shape frames repeated step by step (a buffer or table was too small) */
   int64_t max_points, max_samples, max_cells, max_images;  /* the fixed shapes in force */
   int64_t graph_ready;
+  int64_t last_fallback;    /* why the last fallback happened: 1 point-list arena, 2 cropped-list arena, 8 sweep scratch too
+                               small; 16 more grid cells than the table holds; 32 more selected records than the result
+                               block; 64 more images than max_images; 128 an in-box list longer than the captured
+                               renderers take; << 8: the front end's flags (ag2_detect_frame_raw): 1 voxel lattice larger
+                               than the bitmap, 2 more voxels than max_points, 4 / 8 sub-sampling candidate list, 16 no
+                               more voxels than num_samples */
 } ag2_frame_info;
 
 int ag2_abi_version(void);

@@ -194,8 +194,10 @@ static int run_constants(const char* out_path) {
 // pruned hypotheses before the clustering and the selection, GEOMETRIC keeps the full-antipodal ones,
 // clusters them when min_inliers > 0 and takes num_selected).  Output: int64 n, then per hand
 // {int32 slot, int32 orientation, int32 full_antipodal, int32 half_antipodal, double score, double bottom[3]}.
-static int run_modes(const char* cloud_path, const char* idx_path, const char* params_path, const char* out_path) {
+static int run_modes(const char* cloud_path, const char* idx_path, const char* params_path, const char* out_path,
+                     const char* normals_path) {
   const std::vector<float> xyz = read_all<float>(cloud_path);
+  const std::vector<float> nrm = normals_path ? read_all<float>(normals_path) : std::vector<float>();
   const std::vector<int32_t> idx = read_all<int32_t>(idx_path);
   std::ifstream pf(params_path);
   const std::string ptext((std::istreambuf_iterator<char>(pf)), std::istreambuf_iterator<char>());
@@ -212,7 +214,21 @@ static int run_modes(const char* cloud_path, const char* idx_path, const char* p
     cloud->points[i].y = xyz[3 * i + 1];
     cloud->points[i].z = xyz[3 * i + 2];
   }
-  CloudCamera cc(cloud, (int)cloud->size());
+  // a cloud that brings its normals (cloud_camera.cpp:4-32) -- or one without (:35-51)
+  PointCloudNormal::Ptr cloud_n(new PointCloudNormal);
+  if (!nrm.empty()) {
+    if (nrm.size() != xyz.size()) return 2;
+    cloud_n->points.resize(xyz.size() / 3);
+    for (size_t i = 0; i < cloud_n->size(); i++) {
+      cloud_n->points[i].x = xyz[3 * i];
+      cloud_n->points[i].y = xyz[3 * i + 1];
+      cloud_n->points[i].z = xyz[3 * i + 2];
+      cloud_n->points[i].normal_x = nrm[3 * i];
+      cloud_n->points[i].normal_y = nrm[3 * i + 1];
+      cloud_n->points[i].normal_z = nrm[3 * i + 2];
+    }
+  }
+  CloudCamera cc = nrm.empty() ? CloudCamera(cloud, (int)cloud->size()) : CloudCamera(cloud_n, (int)cloud_n->size());
   cc.setSampleIndices(std::vector<int>(idx.begin(), idx.end()));
   GraspDetector det(prm);
   const std::vector<GraspHypothesis> hands = det.detectGraspPoses(cc);
@@ -235,7 +251,8 @@ static int run_modes(const char* cloud_path, const char* idx_path, const char* p
 }
 
 int main(int argc, char** argv) {
-  if (argc == 6 && std::string(argv[1]) == "--modes") return run_modes(argv[2], argv[3], argv[4], argv[5]);
+  if ((argc == 6 || argc == 7) && std::string(argv[1]) == "--modes")
+    return run_modes(argv[2], argv[3], argv[4], argv[5], argc == 7 ? argv[6] : nullptr);
   if (argc == 3 && std::string(argv[1]) == "--constants") return run_constants(argv[2]);
   if (argc == 5 && std::string(argv[1]) == "--preprocess") return run_preprocess(argv[2], argv[3], argv[4]);
   if (argc == 4 && std::string(argv[1]) == "--caffemodel") return run_caffemodel(argv[2], argv[3]);

@@ -191,9 +191,31 @@ def test_cpp_host_matches_oracle(tmp_path, small_scene, weights_format):
         assert abs(f[1] - np.float32(h["score"])) <= 2 * tol
 
 
+def two_sided_scene(seed, n_boxes=6):
+    """A table and boxes sampled on ALL faces, with the analytic outward normals: a full-antipodal grasp
+    (antipodal.cpp:54-81) needs surface normals that point at both fingers, which a single-view cloud whose
+    normals are flipped towards the viewpoint (hand_search.cpp:88) never has -- the cloud brings its normals
+    (CloudCamera(PointCloudNormal), cloud_camera.cpp:4-32)."""
+    rng = np.random.default_rng(seed)
+    dens = 1.0 / (0.003 ** 2)
+    m = int(0.5 * 0.6 * dens)
+    pts = [np.stack([rng.uniform(0.5, 1.0, m), rng.uniform(-0.3, 0.3, m), np.full(m, scene.TABLE_Z)], axis=1)]
+    nrm = [np.tile([0.0, 0.0, 1.0], (m, 1))]
+    for k in range(n_boxes):
+        size = np.array([rng.uniform(0.025, 0.05), rng.uniform(0.06, 0.12), rng.uniform(0.08, 0.15)])
+        c = np.array([0.58 + 0.07 * k, rng.uniform(-0.2, 0.2), scene.TABLE_Z + 0.5 * size[2]])
+        p, n = scene._box(rng, c, size, rng.uniform(0, np.pi), dens)
+        pts.append(p)
+        nrm.append(n)
+    p = np.concatenate(pts)
+    p = p + rng.normal(scale=0.0003, size=p.shape)
+    ws = np.array([0.45, 1.05, -0.35, 0.35, scene.TABLE_Z - 0.05, 1.0])
+    return p.astype(np.float32), np.concatenate(nrm).astype(np.float32), ws
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,min_inliers", [(0, 0), (0, 1), (2, 0), (2, 1)])
-def test_cpp_detect_modes_none_and_geometric(tmp_path, small_scene, mode, min_inliers):
+def test_cpp_detect_modes_none_and_geometric(tmp_path, mode, min_inliers):
     """GraspDetector::detectGraspPoses with antipodal_mode NONE / GEOMETRIC (grasp_detector.cpp:163-252).
     NONE returns the pruned hypotheses as they are -- BEFORE the clustering and the selection (:170-176),
     whatever min_inliers says; GEOMETRIC keeps the full-antipodal ones (:214-221), clusters them when
@@ -201,8 +223,10 @@ def test_cpp_detect_modes_none_and_geometric(tmp_path, small_scene, mode, min_in
     from oracle import api
     tmp = str(tmp_path)
     exe = build_driver(tmp)
-    xyz, ws, idx = small_scene
+    xyz, nrm, ws = two_sided_scene(1)
+    idx = scene.draw_samples(3, xyz.shape[0], 400)
     xyz.astype("<f4").tofile(os.path.join(tmp, "cloud.f32"))
+    nrm.astype("<f4").tofile(os.path.join(tmp, "normals.f32"))
     idx.astype("<i4").tofile(os.path.join(tmp, "idx.i32"))
     seed, num_selected = 5, 7
     text = params_text(ws, "", "", seed).replace("antipodal_mode = 1", f"antipodal_mode = {mode}")
@@ -210,22 +234,23 @@ def test_cpp_detect_modes_none_and_geometric(tmp_path, small_scene, mode, min_in
     open(os.path.join(tmp, "params.txt"), "w").write(text)
     outp = os.path.join(tmp, "out.bin")
     r = subprocess.run([exe, "--modes", os.path.join(tmp, "cloud.f32"), os.path.join(tmp, "idx.i32"),
-                        os.path.join(tmp, "params.txt"), outp], capture_output=True, text=True, timeout=300)
+                        os.path.join(tmp, "params.txt"), outp, os.path.join(tmp, "normals.f32")],
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert f"modes ok: mode {mode}, min_inliers {min_inliers}" in r.stdout
 
     o = api.Oracle(**dict(scene_params(ws, min_score_diff=-1e30, num_selected=num_selected), num_threads=4))
-    o.set_cloud(xyz)
-    o.compute_normals()
+    o.set_cloud(xyz, normals=nrm.T.astype(np.float64))
     hyps = o.generate_hypotheses(sample_idx=idx, seed=seed)
     keep = o.prune(len(hyps)).astype(bool)
     want = hyps[keep]
     assert len(want) > num_selected
     if mode == 2:
         want = want[want["full_antipodal"] == 1]
-        assert len(want) > 0
+        assert len(want) > num_selected
         if min_inliers > 0:
             want = o.find_clusters(want, min_inliers)
+            assert len(want) > num_selected
         want = want[:num_selected]
     rec = np.frombuffer(open(outp, "rb").read(), dtype=np.dtype(
         [("slot", "<i4"), ("orient", "<i4"), ("full", "<i4"), ("half", "<i4"), ("score", "<f8"), ("bottom", "<f8", 3)]),

@@ -191,7 +191,7 @@ def test_one_round_trip_detect_equals_the_step_by_step_form(small_scene):
         d.close()
     # shapes that do not hold: learn on a bare table (no hypotheses: capacity for 256 images), then a
     # cluttered one with the same number of samples
-    bare, ws1 = scene.make_scene(seed=21, n_target=20000, kind="plane")
+    bare, ws1 = scene.make_scene(seed=21, n_target=60000, kind="plane")
     busy, ws2 = scene.make_scene(seed=22, n_target=60000, kind="tabletop")
     wsu = [min(ws1[0], ws2[0]), max(ws1[1], ws2[1]), min(ws1[2], ws2[2]), max(ws1[3], ws2[3]),
            min(ws1[4], ws2[4]), max(ws1[5], ws2[5])]
@@ -200,11 +200,18 @@ def test_one_round_trip_detect_equals_the_step_by_step_form(small_scene):
     for x in (d, e):
         x.lenet_load(w)
     s = 2500
-    i1, i2 = scene.draw_samples(1, bare.shape[0], s), scene.draw_samples(2, busy.shape[0], s)
+    # samples of the bare table well away from its border: no hand finds anything to close around
+    lo, hi = bare.min(axis=0), bare.max(axis=0)
+    inner = np.flatnonzero((bare[:, 0] > lo[0] + 0.2) & (bare[:, 0] < hi[0] - 0.2) &
+                           (bare[:, 1] > lo[1] + 0.2) & (bare[:, 1] < hi[1] - 0.2)).astype(np.int32)
+    assert len(inner) > s
+    i1 = inner[scene.draw_samples(1, len(inner), s)]
+    i2 = scene.draw_samples(2, busy.shape[0], s)
     d.set_cloud(bare)
     d.compute_normals()
     for _ in range(2):
-        d.detect(sample_idx=i1, seed=1, do_prune=False, want_all=False)
+        _, n_bare = d.detect(sample_idx=i1, seed=1, do_prune=False, want_all=False)
+        assert n_bare == 0
     d.set_cloud(busy)
     d.compute_normals()
     got, n_got = d.detect(sample_idx=i2, seed=2, do_prune=False, want_all=False)   # must fall back
@@ -214,6 +221,11 @@ def test_one_round_trip_detect_equals_the_step_by_step_form(small_scene):
     want, want_all = e.detect(sample_idx=i2, seed=2, do_prune=False)
     assert len(want_all) > 300 and n_got == n_again == len(want_all)
     assert got.tobytes() == want.tobytes() == again.tobytes()
+    # the counters say which form served the calls: bare #2 in one trip; busy #1 launched at the bare
+    # table's shapes (256 images), found > 300 and ran again; busy #2 in one trip at the new shapes
+    cd, ce = d.counters(), e.counters()
+    assert (cd.detect_one_trip, cd.detect_redone) == (2, 1), (cd.detect_one_trip, cd.detect_redone)
+    assert (ce.detect_one_trip, ce.detect_redone) == (0, 0)
     d.close()
     e.close()
 

@@ -117,7 +117,9 @@ def test_empty_and_fully_filtered():
 
 
 @pytest.mark.parametrize("n,k,seed", [(5000, 100, 0), (5000, 4999, 1), (5000, 5000, 2), (5000, 9000, 3),
-                                      (200000, 5000, 4), (3, 1, 5), (70000, 1, 6), (70000, 69999, 7)])
+                                      (200000, 5000, 4), (3, 1, 5), (70000, 1, 6), (70000, 69999, 7),
+                                      # candidate lists of the one-workgroup selection (<= 8192 entries) and beyond
+                                      (300000, 2000, 11), (200000, 6000, 10), (200000, 8000, 8), (200000, 20000, 12)])
 def test_subsample_matches_oracle(n, k, seed):
     d, o = pair(workspace=[-10, 10, -10, 10, -10, 10])
     pts = np.random.default_rng(seed).uniform(-1, 1, size=(n, 3)).astype(np.float32)

@@ -181,10 +181,15 @@ def test_merge_of_the_ranks_selected_lists_on_the_gpu(world, min_inliers):
     ag2_merge_selected_device): the ranks' selected lists concatenated in rank order and the top
     num_selected by score, ties by position -- checked against the same merge done in numpy on the
     exported bytes, and against the unsplit run (same hypotheses; the scores of a tile can differ from
-    the unsplit run's in the last bits because ip1's split-K depends on the batch size)."""
+    the unsplit run's in the last bits because ip1's split-K depends on the batch size).
+    min_inliers > 0: HandleSearch::findClusters counts inliers over the hands of ALL ranks
+    (handle_search.cpp:4-80, grasp_detector.cpp:228-236), so the ranks export their lists before the
+    clustering and the merge clusters the gathered list -- checked against the oracle's findClusters on the
+    exported bytes, and (one rank) against the clustering ag2_detect does by itself."""
     import ctypes as C
     from agile_grasp2_amd import capi
     from agile_grasp2_amd.weights import make_lenet_weights
+    from oracle import api
     hip = C.CDLL("libamdhip64.so.7")
     hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]

@@ -1,10 +1,14 @@
 #!/bin/bash
-# kernel trace of one leg of the cfg5 stream: bash tools/prof_cfg5.sh <tag> [graph|plain|stepwise]
+# rocprofv3 kernel trace of the cfg5 graph leg (RAW frames through ag2_detect_frame_raw):
+#   tools/prof_cfg5.sh <tag>      (on the GPU box)  -> profiles/<tag>_cfg5_kernel_stats.csv
 set -e
-tag=${1:-x}
-export AG2_STREAM_LEG=${2:-graph}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
-out=$GRAFT_REPO_ROOT/gpurun_out/prof_cfg5_$tag
-rm -rf $out && mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --config cfg5 --steps 30 > $out/bench.json 2> $out/bench.err
-cd $GRAFT_REPO_ROOT && python profiles/summarize.py stats $out gpurun_out/prof_cfg5_${tag}_stats.csv
+R=$GRAFT_REPO_ROOT
+base=$R/gpurun_out/prof_${tag}_cfg5
+rm -rf ${base}_stats && mkdir -p ${base}_stats
+AG2_STREAM_LEG=graph rocprofv3 --kernel-trace --stats -d ${base}_stats --output-format csv -- python3 $R/bench.py --config cfg5 --steps 30 > ${base}_stats/bench.json 2> ${base}_stats/bench.err
+cd $R
+python profiles/summarize.py stats ${base}_stats profiles/${tag}_cfg5_kernel_stats.csv
+cp ${base}_stats/bench.json profiles/${tag}_cfg5_graph_leg_under_profiler.json
+mkdir -p gpurun_out/profiles_out && cp profiles/${tag}_cfg5_* gpurun_out/profiles_out/
