@@ -26,7 +26,10 @@ SYMBOLS = [
     "ag2_export_candidates_compact_device", "ag2_hand_constants",
     "ag2_stream_configure", "ag2_detect_frame", "ag2_get_frame_info",
     "ag2_export_selected_compact_device", "ag2_merge_selected_device",
-    "ag2_detect_frame_raw", "ag2_get_samples",
+    "ag2_detect_frame_raw", "ag2_get_samples", "ag2_gather_begin", "ag2_gather_selected", "ag2_merge_gathered",
+    "ag2_submit_frame", "ag2_submit_frame_raw", "ag2_wait_frame", "ag2_pipe_create", "ag2_pipe_destroy",
+    "ag2_pipe_last_error", "ag2_pipe_context", "ag2_pipe_lenet_load", "ag2_pipe_submit", "ag2_pipe_submit_raw",
+    "ag2_pipe_wait",
 ]
 
 
@@ -94,6 +97,13 @@ def load():
     L.ag2_last_error.restype = C.c_char_p
     L.ag2_last_error.argtypes = [C.c_void_p]
     L.ag2_default_params.argtypes = [C.POINTER(Params)]
+    L.ag2_pipe_create.restype = C.c_void_p
+    L.ag2_pipe_create.argtypes = [C.POINTER(Params), C.c_int, C.c_int]
+    L.ag2_pipe_destroy.argtypes = [C.c_void_p]
+    L.ag2_pipe_last_error.restype = C.c_char_p
+    L.ag2_pipe_last_error.argtypes = [C.c_void_p]
+    L.ag2_pipe_context.restype = C.c_void_p
+    L.ag2_pipe_context.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L
 
@@ -467,3 +477,78 @@ class Detector:
         t = Times()
         self._ck(self.L.ag2_get_stage_times(self.h, C.byref(t)))
         return t
+
+
+class Pipe:
+    """ag2_pipe: `depth` contexts on one GPU taken in turn by one caller thread (frames in flight overlap)."""
+
+    def __init__(self, params: Params | None = None, device: int = 0, depth: int = 2, **kw):
+        self.L = load()
+        self.params = params if params is not None else default_params(**kw)
+        h = self.L.ag2_pipe_create(C.byref(self.params), C.c_int(device), C.c_int(depth))
+        if not h:
+            raise RuntimeError("ag2_pipe_create failed: no usable HIP device or bad parameters")
+        self.h = C.c_void_p(h)
+        self.depth = depth
+        self._cap = 1
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ag2_pipe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libag2hip pipe (rc={rc}): " + self.L.ag2_pipe_last_error(self.h).decode())
+
+    def lenet_load(self, w):
+        arrs = [np.ascontiguousarray(w[k], dtype=np.float32) for k in (
+            "conv1_w", "conv1_b", "conv2_w", "conv2_b", "ip1_w", "ip1_b", "ip2_w", "ip2_b")]
+        self._ck(self.L.ag2_pipe_lenet_load(self.h, *[_ptr(a) for a in arrs]))
+
+    def stream_configure(self, use_graph=True):
+        for k in range(self.depth):
+            c = C.c_void_p(self.L.ag2_pipe_context(self.h, C.c_int(k)))
+            rc = self.L.ag2_stream_configure(c, C.c_size_t(0), C.c_size_t(0), C.c_int(1 if use_graph else 0))
+            if rc:
+                raise RuntimeError(f"ag2_stream_configure rc={rc}")
+
+    def submit_raw(self, xyz=None, num_samples=0, sample_seed=0, seed=0, do_prune=True, dptr=None, n=None, stride=12,
+                   filter_workspace=True, voxel_size=0.003):
+        if dptr is None:
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+            n, stride, ptr, on_dev = xyz.shape[0], 12, _ptr(xyz), 0
+        else:
+            ptr, on_dev = C.c_void_p(dptr), 1
+        self._cap = max(1, int(num_samples) * int(self.params.num_orientations))
+        self._ck(self.L.ag2_pipe_submit_raw(self.h, ptr, C.c_int(on_dev), C.c_size_t(n), C.c_size_t(stride),
+                                            C.c_int(int(filter_workspace)), C.c_double(voxel_size),
+                                            C.c_size_t(num_samples), C.c_uint64(sample_seed), C.c_uint64(seed),
+                                            C.c_int(1 if do_prune else 0)))
+
+    def submit(self, xyz=None, sample_idx=None, seed=0, do_prune=True, dptr=None, n=None, stride=12):
+        si = np.ascontiguousarray(sample_idx, dtype=np.int32)
+        if dptr is None:
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+            n, stride, ptr, on_dev = xyz.shape[0], 12, _ptr(xyz), 0
+        else:
+            ptr, on_dev = C.c_void_p(dptr), 1
+        self._cap = max(1, len(si) * int(self.params.num_orientations))
+        self._ck(self.L.ag2_pipe_submit(self.h, ptr, C.c_int(on_dev), C.c_size_t(n), C.c_size_t(stride), _ptr(si),
+                                        C.c_size_t(len(si)), C.c_uint64(seed), C.c_int(1 if do_prune else 0)))
+
+    def wait(self):
+        """(selected, n_scored, n_voxels) of the oldest frame in flight"""
+        nsel = int(self.params.num_selected)
+        cap = self._cap if nsel < 0 else max(1, min(self._cap, nsel))
+        if getattr(self, "_sel_buf", None) is None or len(self._sel_buf) < cap:
+            self._sel_buf = np.zeros(cap, dtype=HYP_DTYPE)
+        ns, na, nv = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._ck(self.L.ag2_pipe_wait(self.h, _ptr(self._sel_buf), C.c_size_t(cap), C.byref(ns), C.byref(na), C.byref(nv)))
+        return self._sel_buf[: ns.value].copy(), na.value, nv.value

@@ -242,7 +242,7 @@ void ag2_destroy(ag2_ctx* c) {
                     &c->d_nrm, &c->d_scan, &c->d_stats, &c->d_hc, &c->d_sample_q, &c->d_frames,
                     &c->d_frame_ok, &c->d_table, &c->d_tab_off, &c->d_tab_keep, &c->d_arena,
                     &c->d_overflow, &c->d_gscratch, &c->d_list, &c->d_list2, &c->d_images,
-                    &c->d_logits, &c->d_act1, &c->d_fcpart, &c->d_tmp, &c->d_sel, &c->d_merge, &c->d_flags, &c->d_desc,
+                    &c->d_logits, &c->d_act1, &c->d_fcpart, &c->d_tmp, &c->d_sel, &c->d_merge, &c->d_gather, &c->d_xchg, &c->d_flags, &c->d_desc,
                     &c->d_raw, &c->d_raw_nrm, &c->d_pre, &c->d_pflags, &c->d_bitmap, &c->d_wrank,
                     &c->d_first, &c->d_prestats, &c->d_hist, &c->d_samples, &c->d_preframe, &c->d_cand, &c->d_cluster, &c->d_cluster_tmp, &c->net.w1p, &c->net.b1,
                     &c->net.w2p, &c->net.b2, &c->net.w3p, &c->net.b3, &c->net.w4, &c->net.b4,

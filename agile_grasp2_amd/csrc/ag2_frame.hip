@@ -36,6 +36,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "ag2_internal.h"
 
@@ -67,6 +68,28 @@ struct ag2_frame_state {
   // ag2_detect_frame_raw: the shapes of the front end (raw == false: frames arrive preprocessed)
   bool raw = false;
   ag2::FrontShapes fs{};
+  // a frame that has been submitted and not yet waited for (ag2_submit_frame* / ag2_wait_frame)
+  struct Pending {
+    bool active = false;
+    bool finished = false;       // ran step by step inside the submit: the results below are final
+    bool replay = false;         // the fixed-shape sequence went out as a graph launch
+    bool unsupported = false;
+    int rc = 0;
+    const void* xyz = nullptr;   // the caller's buffer (device clouds) or the device staging copy
+    int on_device = 0;
+    size_t n = 0, stride = 12;
+    bool raw = false;
+    int filter_ws = 1;
+    double voxel_size = 0.003;
+    size_t num_samples = 0;
+    uint64_t sample_seed = 0, seed = 0;
+    int do_prune = 1;
+    std::vector<int32_t> idx;    // copy of the caller's sample indices
+    std::vector<ag2_hypothesis> recs;
+    size_t n_selected = 0, n_scored = 0, n_voxels = 0;
+  } pend;
+  char* h_stage = nullptr;       // page-locked staging of a cloud handed over in host memory (true async H2D)
+  size_t h_stage_bytes = 0;
 };
 
 namespace ag2 {
@@ -331,8 +354,93 @@ struct FrameModeGuard {
   }
 };
 
-int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, size_t cap, size_t* n_selected,
-                      size_t* n_scored, size_t* n_voxels) {
+// shapes for the frames to come, from a frame that just ran step by step (the context holds its results)
+void learn_shapes(ag2_ctx* c, ag2_frame_state* f, const FrameIn& in, size_t n_vox, size_t s_used) {
+  const int R = c->p.num_orientations;
+  const size_t n = in.n;
+  if (f->raw != in.raw) {
+    c->fm_n_max = c->fm_s_max = 0;
+    f->fs = FrontShapes{};
+  }
+  f->raw = in.raw;
+  const size_t n_cloud = in.raw ? n_vox : n;
+  c->fm_n_max = std::max(c->fm_n_max, n_cloud + n_cloud / 8 + 1024);
+  c->fm_s_max = in.raw ? s_used : std::max(c->fm_s_max, s_used);
+  long long cells = 1;
+  for (int a = 0; a < 3; a++) cells *= (long long)(c->grid.dims[a] + 8);
+  cells = std::min<long long>(cells + cells / 2, 1ll << 30);
+  c->fm_cap_cells = std::max<size_t>(c->fm_cap_cells, (size_t)cells);
+  if (in.raw) {
+    f->fs.raw_max = std::max(f->fs.raw_max, n + n / 8 + 1024);
+    // bitmap of the voxel lattice: this frame's with half as much again (at least 16 voxels) of room per
+    // axis -- an object taller than anything seen so far must not cost a frame --, but never more than the
+    // workspace can hold when it filters
+    double words = 1.0;
+    for (int a = 0; a < 3; a++) words *= (double)(c->last_vox_dims[a] + std::max(16, c->last_vox_dims[a] / 2));
+    words = words / 32.0 + 2.0;
+    if (in.filter_ws) {
+      double wsw = 1.0;
+      for (int a = 0; a < 3; a++)
+        wsw *= floor((c->p.workspace[2 * a + 1] - c->p.workspace[2 * a]) / (double)(float)in.voxel_size) + 2.0;
+      if (wsw >= 1.0) words = std::min(words, wsw / 32.0 + 2.0);
+    }
+    f->fs.cap_words = std::max(f->fs.cap_words, (size_t)std::min(words, 1.0e9));
+    f->fs.n_max = c->fm_n_max;
+    f->fs.num_samples = s_used;
+    f->fs.cand_cap = cand_capacity(s_used);
+    f->fs.cell = (float)in.voxel_size;
+    f->fs.filter_workspace = in.filter_ws ? 1 : 0;
+  }
+  // images: twice what this frame scored, in whole batches of 256 (BASELINE.json configs[4]:
+  // batch_size 256), never below the shapes already in force
+  const size_t want_img = (((size_t)c->n_img * 2 + 512) + 255) / 256 * 256;
+  f->cap_p = std::max(f->cap_p, 2 * c->max_p);  // which renderers the sequence launches
+  f->cap_img = std::min(std::max(f->cap_img, want_img), c->fm_s_max * (size_t)R);
+  f->k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, f->cap_img) : f->cap_img;
+  f->shapes_known = c->fm_s_max * (size_t)R <= 65536;
+}
+
+FrameIn pending_in(const ag2_frame_state::Pending& p) {
+  FrameIn in;
+  in.xyz = p.xyz;
+  in.on_device = p.on_device;
+  in.n = p.n;
+  in.stride = p.stride;
+  in.raw = p.raw;
+  in.filter_ws = p.filter_ws;
+  in.voxel_size = p.voxel_size;
+  in.num_samples = p.num_samples;
+  in.sample_seed = p.sample_seed;
+  in.sample_idx = p.idx.empty() ? nullptr : p.idx.data();
+  in.s = p.idx.size();
+  in.seed = p.seed;
+  in.do_prune = p.do_prune;
+  return in;
+}
+
+// the frame step by step, its results kept in the pending record, the shapes learned
+int run_pending_stepwise(ag2_ctx* c, ag2_frame_state* f) {
+  ag2_frame_state::Pending& p = f->pend;
+  const FrameIn in = pending_in(p);
+  const size_t s_req = in.raw ? in.num_samples : in.s;
+  const size_t cap = std::max<size_t>(1, s_req * (size_t)c->p.num_orientations);
+  p.recs.resize((c->p.num_selected >= 0) ? std::max<size_t>(1, std::min<size_t>(cap, (size_t)c->p.num_selected)) : cap);
+  f->info.stepwise_runs++;
+  size_t n_vox = in.n, s_used = in.s;
+  p.n_selected = p.n_scored = 0;
+  const int rc = frame_stepwise(c, p.xyz, in, p.recs.data(), p.recs.size(), &p.n_selected, &p.n_scored, &n_vox, &s_used);
+  p.n_voxels = n_vox;
+  p.finished = true;
+  p.rc = rc;
+  if (rc) return rc;
+  // a raw frame with no more voxels than num_samples takes every point as a sample (grasp_detector.cpp:322-330):
+  // that is not what the fixed-shape sub-sampling does, such frames stay on this path
+  if (!p.unsupported && !(in.raw && s_used != in.num_samples)) learn_shapes(c, f, in, n_vox, s_used);
+  return 0;
+}
+
+// ---- submit: everything of a frame up to (not including) the wait for its results -------------------
+int frame_submit(ag2_ctx* c, const FrameIn& in) {
   if (c->p.n_cams != 1) return set_err(c, AG2_ERR_ARG, "frames are single-camera clouds");
   if (in.stride < 12 || in.stride % 4 != 0) return set_err(c, AG2_ERR_ARG, "bad stride");
   if (in.n > (size_t)1 << 30) return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 points");
@@ -340,26 +448,53 @@ int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, s
   if (!c->net.loaded) return set_err(c, AG2_ERR_STATE, "lenet weights not loaded");
   if (!c->fm) c->fm = new ag2_frame_state();
   ag2_frame_state* f = c->fm;
+  if (f->pend.active) return set_err(c, AG2_ERR_STATE, "a frame is in flight on this context: ag2_wait_frame first");
   const int R = c->p.num_orientations;
   const size_t n = in.n;
-  // a cloud in host memory goes through a device staging buffer first
+  ag2_frame_state::Pending& p = f->pend;
+  p = ag2_frame_state::Pending{};
+  // A cloud in host memory goes through page-locked staging (the host copies, then a true asynchronous
+  // DMA: the call does not wait for the transfer) into a device staging buffer.
   const void* d_xyz = in.xyz;
   if (!in.on_device && n) {
-    AG2_HIP(c, f->d_raw.reserve(n * in.stride));
-    AG2_HIP(c, hipMemcpyAsync(f->d_raw.p, in.xyz, n * in.stride, hipMemcpyHostToDevice, c->stream));
+    const size_t bytes = n * in.stride;
+    if (bytes > f->h_stage_bytes) {
+      AG2_HIP(c, hipStreamSynchronize(c->stream));
+      if (f->h_stage) (void)hipHostFree(f->h_stage);
+      f->h_stage = nullptr;
+      f->h_stage_bytes = 0;
+      const size_t want = bytes + bytes / 8 + 4096;
+      AG2_HIP(c, hipHostMalloc((void**)&f->h_stage, want, hipHostMallocDefault));
+      f->h_stage_bytes = want;
+    }
+    AG2_HIP(c, f->d_raw.reserve(bytes));
+    memcpy(f->h_stage, in.xyz, bytes);
+    AG2_HIP(c, hipMemcpyAsync(f->d_raw.p, f->h_stage, bytes, hipMemcpyHostToDevice, c->stream));
     d_xyz = f->d_raw.p;
   }
+  p.active = true;
+  p.xyz = d_xyz;
+  p.on_device = 1;
+  p.n = n;
+  p.stride = in.stride;
+  p.raw = in.raw;
+  p.filter_ws = in.filter_ws;
+  p.voxel_size = in.voxel_size;
+  p.num_samples = in.num_samples;
+  p.sample_seed = in.sample_seed;
+  p.seed = in.seed;
+  p.do_prune = in.do_prune;
+  if (!in.raw && in.s) p.idx.assign(in.sample_idx, in.sample_idx + in.s);
   f->info.frames++;
-  if (n_voxels) *n_voxels = in.raw ? 0 : n;
   const size_t s_req = in.raw ? in.num_samples : in.s;
   // Frames the captured sequence cannot take: clustering inside detect (k_cluster is not part of
   // it), more than 65536 table slots, an empty frame, the f32-input LeNet kernels.
-  const bool unsupported = c->min_inliers > 0 || s_req * (size_t)R > 65536 || n == 0 || s_req == 0 || !c->net.use_x3;
+  p.unsupported = c->min_inliers > 0 || s_req * (size_t)R > 65536 || n == 0 || s_req == 0 || !c->net.use_x3;
   if (f->shapes_known && f->raw != in.raw) {  // the stream changed its entry point: learn the shapes again
     f->shapes_known = false;
     drop_graph(f);
   }
-  bool stepwise = unsupported || !f->shapes_known;
+  bool stepwise = p.unsupported || !f->shapes_known;
   if (!stepwise) {
     if (in.raw)
       stepwise = n > f->fs.raw_max || in.num_samples != c->fm_s_max || (float)in.voxel_size != f->fs.cell ||
@@ -367,65 +502,97 @@ int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, s
     else
       stepwise = n > c->fm_n_max || in.s > c->fm_s_max;
   }
-  if (!stepwise) {
-    // ---- the frame at fixed shapes: pack + extent in front, then the sequence (graph or plain) ----
-    FrameModeGuard guard(c);
-    c->fm_on = true;
-    c->fm_grid_ready = in.raw;
-    int rc = frame_pin_reserve(c, f);
-    if (rc) return rc;
-    FrameArgs* fa = (FrameArgs*)f->h_pin;
-    fa->seed = in.seed;
-    fa->slot_base = 0;
-    fa->sample_seed = in.sample_seed;
-    if (!in.raw) {
-      int32_t* hidx = (int32_t*)(f->h_pin + f->off_idx);
-      memcpy(hidx, in.sample_idx, in.s * 4);
-      for (size_t i = in.s; i < c->fm_s_max; i++) hidx[i] = -1;
+  if (stepwise) {
+    // the first frame, frames that outgrow the shapes, unsupported settings: step by step, here and now
+    const int rc = run_pending_stepwise(c, f);
+    if (rc) p.active = false;
+    return rc;
+  }
+  // ---- the frame at fixed shapes: pack + extent in front, then the sequence (graph or plain) ----
+  FrameModeGuard guard(c);
+  c->fm_on = true;
+  c->fm_grid_ready = in.raw;
+  auto fail = [&](int rc) {
+    p.active = false;
+    return rc;
+  };
+  int rc = frame_pin_reserve(c, f);
+  if (rc) return fail(rc);
+  FrameArgs* fa = (FrameArgs*)f->h_pin;
+  fa->seed = in.seed;
+  fa->slot_base = 0;
+  fa->sample_seed = in.sample_seed;
+  if (!in.raw) {
+    int32_t* hidx = (int32_t*)(f->h_pin + f->off_idx);
+    memcpy(hidx, in.sample_idx, in.s * 4);
+    for (size_t i = in.s; i < c->fm_s_max; i++) hidx[i] = -1;
+  }
+  if (c->d_xyz_in.reserve(c->fm_n_max * 16) != hipSuccess || c->d_bounds.reserve((size_t)128 * 8 * 4) != hipSuccess ||
+      c->d_griddesc.reserve(sizeof(GridDesc)) != hipSuccess)
+    return fail(set_err(c, AG2_ERR_HIP, "frame: device allocation failed"));
+  if (in.raw) rc = front_pack_raw(c, d_xyz, n, in.stride, f->fs);
+  else rc = pack_device_xyz(c, d_xyz, n, in.stride, c->d_xyz_in.as<float4>(), /*with_bounds=*/true, c->fm_n_max);
+  if (rc) return fail(rc);
+  p.replay = f->use_graph && f->graph_valid && f->do_prune == in.do_prune && f->sig_at_capture == frame_signature(c, f);
+  if (p.replay) {
+    if (hipGraphLaunch(f->exec, c->stream) != hipSuccess) return fail(set_err(c, AG2_ERR_HIP, "hipGraphLaunch failed"));
+    f->info.graph_replays++;
+  } else {
+    drop_graph(f);
+    const int lvl = c->stage_timing;
+    c->stage_timing = 0;  // (events are not part of the sequence)
+    rc = enqueue_frame(c, f, in.do_prune);
+    c->stage_timing = lvl;
+    if (rc) return fail(rc);
+    f->info.plain_runs++;
+  }
+  return 0;
+}
+
+// ---- wait: the results of the submitted frame -------------------------------------------------------
+int frame_wait(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored,
+               size_t* n_voxels) {
+  ag2_frame_state* f = c->fm;
+  if (!f || !f->pend.active) return set_err(c, AG2_ERR_STATE, "no frame in flight on this context");
+  ag2_frame_state::Pending& p = f->pend;
+  const int R = c->p.num_orientations;
+  if (!p.finished) {
+    const FrameIn in = pending_in(p);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {
+      p.active = false;
+      return set_err(c, AG2_ERR_HIP, "frame: hipStreamSynchronize failed");
     }
-    AG2_HIP(c, c->d_xyz_in.reserve(c->fm_n_max * 16));
-    AG2_HIP(c, c->d_bounds.reserve((size_t)128 * 8 * 4));
-    AG2_HIP(c, c->d_griddesc.reserve(sizeof(GridDesc)));
-    if (in.raw) rc = front_pack_raw(c, d_xyz, n, in.stride, f->fs);
-    else rc = pack_device_xyz(c, d_xyz, n, in.stride, c->d_xyz_in.as<float4>(), /*with_bounds=*/true, c->fm_n_max);
-    if (rc) return rc;
-    const bool replay = f->use_graph && f->graph_valid && f->do_prune == in.do_prune &&
-                        f->sig_at_capture == frame_signature(c, f);
-    if (replay) {
-      AG2_HIP(c, hipGraphLaunch(f->exec, c->stream));
-      f->info.graph_replays++;
-    } else {
-      drop_graph(f);
-      const int lvl = c->stage_timing;
-      c->stage_timing = 0;  // (events are not part of the sequence)
-      rc = enqueue_frame(c, f, in.do_prune);
-      c->stage_timing = lvl;
-      if (rc) return rc;
-      f->info.plain_runs++;
-    }
-    AG2_HIP(c, hipStreamSynchronize(c->stream));
     const FrameOut* fo = (const FrameOut*)(f->h_pin + f->off_out);
     const unsigned flags = fo->st.err_flags;
     const bool bad = (flags & (1u | 2u | 8u)) != 0 || fo->g.ncells < 0 || fo->topk_overflow != 0 ||
                      (size_t)fo->st.n_list > std::min(f->cap_img, c->fm_s_max * (size_t)R) ||
                      (int)fo->st.max_p > render_capacity_for(f->cap_p) || (in.raw && fo->pre.flags != 0u);
     if (bad) {
-      if (fo->g.ncells == -2)
+      if (fo->g.ncells == -2) {
+        p.active = false;
         return set_err(c, AG2_ERR_ARG, "a point lies below the grid origin given to ag2_set_grid_origin");
+      }
       f->info.fallbacks++;
       f->info.last_fallback = (int64_t)(flags & (1u | 2u | 8u)) | (fo->g.ncells < 0 ? 16 : 0) |
                               (fo->topk_overflow ? 32 : 0) |
                               ((size_t)fo->st.n_list > std::min(f->cap_img, c->fm_s_max * (size_t)R) ? 64 : 0) |
                               ((int)fo->st.max_p > render_capacity_for(f->cap_p) ? 128 : 0) |
                               (in.raw ? ((int64_t)fo->pre.flags << 8) : 0);
-      f->shapes_known = false;  // learn the shapes again from the step-by-step run below
-      stepwise = true;
+      f->shapes_known = false;  // learn the shapes again from the step-by-step run
+      const int rc = run_pending_stepwise(c, f);
+      if (rc) {
+        p.active = false;
+        return rc;
+      }
     } else {
       // capture for the frames to come (right after the run that gave every buffer its size)
-      if (!replay && f->use_graph) {
+      if (!p.replay && f->use_graph) {
         if (c->stream == nullptr) {
           f->info.capture_refused++;  // the legacy default stream cannot be captured
         } else {
+          FrameModeGuard guard(c);
+          c->fm_on = true;
+          c->fm_grid_ready = in.raw;
           const unsigned long long sig0 = frame_signature(c, f);
           const int lvl = c->stage_timing;
           c->stage_timing = 0;
@@ -449,7 +616,7 @@ int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, s
         }
       }
       // results
-      const size_t n_cloud = in.raw ? (size_t)fo->pre.n_vox : n;
+      const size_t n_cloud = in.raw ? (size_t)fo->pre.n_vox : in.n;
       const size_t s = in.raw ? in.num_samples : in.s;
       c->n = n_cloud;
       c->n_valid = (size_t)fo->g.n_valid;
@@ -479,6 +646,7 @@ int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, s
       c->cnt.list_points = (int64_t)fo->st.list_top;
       const size_t k = fo->n_out;
       c->cnt.n_selected = (int64_t)k;
+      p.active = false;
       *n_selected = k;
       if (n_scored) *n_scored = fo->st.n_list;
       if (n_voxels) *n_voxels = n_cloud;
@@ -487,58 +655,21 @@ int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, s
       return 0;
     }
   }
-  // ---- step-by-step path: the first frame, frames that outgrow the shapes, unsupported settings ----
-  f->info.stepwise_runs++;
-  size_t n_vox = n, s_used = in.s;
-  const int rc = frame_stepwise(c, d_xyz, in, selected, cap, n_selected, n_scored, &n_vox, &s_used);
-  if (n_voxels) *n_voxels = n_vox;
-  if (rc) return rc;
-  // a raw frame with no more voxels than num_samples takes every point as a sample (grasp_detector.cpp:322-330):
-  // that is not what the fixed-shape sub-sampling does, such frames stay on this path
-  if (!unsupported && !(in.raw && s_used != in.num_samples)) {
-    // shapes for the frames to come: this frame's, with room for the cloud to move and grow
-    if (f->raw != in.raw) {
-      c->fm_n_max = c->fm_s_max = 0;
-      f->fs = FrontShapes{};
-    }
-    f->raw = in.raw;
-    const size_t n_cloud = in.raw ? n_vox : n;
-    c->fm_n_max = std::max(c->fm_n_max, n_cloud + n_cloud / 8 + 1024);
-    c->fm_s_max = in.raw ? s_used : std::max(c->fm_s_max, s_used);
-    long long cells = 1;
-    for (int a = 0; a < 3; a++) cells *= (long long)(c->grid.dims[a] + 8);
-    cells = std::min<long long>(cells + cells / 2, 1ll << 30);
-    c->fm_cap_cells = std::max<size_t>(c->fm_cap_cells, (size_t)cells);
-    if (in.raw) {
-      f->fs.raw_max = std::max(f->fs.raw_max, n + n / 8 + 1024);
-      // bitmap of the voxel lattice: this frame's with half as much again (at least 16 voxels) of room per
-      // axis -- an object taller than anything seen so far must not cost a frame --, but never more than the
-      // workspace can hold when it filters
-      double words = 1.0;
-      for (int a = 0; a < 3; a++) words *= (double)(c->last_vox_dims[a] + std::max(16, c->last_vox_dims[a] / 2));
-      words = words / 32.0 + 2.0;
-      if (in.filter_ws) {
-        double wsw = 1.0;
-        for (int a = 0; a < 3; a++)
-          wsw *= floor((c->p.workspace[2 * a + 1] - c->p.workspace[2 * a]) / (double)(float)in.voxel_size) + 2.0;
-        if (wsw >= 1.0) words = std::min(words, wsw / 32.0 + 2.0);
-      }
-      f->fs.cap_words = std::max(f->fs.cap_words, (size_t)std::min(words, 1.0e9));
-      f->fs.n_max = c->fm_n_max;
-      f->fs.num_samples = s_used;
-      f->fs.cand_cap = cand_capacity(s_used);
-      f->fs.cell = (float)in.voxel_size;
-      f->fs.filter_workspace = in.filter_ws ? 1 : 0;
-    }
-    // images: twice what this frame scored, in whole batches of 256 (BASELINE.json configs[4]:
-    // batch_size 256), never below the shapes already in force
-    const size_t want_img = (((size_t)c->n_img * 2 + 512) + 255) / 256 * 256;
-    f->cap_p = std::max(f->cap_p, 2 * c->max_p);  // which renderers the sequence launches
-    f->cap_img = std::min(std::max(f->cap_img, want_img), c->fm_s_max * (size_t)R);
-    f->k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, f->cap_img) : f->cap_img;
-    f->shapes_known = c->fm_s_max * (size_t)R <= 65536;
-  }
+  // the frame ran step by step (inside the submit, or just now as a fallback): its results were kept
+  p.active = false;
+  *n_selected = p.n_selected;
+  if (n_scored) *n_scored = p.n_scored;
+  if (n_voxels) *n_voxels = p.n_voxels;
+  if (p.n_selected > cap) return set_err(c, AG2_ERR_CAPACITY, "detect_frame: output capacity too small");
+  if (p.n_selected) memcpy(selected, p.recs.data(), p.n_selected * sizeof(ag2_hypothesis));
   return 0;
+}
+
+int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, size_t cap, size_t* n_selected,
+                      size_t* n_scored, size_t* n_voxels) {
+  const int rc = frame_submit(c, in);
+  if (rc) return rc;
+  return frame_wait(c, selected, cap, n_selected, n_scored, n_voxels);
 }
 
 }  // namespace
@@ -548,6 +679,7 @@ void frame_release(ag2_ctx* c) {
   if (!f) return;
   drop_graph(f);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
+  if (f->h_stage) (void)hipHostFree(f->h_stage);
   f->d_raw.release();
   delete f;
   c->fm = nullptr;
@@ -613,6 +745,147 @@ int ag2_detect_frame_raw(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t 
   in.seed = seed;
   in.do_prune = do_prune;
   return detect_frame_impl(c, in, selected, cap, n_selected, n_scored, n_voxels);
+}
+
+// ---- the asynchronous form: submit a frame, do something else (submit the next one to another context),
+// wait for its results ----
+int ag2_submit_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                     const int32_t* sample_idx, size_t s, uint64_t seed, int do_prune) {
+  if (!c || (s && !sample_idx) || (n && !xyz)) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  FrameIn in;
+  in.xyz = xyz;
+  in.on_device = xyz_on_device;
+  in.n = n;
+  in.stride = stride_bytes;
+  in.sample_idx = sample_idx;
+  in.s = s;
+  in.seed = seed;
+  in.do_prune = do_prune;
+  return frame_submit(c, in);
+}
+
+int ag2_submit_frame_raw(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                         int filter_workspace, double voxel_size, size_t num_samples, uint64_t sample_seed,
+                         uint64_t seed, int do_prune) {
+  if (!c || (n && !xyz)) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  FrameIn in;
+  in.xyz = xyz;
+  in.on_device = xyz_on_device;
+  in.n = n;
+  in.stride = stride_bytes;
+  in.raw = true;
+  in.filter_ws = filter_workspace ? 1 : 0;
+  in.voxel_size = voxel_size;
+  in.num_samples = num_samples;
+  in.sample_seed = sample_seed;
+  in.seed = seed;
+  in.do_prune = do_prune;
+  return frame_submit(c, in);
+}
+
+int ag2_wait_frame(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored,
+                   size_t* n_voxels) {
+  if (!c || !n_selected) return AG2_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  return frame_wait(c, selected, cap, n_selected, n_scored, n_voxels);
+}
+
+// ---- ag2_pipe: one caller thread, several frames in flight ------------------------------------------
+// `depth` contexts on one GPU, each with its own stream, taken in turn: while the tail of frame k (LeNet,
+// selection) runs on one stream, the front of frame k + 1 (transfer, front end, grid, normals, sweep) runs on
+// the next -- one cloud alone does not fill 256 CUs.  Results come back in submission order.
+struct ag2_pipe {
+  std::vector<ag2_ctx*> ctx;
+  size_t next_submit = 0, next_wait = 0, in_flight = 0;
+  std::string err;
+};
+
+ag2_pipe* ag2_pipe_create(const ag2_params* p, int device_id, int depth) {
+  if (!p || depth < 1 || depth > 8) return nullptr;
+  ag2_pipe* q = new ag2_pipe();
+  for (int k = 0; k < depth; k++) {
+    ag2_ctx* c = ag2_create(p, device_id);
+    if (!c) {
+      ag2_pipe_destroy(q);
+      return nullptr;
+    }
+    (void)ag2_set_stage_timing(c, 0);  // (events serialise the streams)
+    q->ctx.push_back(c);
+  }
+  return q;
+}
+
+void ag2_pipe_destroy(ag2_pipe* q) {
+  if (!q) return;
+  for (ag2_ctx* c : q->ctx) ag2_destroy(c);
+  delete q;
+}
+
+const char* ag2_pipe_last_error(const ag2_pipe* q) { return q ? q->err.c_str() : "null pipe"; }
+ag2_ctx* ag2_pipe_context(ag2_pipe* q, int k) { return (q && k >= 0 && (size_t)k < q->ctx.size()) ? q->ctx[(size_t)k] : nullptr; }
+
+int ag2_pipe_lenet_load(ag2_pipe* q, const float* c1w, const float* c1b, const float* c2w, const float* c2b,
+                        const float* f1w, const float* f1b, const float* f2w, const float* f2b) {
+  if (!q) return AG2_ERR_ARG;
+  for (ag2_ctx* c : q->ctx) {
+    const int rc = ag2_lenet_load(c, c1w, c1b, c2w, c2b, f1w, f1b, f2w, f2b);
+    if (rc) {
+      q->err = ag2_last_error(c);
+      return rc;
+    }
+  }
+  return 0;
+}
+
+static int pipe_submitted(ag2_pipe* q, ag2_ctx* c, int rc) {
+  if (rc) {
+    q->err = ag2_last_error(c);
+    return rc;
+  }
+  q->next_submit = (q->next_submit + 1) % q->ctx.size();
+  q->in_flight++;
+  return 0;
+}
+
+int ag2_pipe_submit_raw(ag2_pipe* q, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                        int filter_workspace, double voxel_size, size_t num_samples, uint64_t sample_seed,
+                        uint64_t seed, int do_prune) {
+  if (!q) return AG2_ERR_ARG;
+  if (q->in_flight == q->ctx.size()) {
+    q->err = "pipe full: ag2_pipe_wait first";
+    return AG2_ERR_STATE;
+  }
+  ag2_ctx* c = q->ctx[q->next_submit];
+  return pipe_submitted(q, c, ag2_submit_frame_raw(c, xyz, xyz_on_device, n, stride_bytes, filter_workspace, voxel_size,
+                                                   num_samples, sample_seed, seed, do_prune));
+}
+
+int ag2_pipe_submit(ag2_pipe* q, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                    const int32_t* sample_idx, size_t s, uint64_t seed, int do_prune) {
+  if (!q) return AG2_ERR_ARG;
+  if (q->in_flight == q->ctx.size()) {
+    q->err = "pipe full: ag2_pipe_wait first";
+    return AG2_ERR_STATE;
+  }
+  ag2_ctx* c = q->ctx[q->next_submit];
+  return pipe_submitted(q, c, ag2_submit_frame(c, xyz, xyz_on_device, n, stride_bytes, sample_idx, s, seed, do_prune));
+}
+
+int ag2_pipe_wait(ag2_pipe* q, ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored,
+                  size_t* n_voxels) {
+  if (!q || !n_selected) return AG2_ERR_ARG;
+  if (q->in_flight == 0) {
+    q->err = "pipe empty: nothing was submitted";
+    return AG2_ERR_STATE;
+  }
+  ag2_ctx* c = q->ctx[q->next_wait];
+  const int rc = ag2_wait_frame(c, selected, cap, n_selected, n_scored, n_voxels);
+  q->next_wait = (q->next_wait + 1) % q->ctx.size();
+  q->in_flight--;
+  if (rc) q->err = ag2_last_error(c);
+  return rc;
 }
 
 int ag2_get_frame_info(ag2_ctx* c, ag2_frame_info* out) {

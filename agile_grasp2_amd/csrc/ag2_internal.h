@@ -211,6 +211,9 @@ struct ag2_ctx {
   ag2::DevBuf d_tmp;       // misc staging
   ag2::DevBuf d_sel;       // ag2_hypothesis: scored records with score >= min_score_diff, list order (+ count trailer)
   ag2::DevBuf d_merge;     // ag2_hypothesis: the gathered selected lists of all ranks, flattened (ag2_merge_selected_device)
+  ag2::DevBuf d_gather;    // one process, several GPUs: the ranks' compact lists on the root's GPU (ag2_gather_begin)
+  ag2::DevBuf d_xchg;      // ... and a rank's own list before the peer copy
+  size_t gather_world = 0, gather_cap = 0;
   const void* d_last_sel = nullptr;    // what the last ag2_detect selected from (d_sel or d_cluster) ...
   const unsigned* d_last_nsel = nullptr;  // ... and its count on the device
   ag2::DevBuf d_flags;     // uint32 flags / prefix for slot compaction

@@ -580,6 +580,42 @@ int ag2_merge_selected_device(ag2_ctx* c, const void* d_gathered, size_t world, 
   return merge_selected(c, d_gathered, world, cap_records, selected, cap, n_selected, n_total);
 }
 
+int ag2_gather_begin(ag2_ctx* root, size_t world, size_t cap_records) {
+  if (!root || world == 0) return AG2_ERR_ARG;
+  (void)hipSetDevice(root->device);
+  if (world > 4096 || cap_records > ((size_t)1 << 24)) return set_err(root, AG2_ERR_ARG, "gather: sizes");
+  const size_t per = 16 + cap_records * sizeof(ag2_hypothesis);
+  AG2_HIP(root, hipStreamSynchronize(root->stream));  // (a merge of the previous exchange may still read the buffer)
+  AG2_HIP(root, root->d_gather.reserve(world * per));
+  root->gather_world = world;
+  root->gather_cap = cap_records;
+  return 0;
+}
+
+int ag2_gather_selected(ag2_ctx* root, ag2_ctx* src, size_t rank) {
+  if (!root || !src) return AG2_ERR_ARG;
+  if (rank >= root->gather_world) return set_err(src, AG2_ERR_ARG, "gather: rank outside the world given to ag2_gather_begin");
+  const size_t cap = root->gather_cap, per = 16 + cap * sizeof(ag2_hypothesis);
+  (void)hipSetDevice(src->device);
+  AG2_HIP(src, src->d_xchg.reserve(per));
+  const int rc = ag2_export_selected_compact_device(src, src->d_xchg.p, per, cap);
+  if (rc) return rc;
+  char* dst = (char*)root->d_gather.p + rank * per;
+  if (src->device == root->device)
+    AG2_HIP(src, hipMemcpyAsync(dst, src->d_xchg.p, per, hipMemcpyDeviceToDevice, src->stream));
+  else  // over xGMI; the runtime stages through the host when the devices have no peer access
+    AG2_HIP(src, hipMemcpyPeerAsync(dst, root->device, src->d_xchg.p, src->device, per, src->stream));
+  AG2_HIP(src, hipStreamSynchronize(src->stream));
+  return 0;
+}
+
+int ag2_merge_gathered(ag2_ctx* root, ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_total) {
+  if (!root || !n_selected) return AG2_ERR_ARG;
+  (void)hipSetDevice(root->device);
+  if (root->gather_world == 0) return set_err(root, AG2_ERR_STATE, "merge: no ag2_gather_begin");
+  return merge_selected(root, root->d_gather.p, root->gather_world, root->gather_cap, selected, cap, n_selected, n_total);
+}
+
 int ag2_export_candidates_compact_device(ag2_ctx* c, void* d_dst, size_t bytes, size_t cap_records) {
   if (!c || !d_dst) return AG2_ERR_ARG;
   (void)hipSetDevice(c->device);

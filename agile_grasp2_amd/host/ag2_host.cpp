@@ -10,6 +10,7 @@
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <thread>
 
 #include "agile_grasp2/caffe_classifier.h"
 #include "agile_grasp2/cloud_camera.h"
@@ -838,6 +839,11 @@ bool set_param(GraspDetector::Params* p, const std::string& k, const std::string
   if (k == "workspace") { p->workspace = parse_list(v); return true; }
   if (k == "camera_pose") { p->camera_pose = parse_list(v); return true; }
   if (k == "gripper_width_range") { p->gripper_width_range = parse_list(v); return true; }
+  if (k == "devices") {
+    p->devices.clear();
+    for (double d : parse_list(v)) p->devices.push_back((int)d);
+    return true;
+  }
   if (k == "sample_indices") {
     p->sample_indices.clear();
     for (double d : parse_list(v)) p->sample_indices.push_back((int)d);
@@ -959,8 +965,7 @@ void GraspDetector::cameraPoses(Matrix4d* left, Matrix4d* right) const {
   *right = base_tf * sqrt_tf;
 }
 
-std::shared_ptr<ag2::Context> GraspDetector::contextFor(int n_cams) {
-  if (ctx_ && ctx_cams_ == n_cams) return ctx_;
+ag2_params GraspDetector::abiParams(int n_cams) const {
   HandSearch::Parameters hp;
   hp.nn_radius_taubin_ = p_.nn_radius_taubin;
   hp.nn_radius_hands_ = p_.nn_radius_hands;
@@ -982,7 +987,14 @@ std::shared_ptr<ag2::Context> GraspDetector::contextFor(int n_cams) {
   }
   ap.min_score_diff = p_.min_score_diff;
   ap.num_selected = p_.num_selected;
-  ctx_.reset(new ag2::Context(ap, p_.device));
+  return ap;
+}
+
+std::shared_ptr<ag2::Context> GraspDetector::contextFor(int n_cams) {
+  if (ctx_ && ctx_cams_ == n_cams) return ctx_;
+  const ag2_params ap = abiParams(n_cams);
+  ctx_.reset(new ag2::Context(ap, p_.devices.empty() ? p_.device : p_.devices[0]));
+  peers_.clear();
   ctx_cams_ = n_cams;
   resident_ctx_ = nullptr;
   if (!ctx_->ok()) {
@@ -1057,7 +1069,14 @@ std::vector<GraspHypothesis> GraspDetector::detectImpl(const CloudCamera& cloud_
                           classifier_->blob(3).data(), classifier_->blob(4).data(), classifier_->blob(5).data(),
                           classifier_->blob(6).data(), classifier_->blob(7).data());
       if (!rc) rc = ag2_set_min_inliers(c, min_inliers);  // clustering between threshold and top-k, on the GPU
-      if (!rc) rc = ag2_detect(c, pidx, pxyz, s, 0, p_.seed, do_prune ? 1 : 0, recs.data(), cap, &n, nullptr, 0, nullptr);
+      if (!rc && p_.devices.size() > 1 && !use_samples && s > 0) {
+        if (!detectOnDevices(c, cloud_cam, idx, do_prune, min_inliers, &recs, &n)) {
+          fprintf(stderr, "GraspDetector::detectGraspPoses: %s\n", err_.c_str());
+          return out;
+        }
+      } else if (!rc) {
+        rc = ag2_detect(c, pidx, pxyz, s, 0, p_.seed, do_prune ? 1 : 0, recs.data(), cap, &n, nullptr, 0, nullptr);
+      }
     } else {
       rc = ag2_generate_hypotheses(c, pidx, pxyz, s, 0, p_.seed, recs.data(), cap, &n);
       if (!rc) {
@@ -1094,6 +1113,84 @@ std::vector<GraspHypothesis> GraspDetector::detectImpl(const CloudCamera& cloud_
   out.reserve(n);
   for (size_t h = 0; h < n; h++) out.push_back(GraspHypothesis(recs[h]));
   return out;
+}
+
+// Params::devices: the sample list cut into contiguous ranges, one per device; every device holds the whole
+// cloud (a 300 k-point cloud is 4.8 MB) and runs grid, normals and detect for its range with the samples'
+// positions in the WHOLE list as slot base -- so its hypotheses are those of the one-device run
+// (hand_search.cpp:194-228: no state crosses samples; the draws are keyed by the slot).  The ranks leave their
+// scored candidates above the threshold on the first device (ag2_gather_selected) and that device clusters
+// (when min_inliers > 0) and takes the top num_selected over the concatenation, which is in sample order
+// (grasp_detector.cpp:228-252).  `root` (device 0's context) already holds cloud, normals and weights.
+bool GraspDetector::detectOnDevices(ag2_ctx* root, const CloudCamera& cloud_cam, const std::vector<int32_t>& idx,
+                                    bool do_prune, int min_inliers, std::vector<ag2_hypothesis>* recs, size_t* n) {
+  const size_t G = p_.devices.size(), s = idx.size();
+  const int n_cams = std::max(1, cloud_cam.getCameraSource().rows());
+  if (peers_.size() != G - 1 || peers_cams_ != n_cams) {
+    peers_.clear();
+    const ag2_params ap = abiParams(n_cams);
+    for (size_t g = 1; g < G; g++) {
+      std::shared_ptr<ag2::Context> pc(new ag2::Context(ap, p_.devices[g]));
+      if (!pc->ok()) {
+        err_ = "could not create a GPU context on device " + std::to_string(p_.devices[g]) + " (no CPU fallback)";
+        peers_.clear();
+        return false;
+      }
+      peers_.push_back(pc);
+    }
+    peers_cams_ = n_cams;
+  }
+  std::vector<ag2_ctx*> cs(G, root);
+  for (size_t g = 1; g < G; g++) cs[g] = peers_[g - 1]->get();
+  std::vector<size_t> lo(G + 1);
+  size_t longest = 0;
+  for (size_t g = 0; g <= G; g++) lo[g] = s * g / G;
+  for (size_t g = 0; g < G; g++) longest = std::max(longest, lo[g + 1] - lo[g]);
+  const size_t cap_records = std::max<size_t>(1, longest * (size_t)p_.num_orientations);  // every slot: never cut
+  if (ag2_gather_begin(root, G, cap_records)) {
+    err_ = ag2_last_error(root);
+    return false;
+  }
+  std::vector<int> rcs(G, 0);
+  std::vector<std::string> msgs(G);
+  auto run = [&](size_t g) {
+    ag2_ctx* c = cs[g];
+    int rc = 0;
+    if (g > 0) {  // (the root was set up by the caller)
+      rc = HandSearch::uploadCloud(c, cloud_cam);
+      if (!rc)
+        rc = ag2_lenet_load(c, classifier_->blob(0).data(), classifier_->blob(1).data(), classifier_->blob(2).data(),
+                            classifier_->blob(3).data(), classifier_->blob(4).data(), classifier_->blob(5).data(),
+                            classifier_->blob(6).data(), classifier_->blob(7).data());
+      if (!rc) rc = ag2_set_min_inliers(c, min_inliers);
+    }
+    size_t ns = 0, nsc = 0;
+    const int32_t dummy = 0;
+    const size_t len = lo[g + 1] - lo[g];
+    if (!rc)  // selected == NULL, cap == 0: no local read-back, the merge selects
+      rc = ag2_detect(c, len ? idx.data() + lo[g] : &dummy, nullptr, len, (uint64_t)lo[g], p_.seed, do_prune ? 1 : 0,
+                      nullptr, 0, &ns, nullptr, 0, &nsc);
+    if (!rc) rc = ag2_gather_selected(root, c, g);
+    rcs[g] = rc;
+    if (rc) msgs[g] = ag2_last_error(c);
+  };
+  std::vector<std::thread> th;
+  for (size_t g = 1; g < G; g++) th.emplace_back(run, g);
+  run(0);
+  for (std::thread& t : th) t.join();
+  for (size_t g = 0; g < G; g++)
+    if (rcs[g]) {
+      err_ = "device " + std::to_string(p_.devices[g]) + " (rank " + std::to_string(g) + "): " + msgs[g];
+      return false;
+    }
+  const size_t k_cap = (p_.num_selected >= 0) ? std::min<size_t>((size_t)p_.num_selected, G * cap_records) : G * cap_records;
+  recs->resize(std::max<size_t>(1, k_cap));
+  size_t n_total = 0;
+  if (ag2_merge_gathered(root, recs->data(), recs->size(), n, &n_total)) {
+    err_ = ag2_last_error(root);
+    return false;
+  }
+  return true;
 }
 
 // Steps 1-2 (+ the uniform draw of step 3) on the GPU through ag2_preprocess_cloud; the processed

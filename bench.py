@@ -795,6 +795,46 @@ def main():
                               "note": "two clouds in flight on two HIP streams; never `value`"}
         for dk in pair:
             dk.close()
+        # (3b) the same, from ONE host thread: ag2_pipe (two contexts taken in turn, frames submitted
+        # asynchronously), clouds handed over in HOST memory (page-locked staging + asynchronous DMA) -- the
+        # headline cloud with its samples, then the raw cloud of (2) through the front end
+        pipe = capi.Pipe(device=local_rank, depth=2, **launch_params(ws, R))
+        pipe.lenet_load(weights)
+
+        def run_pipe(submit, reps):
+            submit()
+            scored = 0
+            for _ in range(reps - 1):
+                submit()
+                scored += pipe.wait()[1]
+            scored += pipe.wait()[1]
+            return scored
+
+        legs_pipe = {}
+        for name, sub in (("headline_cloud_from_host", lambda: pipe.submit(xyz, idx, seed=args.seed)),
+                          ("raw_cloud_from_host", (lambda: pipe.submit_raw(raw, num_samples=S, sample_seed=args.seed,
+                                                                           seed=args.seed, voxel_size=scene.VOXEL))
+                           if voxelised else None)):
+            if sub is None:
+                continue
+            run_pipe(sub, 8)   # both contexts: step by step, fixed shapes + capture, first replays
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps_p = 40
+            sc = run_pipe(sub, reps_p)
+            dtp = (time.perf_counter() - t1) / reps_p
+            t1 = time.perf_counter()   # latency of ONE cloud through the same pipe (nothing else in flight)
+            for _ in range(10):
+                sub()
+                pipe.wait()
+            lat1 = (time.perf_counter() - t1) / 10
+            legs_pipe[name] = {"ms_per_cloud": dtp * 1e3, "value": sc / reps_p / dtp, "unit": "hypotheses/s",
+                               "scored_per_cloud": sc / reps_p, "single_cloud_latency_ms": lat1 * 1e3}
+        pipe.close()
+        out["async_pipeline"] = dict(legs_pipe, depth=2,
+                                     note=("ONE host thread, ag2_pipe: two frames in flight on two HIP streams, clouds "
+                                           "copied from pageable host memory into page-locked staging and transferred by "
+                                           "asynchronous DMA; never `value`"))
         # (4) the launch-file variant with grasp clustering (launch/file_detect_grasps.launch:45
         # min_inliers = 5: HandleSearch::findClusters between the threshold and the top-k)
         d.set_min_inliers(5)

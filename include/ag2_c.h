@@ -247,6 +247,42 @@ int ag2_detect_frame_raw(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t 
                          size_t* n_selected, size_t* n_scored, size_t* n_voxels);
 int ag2_get_frame_info(ag2_ctx* c, ag2_frame_info* out);
 
+/* ---- the asynchronous form of the two frame entries (no counterpart in the reference, whose node handles one
+ * cloud at a time, grasp_detection_node.cpp:69-95) ----
+ * ag2_submit_frame[_raw] = ag2_detect_frame[_raw] up to, and not including, the wait for the results: a cloud
+ * in host memory is copied into page-locked staging and transferred by an asynchronous DMA, the per-frame
+ * sequence is queued on the context's stream, and the call returns.  ag2_wait_frame brings the results of the
+ * frame submitted last: same bytes as the synchronous call.  One frame per context may be in flight; no other
+ * call on the context in between; a device-resident cloud must stay valid until the wait.  (A frame that has to
+ * run step by step -- the first of a stream, one that outgrows the shapes -- does so inside the submit, or inside
+ * the wait when the flags that come back say so.) */
+int ag2_submit_frame(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                     const int32_t* sample_idx, size_t s, uint64_t seed, int do_prune);
+int ag2_submit_frame_raw(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                         int filter_workspace, double voxel_size, size_t num_samples, uint64_t sample_seed,
+                         uint64_t seed, int do_prune);
+int ag2_wait_frame(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored,
+                   size_t* n_voxels);
+/* ag2_pipe: `depth` contexts on one GPU (own streams), taken in turn by ONE caller thread -- while LeNet and the
+ * selection of frame k run on one stream, transfer, front end, grid, normals and sweep of frame k + 1 run on
+ * the next; a single cloud does not fill the GPU.  submit returns AG2_ERR_STATE when `depth` frames are in
+ * flight; wait returns the results of the oldest frame (submission order). */
+typedef struct ag2_pipe ag2_pipe;
+ag2_pipe* ag2_pipe_create(const ag2_params* p, int device_id, int depth);
+void ag2_pipe_destroy(ag2_pipe* q);
+const char* ag2_pipe_last_error(const ag2_pipe* q);
+ag2_ctx* ag2_pipe_context(ag2_pipe* q, int k);  /* context k of the pipe (settings such as ag2_stream_configure) */
+int ag2_pipe_lenet_load(ag2_pipe* q, const float* conv1_w, const float* conv1_b, const float* conv2_w,
+                        const float* conv2_b, const float* ip1_w, const float* ip1_b, const float* ip2_w,
+                        const float* ip2_b);
+int ag2_pipe_submit(ag2_pipe* q, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                    const int32_t* sample_idx, size_t s, uint64_t seed, int do_prune);
+int ag2_pipe_submit_raw(ag2_pipe* q, const void* xyz, int xyz_on_device, size_t n, size_t stride_bytes,
+                        int filter_workspace, double voxel_size, size_t num_samples, uint64_t sample_seed,
+                        uint64_t seed, int do_prune);
+int ag2_pipe_wait(ag2_pipe* q, ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored,
+                  size_t* n_voxels);
+
 int ag2_export_candidates_device(ag2_ctx* c, void* d_dst, size_t bytes);
 /* Multi-GPU merge of the detect results (no counterpart in the single-process reference; this is the
  * step grasp_detector.cpp:239-252 -- top num_selected by score -- becomes when the samples are sharded):
@@ -264,6 +300,17 @@ int ag2_export_selected_compact_device(ag2_ctx* c, void* d_dst, size_t bytes, si
  * tail of the pipeline still queued: what a rank calls when the merge follows.) */
 int ag2_merge_selected_device(ag2_ctx* c, const void* d_gathered, size_t world, size_t cap_records,
                               ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_total);
+/* The same exchange from ONE process that owns several GPUs (what the C++ host mirror uses:
+ * GraspDetector::Params::devices -- one context per device, one host thread each; a process per GPU with an
+ * RCCL all-gather is the other way, see bench.py).  ag2_gather_begin sizes a gather buffer on root's
+ * GPU for `world` lists of cap_records records; ag2_gather_selected exports what src's last ag2_detect
+ * selected from (as ag2_export_selected_compact_device) and copies it into position `rank` of that buffer --
+ * a peer copy over xGMI when the devices differ -- and returns when it has landed; it touches only src and
+ * its own slot of the buffer, so the ranks may call it from their threads concurrently.
+ * ag2_merge_gathered is ag2_merge_selected_device on the buffer. */
+int ag2_gather_begin(ag2_ctx* root, size_t world, size_t cap_records);
+int ag2_gather_selected(ag2_ctx* root, ag2_ctx* src, size_t rank);
+int ag2_merge_gathered(ag2_ctx* root, ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_total);
 /* The same candidates in compact form (what a multi-GPU job should put on the wire: the table is
  * mostly empty): a 16-byte header {uint32 count, uint32 cap_records, 0, 0} followed by
  * min(count, cap_records) records in slot order -- the occupied slots of the table above, so the

@@ -52,6 +52,12 @@ class GraspDetector {
     // not in the reference
     int device = 0;
     uint64_t seed = 0;
+    // More than one entry: detectGraspPoses (antipodal_mode PREDICTION, index samples) spreads the sample list
+    // over these GPUs -- one context and one host thread per entry, the cloud replicated, every device taking a
+    // contiguous range of the samples (they are independent, hand_search.cpp:194-228) --, gathers the ranks'
+    // scored candidates on the first device (peer copies over xGMI) and clusters / selects there
+    // (grasp_detector.cpp:228-252).  The same device may appear more than once.  Empty: {device}.
+    std::vector<int> devices;
     // "name=value" lines ('#' comments); vectors as "[a, b, c]".  Unknown names are an error.
     static bool fromKeyValueText(const std::string& text, Params* out, std::string* err);
     // <param name=".." value=".."/> and <rosparam param=".."> [..] </rosparam> of a roslaunch file
@@ -110,6 +116,10 @@ class GraspDetector {
                                                            float min_x, float max_x, float min_y,
                                                            float max_y, float min_z);
   std::shared_ptr<ag2::Context> contextFor(int n_cams);
+  ag2_params abiParams(int n_cams) const;
+  // the multi-GPU form of step 1 - 5 (Params::devices); false: error (err_ says what)
+  bool detectOnDevices(ag2_ctx* root, const CloudCamera& cloud_cam, const std::vector<int32_t>& idx, bool do_prune,
+                       int min_inliers, std::vector<ag2_hypothesis>* recs, size_t* n);
   bool preprocessOnDevice(CloudCamera& cloud_cam);
 
   Params p_;
@@ -123,6 +133,8 @@ class GraspDetector {
   HandleSearch handle_search_;
   std::shared_ptr<ag2::Context> ctx_;
   int ctx_cams_ = 0;
+  std::vector<std::shared_ptr<ag2::Context>> peers_;  // contexts of Params::devices[1 ...]
+  int peers_cams_ = 0;
   // cloud left in the context by preprocessPointCloud: detectGraspPoses does not upload it again
   const void* resident_cloud_ = nullptr;
   size_t resident_n_ = 0;

@@ -265,6 +265,44 @@ def test_cpp_detect_modes_none_and_geometric(tmp_path, mode, min_inliers):
     assert np.array_equal(rec["score"], want["score"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("min_inliers", [0, 1])
+def test_cpp_detect_on_several_devices_equals_one_device(tmp_path, small_scene, min_inliers):
+    """GraspDetector::Params::devices: the C++ host's own path to N GPUs -- one context and one host thread per
+    entry, the sample list cut into contiguous ranges, the ranks' scored candidates gathered on the first device
+    (ag2_gather_selected: a device-to-device copy here, a peer copy over xGMI between GPUs), clustering and
+    top-k there.  devices = [0, 0, 0] on the one GPU of the box against the one-context run: the same hands,
+    field for field; scores within the LeNet tolerance (ip1's split-K follows the batch size, so the last bits
+    of a score may differ between a third of the list and the whole list)."""
+    tmp = str(tmp_path)
+    exe = build_driver(tmp)
+    xyz, ws, idx = small_scene
+    w = make_lenet_weights(7)
+    wpath, lpath = os.path.join(tmp, "w.ag2w"), os.path.join(tmp, "labels.txt")
+    save_ag2w(wpath, w)
+    open(lpath, "w").write("0\n1\n")
+    xyz.astype("<f4").tofile(os.path.join(tmp, "cloud.f32"))
+    idx.astype("<i4").tofile(os.path.join(tmp, "idx.i32"))
+    dt = np.dtype([("slot", "<i4"), ("orient", "<i4"), ("full", "<i4"), ("half", "<i4"), ("score", "<f8"), ("bottom", "<f8", 3)])
+    out = {}
+    for tag, extra in (("one", ""), ("three", "devices = [0, 0, 0]\n")):
+        open(os.path.join(tmp, f"params_{tag}.txt"), "w").write(
+            params_text(ws, wpath, lpath, 5) + f"min_inliers = {min_inliers}\n" + extra)
+        outp = os.path.join(tmp, f"out_{tag}.bin")
+        r = subprocess.run([exe, "--modes", os.path.join(tmp, "cloud.f32"), os.path.join(tmp, "idx.i32"),
+                            os.path.join(tmp, f"params_{tag}.txt"), outp], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        out[tag] = np.frombuffer(open(outp, "rb").read(), dtype=dt, offset=8)
+    a, b = out["one"], out["three"]
+    assert len(a) == len(b) and len(a) > (5 if min_inliers == 0 else 1)
+    ka, kb = np.lexsort((a["orient"], a["slot"])), np.lexsort((b["orient"], b["slot"]))
+    for f in ("slot", "orient", "full", "half", "bottom"):
+        assert np.array_equal(a[f][ka], b[f][kb]), f
+    tol = 1e-4 * np.abs(a["score"]).max() + 2e-3
+    assert np.abs(a["score"][ka] - b["score"][kb]).max() <= tol
+    assert np.all(np.diff(b["score"]) <= 0)   # the merge's own order: score descending
+
+
 def test_launch_xml_and_keyvalue_readers(tmp_path):
     """Params readers accept the reference's own launch file text (parameter NAMES are the
     contract; the file is read at test time from /root/reference when present, else a literal

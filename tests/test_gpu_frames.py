@@ -250,3 +250,74 @@ def test_raw_frames_that_leave_the_shapes():
     assert m == n_vox and wn == n_sc and got.tobytes() == want.tobytes()
     for x in (df, ds, ds2):
         x.close()
+
+
+# ---- the asynchronous form: ag2_submit_frame* / ag2_wait_frame behind ag2_pipe -----------------------------
+@pytest.mark.parametrize("raw", [True, False])
+def test_pipe_returns_the_bytes_of_the_synchronous_calls(raw):
+    """One caller thread, two frames in flight (ag2_pipe, depth 2): every frame's results are byte for byte
+    those of the synchronous ag2_detect_frame[_raw] on its own context, in submission order -- clouds handed
+    over in host memory (page-locked staging + asynchronous DMA) and resident in HBM."""
+    import ctypes as C
+    from agile_grasp2_amd import capi
+    n_frames, ns = 9, 200
+    if raw:
+        clouds, ws = scene.make_stream(80, 40000, n_frames, voxel=None)
+        idxs = [None] * n_frames
+    else:
+        clouds, ws = scene.make_stream(81, 15000, n_frames)
+        idxs = [scene.draw_samples(90 + k, c.shape[0], ns) for k, c in enumerate(clouds)]
+    prm = scene_params(ws, min_score_diff=-1e30, num_selected=35)
+    w = make_lenet_weights(7)
+    sync = capi.Detector(**prm)
+    sync.lenet_load(w)
+    want = []
+    for k, c in enumerate(clouds):
+        if raw:
+            sel, n_sc, n_vox = sync.detect_frame_raw(c, num_samples=ns, sample_seed=500 + k, seed=k)
+        else:
+            sel, n_sc = sync.detect_frame(c, idxs[k], seed=k)
+            n_vox = c.shape[0]
+        want.append((sel.tobytes(), n_sc, n_vox))
+    assert sum(x[1] for x in want) > 100
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    for on_device in (False, True):
+        pipe = capi.Pipe(depth=2, **prm)
+        pipe.lenet_load(w)
+        with pytest.raises(RuntimeError, match="pipe empty"):
+            pipe.wait()
+        dbufs = []
+        if on_device:   # every frame its own device buffer: it must stay valid until the frame's wait
+            for c in clouds:
+                dp = C.c_void_p()
+                assert hip.hipMalloc(C.byref(dp), c.nbytes) == 0
+                assert hip.hipMemcpy(dp, c.ctypes.data_as(C.c_void_p), c.nbytes, 1) == 0
+                dbufs.append(dp)
+
+        def submit(k):
+            kw = dict(dptr=dbufs[k].value, n=clouds[k].shape[0], stride=12) if on_device else dict(xyz=clouds[k])
+            if raw:
+                pipe.submit_raw(num_samples=ns, sample_seed=500 + k, seed=k, **kw)
+            else:
+                pipe.submit(sample_idx=idxs[k], seed=k, **kw)
+
+        got = []
+        submit(0)
+        submit(1)
+        with pytest.raises(RuntimeError, match="pipe full"):
+            submit(2)
+        for k in range(2, n_frames):
+            got.append(pipe.wait())
+            submit(k)
+        got.append(pipe.wait())
+        got.append(pipe.wait())
+        assert len(got) == n_frames
+        for k, (sel, n_sc, n_vox) in enumerate(got):
+            assert (sel.tobytes(), n_sc, n_vox) == want[k], (on_device, k)
+        pipe.close()
+        for dp in dbufs:
+            hip.hipFree(dp)
+    sync.close()
