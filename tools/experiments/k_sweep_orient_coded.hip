@@ -1,3 +1,17 @@
+// EXPERIMENT (round 3), not part of libag2hip.so: k_sweep_orient with a second instantiation for long lists
+// (dense clouds) that reads a pair's cropped list ONCE from the list arena and leaves one code byte per point in
+// LDS (inside the finger gap or not; first deepen level the point lies under), from which the closing-region
+// pass takes its members without touching the points again; the scaling pass gathers the members only.
+// Bit-identical results (the full-size parity tests passed with it).  Measured on MI355X, configuration 3
+// (1 M points, 20 000 samples, 16 orientations): the sweep's counted HBM traffic 23.8 -> 20.6 GB per step, but
+// its time 6.0 -> 6.3 ms -- the orientation passes are not bandwidth-bound there (FETCH_SIZE of the two
+// instantiations 2.5 GB in 2.8 ms; waves issue VALU 13 % of their cycles at 3-4 waves per SIMD): they are a
+// chain of dependent phases per pair, and the code-byte form adds work to the streaming pass (the level
+// lookup) while three workgroups per CU (145 VGPRs, 53 KB of LDS) hide less of it than four.  With every
+// list longer than ONE chunk sent to the second kernel, configuration 2 lost 50 us (its few hundred two- and
+// three-chunk lists then run after the first kernel instead of beside its pairs).  What would help instead:
+// fewer instructions per point in the two full passes (f32 classification with an exact f64 fallback near
+// the thresholds, as pass A of k_sweep does).
 // k_sweep_orient.hip -- K3, second half: the per-orientation passes of the hand sweep, one workgroup
 // per (sample, orientation) pair that passed the gates.
 //
@@ -22,30 +36,50 @@ namespace ag2 {
 constexpr int kOThreads = 256;
 constexpr int kONW = kOThreads / kWave;
 constexpr int kOMaskWords = 16;    // 64-bit membership ballots of one wave's quarter of a chunk
-// lists are staged in LDS in chunks of this many points (the usual list is one chunk)
-constexpr int kOStage = 2432;
+// lists are staged in LDS in chunks of this many points (the usual list is one chunk): kOStage, k_sweep_common.h
 static_assert((((kOStage + 3) / 4 + 63) & ~63) / 64 <= 16, "mask words per wave");
+// LONG instantiation (lists longer than one chunk, dense clouds): pass B streams the list ONCE from the arena
+// and leaves one byte per point in LDS -- inside the finger gap or not, and the first depth level the point
+// lies under -- from which pass C takes the members of the closing region without touching the points
+// again; pass D gathers only the members.  The one-chunk form re-stages a long list for every pass (three
+// reads of K x 16 B per pair: 10.3 GB of configuration 3's 23.8 GB per step).
+constexpr int kOCode = 32768;      // points whose code bytes fit (longer lists take the chunked form)
+constexpr int kOMem = 9216;        // members listed at a time (16-bit list indices)
 
 struct OrientShared {
   double fs[20], fsr[20];
   double depths[kMaxDepths];
+  double lv[kMaxDepths + 1];       // LONG: the levels top can take: init_bite, then the deepen depths
   Red<kONW> red;
   unsigned long long inmask[kONW][kOMaskWords];
   int next_w[2];
   long long arena_off;
-  struct {
+  union {
     struct {
       float px[kOStage], py[kOStage], pz[kOStage];  // the staged chunk: centred coordinates ...
       unsigned short box16[kOStage];               // ... and, for a one-chunk list, its members' indices
     } st;
+    struct {
+      unsigned char code[kOCode];                  // bit 7: inside the finger gap; bits 0-5: first level with y < level
+      unsigned short mem16[kOMem];                 // list indices of the members, in list order
+    } lg;
   } u;
 };
-static_assert(sizeof(OrientShared) * 4 <= 160 * 1024, "k_sweep_orient: four workgroups per CU");
+template <bool LONG>
+struct OrientSharedSized {
+  static constexpr size_t bytes = LONG ? sizeof(OrientShared)
+                                       : sizeof(OrientShared) - sizeof(OrientShared::u) + sizeof(OrientShared::u.st);
+};
+static_assert(OrientSharedSized<false>::bytes * 4 <= 160 * 1024, "k_sweep_orient: four workgroups per CU");
+static_assert(OrientSharedSized<true>::bytes * 3 <= 160 * 1024, "k_sweep_orient<LONG>: three workgroups per CU");
 
 // (four workgroups per CU: 128 VGPRs, 52 B of scratch per lane around pass D; three per CU -- 150 VGPRs,
 // no scratch -- is equal at configuration 2 and 7 % slower at configuration 3)
-__global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
-  __shared__ OrientShared S;
+// Two instantiations share the pair queue: <false> takes the pairs whose list is one chunk, <true> the rest.
+template <bool LONG>
+__global__ void __launch_bounds__(kOThreads, LONG ? 3 : 4) k_sweep_orient(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char orient_smem[];
+  OrientShared& S = *reinterpret_cast<OrientShared*>(orient_smem);
   constexpr int NT = kOThreads, NW = kONW;
   const HandConst& hc = *A.hc;
   const float cloud_min_z = A.gp ? A.gp->min_z : A.min_z;
@@ -56,11 +90,13 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
   const double hh = hc.hand_height;
   const int n_work = (int)A.st->n_pairs;
   if (n_work == 0) return;
+  if (LONG && A.st->n_pairs_long == 0u) return;
   if (tid < 20) {
     S.fs[tid] = hc.fs[tid];
     S.fsr[tid] = hc.fsr[tid];
   }
   if (tid < kMaxDepths) S.depths[tid] = hc.depths[tid];
+  if (tid <= kMaxDepths) S.lv[tid] = (tid == 0) ? hc.init_bite : hc.depths[tid - 1];
   __syncthreads();
   const int n_depths = hc.n_depths;
   const double hand_depth = hc.hand_depth;
@@ -76,9 +112,11 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     return w;
   };
   for (int w = blockIdx.x; w < n_work; w = next_work()) {
-    if (tid == 0) nxt = gridDim.x + atomicAdd(&A.st->work_next[2], 1u);
+    if (tid == 0) nxt = gridDim.x + atomicAdd(&A.st->work_next[LONG ? 3 : 2], 1u);
     const SweepPair pr = A.pairs[w];
     const int t = pr.t, oi = pr.oi, K = pr.K;
+    if ((K > kOLong) != LONG) continue;  // (uniform) the other instantiation's pair
+    const bool coded = LONG && K <= kOCode;  // (uniform)
     const unsigned hand = pr.hand;
     const float4* plist = A.lists + pr.list_off;
     // (the list's segments: the same in every lane, kept in scalar registers)
@@ -113,7 +151,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
       __syncthreads();
       return clen;
     };
-    stage(0);  // (here, before the frame and the rotation occupy registers)
+    if (!coded) stage(0);  // (here, before the frame and the rotation occupy registers)
     const double* fr = A.frames + (size_t)t * 12;
     // frame = [normal binormal curvature_axis] as columns, hand_search.cpp:325-326
     const double F[3][3] = {{fr[3], fr[6], fr[9]}, {fr[4], fr[7], fr[10]}, {fr[5], fr[8], fr[11]}};
@@ -148,7 +186,47 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     // (the same pass yields surface = min y over ALL rotated points, finger_hand.cpp:158)
     int kfail = n_depths;
     double miny = __builtin_inf();
-    for (int c = 0; c < nchunks; c++) {
+    if (coded) {
+      // pass B over the list in the arena (four 16-byte loads in flight per thread, the next four requested
+      // before these are used); every point leaves its code byte
+      constexpr int kIn = 4;
+      float4 cur[kIn], nxtv[kIn];
+#pragma unroll
+      for (int u = 0; u < kIn; u++) cur[u] = plist[lslot(min(tid + u * NT, K - 1))];
+      for (int j0 = 0; j0 < K; j0 += kIn * NT) {
+#pragma unroll
+        for (int u = 0; u < kIn; u++) nxtv[u] = plist[lslot(min(j0 + kIn * NT + tid + u * NT, K - 1))];
+#pragma unroll
+        for (int u = 0; u < kIn; u++) {
+          const int j = j0 + tid + u * NT;
+          if (j < K) {
+            const double p0 = (double)cur[u].x, p1 = (double)cur[u].y, p2 = (double)cur[u].z;
+            const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
+            const double y = (Fr[0][1] * p0 + Fr[1][1] * p1) + Fr[2][1] * p2;
+            miny = (y < miny) ? y : miny;
+            const bool zone = (x > fl0 && x < fl1) || (x > fr0 && x < fr1);
+            for (int di = 0; di < kfail; di++) {
+              const double d = S.depths[di];
+              if (y < d && (zone || y < d - hand_depth)) {
+                kfail = di;
+                break;
+              }
+            }
+            // first level index e with y < lv[e] (n_depths + 1: none).  The levels are 5 mm apart
+            // (finger_hand.cpp:122), which places the estimate; the exact f64 comparisons decide.
+            const double tq = (y - top0) * 200.0;
+            int e = (tq < 0.0) ? 0 : ((tq > (double)n_depths) ? n_depths + 1 : (int)tq + 1);
+            while (e > 0 && y < S.lv[e - 1]) e--;
+            while (e <= n_depths && !(y < S.lv[e])) e++;
+            const bool inx = x > fl1 && x < fr0;  // left = fs + finger_width = fsr, right = fs[10 + idx]
+            S.u.lg.code[j] = (unsigned char)(e | (inx ? 0x80 : 0));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kIn; u++) cur[u] = nxtv[u];
+      }
+    }
+    for (int c = 0; !coded && c < nchunks; c++) {
       const int clen = (c == 0) ? min(kOStage, K) : stage(c);
       for (int j = tid; j < clen; j += NT) {
         double x, y;
@@ -219,7 +297,21 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     };
     int cnt = 0;
     double mnx = __builtin_inf(), mxx = -__builtin_inf();
-    for (int c = 0; c < nchunks; c++) {
+    // coded: y < top  <=>  top's level index (kfail: top = lv[kfail]) >= the point's first level under which it lies
+    auto coded_member = [&](int j) -> bool {
+      const unsigned cb = S.u.lg.code[j];
+      return (cb & 0x80u) && (int)(cb & 0x3Fu) <= kfail;
+    };
+    if (coded) {
+      __syncthreads();  // every code byte is written
+      int jb, je;
+      seg_of(K, jb, je);
+      for (int j0 = jb; j0 < je; j0 += 64) {
+        const int j = j0 + lane;
+        cnt += __popcll(__ballot(j < je && coded_member(j)));
+      }
+    }
+    for (int c = 0; !coded && c < nchunks; c++) {
       const int clen = (nchunks > 1) ? stage(c) : K;  // (a single chunk is still staged from pass B)
       cnt += members(clen, mnx, mxx);
     }
@@ -260,6 +352,52 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     __syncthreads();
     const long long off = S.arena_off;
     // pass D: unit-box scaling (hand_search.cpp:399-409), list emission, antipodal extents
+    // coded: the members' list indices, kOMem at a time, at their ordered positions; their extent in x
+    // (the other form took it along in pass C)
+    auto fill_members = [&](int base) {
+      int jb, je;
+      seg_of(K, jb, je);
+      int run = pbase_w;
+      __syncthreads();  // the readers of the previous window are done
+      for (int j0 = jb; j0 < je; j0 += 64) {
+        const int j = j0 + lane;
+        const bool in = j < je && coded_member(j);
+        const unsigned long long mask = __ballot(in);
+        const int pos = run + __popcll(mask & lt_mask) - base;
+        if (in && pos >= 0 && pos < kOMem) S.u.lg.mem16[pos] = (unsigned short)j;
+        run += __popcll(mask);
+      }
+      __syncthreads();
+    };
+    if (coded) {
+      for (int base = 0; base < P; base += kOMem) {
+        fill_members(base);
+        const int nb = min(kOMem, P - base);
+        for (int b = tid; b < nb; b += NT) {
+          const float4 v = plist[lslot((int)S.u.lg.mem16[b])];
+          const double p0 = (double)v.x, p1 = (double)v.y, p2 = (double)v.z;
+          const double x = (Fr[0][0] * p0 + Fr[1][0] * p1) + Fr[2][0] * p2;
+          mnx = (x < mnx) ? x : mnx;
+          mxx = (x > mxx) ? x : mxx;
+        }
+      }
+      mnx = wave_min_d(mnx);
+      mxx = wave_max_d(mxx);
+      red_sel ^= 1;
+      if (lane == 0) {
+        S.red.d[red_sel][wid][0] = mnx;
+        S.red.d[red_sel][wid][1] = mxx;
+      }
+      __syncthreads();
+      mnx = __builtin_inf();
+      mxx = -__builtin_inf();
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        const double a = S.red.d[red_sel][k][0], b = S.red.d[red_sel][k][1];
+        mnx = (a < mnx) ? a : mnx;
+        mxx = (b > mxx) ? b : mxx;
+      }
+    }
     const double baseline = 0.1;
     const double left_const = left - 0.5 * (baseline - (right - left));
     const double lower[3] = {left_const, bottom, -1.0 * hh};
@@ -270,9 +408,8 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     double e[8] = {-__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf(),
                    -__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf()};
     // e: lmaxy lminy lmaxz lminz rmaxy rminy rmaxz rminz
-    auto emit = [&](int bpos, int jl, int jg) {  // member jl of the staged chunk = list entry jg
-      const double p0 = (double)S.u.st.px[jl], p1 = (double)S.u.st.py[jl], p2 = (double)S.u.st.pz[jl];
-      const float4 nn = A.nrm[__float_as_int(plist[lslot(jg)].w)];  // hand_search.cpp:211, :394: the point's normal
+    auto emit_p = [&](int bpos, double p0, double p1, double p2, int npos) {  // member at ordered position bpos
+      const float4 nn = A.nrm[npos];  // hand_search.cpp:211, :394: the point's normal
       const double q0 = (double)nn.x, q1 = (double)nn.y, q2 = (double)nn.z;
       double X[3], Y[3], U[3];
 #pragma unroll
@@ -281,7 +418,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
         Y[a] = (Fr[0][a] * q0 + Fr[1][a] * q1) + Fr[2][a] * q2;
         U[a] = scales[a] * (X[a] - lower[a]);
       }
-      if (off >= 0) {  // 48 B per member as three 16-byte stores
+      if (off >= 0) {  // 48 B per member as three 16-byte stores (six 8-byte ones left partial sectors behind)
         double2* dst = reinterpret_cast<double2*>(A.arena + (size_t)(off + bpos) * 6);
         dst[0] = make_double2(U[0], U[1]);
         dst[1] = make_double2(U[2], Y[0]);
@@ -300,7 +437,20 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
         e[6] = (U[2] > e[6]) ? U[2] : e[6]; e[7] = (U[2] < e[7]) ? U[2] : e[7];
       }
     };
-    if (nchunks == 1) {
+    auto emit = [&](int bpos, int jl, int jg) {  // member jl of the staged chunk = list entry jg
+      emit_p(bpos, (double)S.u.st.px[jl], (double)S.u.st.py[jl], (double)S.u.st.pz[jl],
+             __float_as_int(plist[lslot(jg)].w));
+    };
+    if (coded) {
+      for (int base = 0; base < P; base += kOMem) {
+        if (P > kOMem) fill_members(base);  // (a list of one window is still there from the extent pass)
+        const int nb = min(kOMem, P - base);
+        for (int b = tid; b < nb; b += NT) {
+          const float4 v = plist[lslot((int)S.u.lg.mem16[b])];
+          emit_p(base + b, (double)v.x, (double)v.y, (double)v.z, __float_as_int(v.w));
+        }
+      }
+    } else if (nchunks == 1) {
       // the usual case: the masks of pass C give every member its ordered position; the members are
       // listed (16-bit indices) so that ALL threads share the arithmetic of the emission
       int jb, je;
@@ -466,7 +616,16 @@ __global__ void __launch_bounds__(256) k_hyp_stats(const unsigned char* __restri
 int launch_sweep_orient(ag2_ctx* c, const SweepArgs& A, size_t n_slots) {
   // the queue length is read on the device: a fixed launch, the surplus workgroups leave at once
   const int grid = (int)std::min<size_t>(std::max<size_t>(n_slots, 1), 256 * 8);
-  hipLaunchKernelGGL(k_sweep_orient, dim3(grid), dim3(kOThreads), 0, c->stream, A);
+  static bool attr_set = false;
+  if (!attr_set) {  // (more than 64 KB of dynamic LDS needs the attribute)
+    AG2_HIP(c, hipFuncSetAttribute((const void*)k_sweep_orient<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)OrientSharedSized<true>::bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_sweep_orient<false>, dim3(grid), dim3(kOThreads), OrientSharedSized<false>::bytes, c->stream, A);
+  // the pairs with a list longer than one chunk (dense clouds; none on a tabletop cloud: the kernel leaves at once)
+  hipLaunchKernelGGL(k_sweep_orient<true>, dim3(std::min(grid, 256 * 3)), dim3(kOThreads), OrientSharedSized<true>::bytes,
+                     c->stream, A);
   // the statistics: along with the slot compaction when the caller has announced one (one launch less)
   if (c->defer_hyp_stats) {
     c->hyp_stats_pending = true;
