@@ -63,9 +63,8 @@ typedef struct ag2_params {
   int32_t debug_flags;        /* 0. bit0: visit every radius neighbour in the hand sweep (no
                                  sphere/slab row culling) so counters.sum_k2 is exact; results
                                  are identical either way.  bit1: start the sweep's list arena at
-                                 4 096 points instead of 16 Mi (and, with AG2_SWEEP_MONO=1, its global
-                                 scratch at 1 024 points per workgroup instead of 65 536): exercises
-                                 the grow-and-repeat paths on small clouds; results identical */
+                                 4 096 points instead of 16 Mi: exercises the grow-and-repeat path on
+                                 small clouds; results identical */
 } ag2_params;
 
 /* One grasp hypothesis = the fixed part of GraspHypothesis
