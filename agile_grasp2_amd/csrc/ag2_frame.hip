@@ -195,6 +195,7 @@ unsigned long long frame_signature(const ag2_ctx* c, const ag2_frame_state* f) {
   memcpy(&cell_bits, &f->fs.cell, 4);
   const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points, c->list_ints, f->cap_img,
                                      (unsigned long long)c->sweep_gcap, (unsigned long long)c->sweep_g2,
+                                     (unsigned long long)c->sweep_gpos_cap,
                                      (unsigned long long)c->p.num_selected, f->k_cap, (unsigned long long)f->cap_p,
                                      (unsigned long long)c->origin_set, (unsigned long long)f->raw, f->fs.raw_max,
                                      f->fs.cap_words, f->fs.cand_cap, (unsigned long long)cell_bits,

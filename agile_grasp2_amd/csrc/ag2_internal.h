@@ -202,6 +202,7 @@ struct ag2_ctx {
   size_t list_ints = 0;    // capacity of d_lists in points; grown on demand like the arena
   int sweep_gcap = 1 << 16;  // points per workgroup of that scratch; grows to the longest list met
   int sweep_g2 = 1024;       // workgroups of the stage that uses it
+  int sweep_gpos_cap = 0;    // longest list the sweep's first stage keeps (k_sweep.hip: kGposCap / kGposCapBig, adaptive)
   ag2::DevBuf d_list;      // int compacted slot ids (hypotheses in order)
   ag2::DevBuf d_list2;     // int compacted slot ids after prune / for scoring
   ag2::DevBuf d_images;    // uint8 n_img x 10800 (HWC)
@@ -340,6 +341,7 @@ struct FrameOut {
 int launch_topk(ag2_ctx* c, const ag2_hypothesis* d_recs, const unsigned* d_n, size_t cap, size_t k_cap,
                 ag2_hypothesis* d_out, FrameOut* d_fo, const GridDesc* gp, const PreFrame* pfp = nullptr);
 int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool run_cleared = false);
+void sweep_adapt_gpos(ag2_ctx* c, size_t n_samples, size_t n_overflow);
 int launch_hyp_stats(ag2_ctx* c, size_t n_slots);  // k_sweep_orient.hip: n_hyp, sum_p, max_p from the slot table
 // k_select.hip
 int compact_slots(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, size_t* n_out);

@@ -56,6 +56,7 @@ void note_sweep(ag2_ctx* c, size_t s, const DevStats& hs, int compact_mode) {
   c->cnt.sum_kcrop = (int64_t)hs.sum_kcrop;
   c->cnt.sum_p = (int64_t)hs.sum_p;
   c->cnt.n_overflow_samples = hs.n_overflow;  // handed to the sweep's long-list stage
+  sweep_adapt_gpos(c, s, hs.n_overflow);
   c->cnt.list_points = (int64_t)hs.list_top;
   if (compact_mode >= 0) c->n_img = hs.n_list;
   c->max_p = (int)hs.max_p;

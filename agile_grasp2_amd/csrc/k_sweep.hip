@@ -397,8 +397,16 @@ static_assert(kLdsCap >= 2048, "unexpected LDS stage size");
 // A list that is longer than stage 0's LDS but not by much keeps its positions in a per-workgroup
 // global slice instead (L2-resident, same code): the few such samples of a tabletop cloud would
 // otherwise cost a whole extra launch whose duration is one sample's latency.
-constexpr int kGposCap = 2 * kLdsCap;  // (A/B at cfg3: 10 k, 24 k and 32 k are all slower than ~7.4 k)
-static_assert(kGposCap <= 65536, "in-box indices are 16 bits");
+// The slice's capacity is a launch argument (SweepArgs::gpos_cap), chosen by the host from what the previous
+// run of the context saw (results do not depend on it: a routing decision):
+//   kGposCap     clouds on which many samples overflow anyway (configuration 3: 85 % of them; A/B there: 10 k,
+//                24 k and 32 k are all slower than ~7.4 k -- the long-list stage crops such lists in one pass)
+//   kGposCapBig  clouds on which only a few samples per run are that long: they stay in this stage, among
+//                the other samples, instead of costing a launch of their own whose duration is one long
+//                sample's latency (55 us per frame at configuration 5)
+constexpr int kGposCap = 2 * kLdsCap;
+constexpr int kGposCapBig = 16384;
+static_assert(kGposCapBig <= 65535, "list offsets inside a piece table entry are 16 bits");
 
 // Two instantiations run back to back; the second reads its queue length on the device (no host
 // round trip):
@@ -426,7 +434,7 @@ k_sweep(SweepArgs A) {
   // float4 per point in the list arena), and pass A streams it from there -- no per-workgroup scratch,
   // no copy at the gates, and no bound on the list length other than the arena's (which grows).
   constexpr bool ARENA = STAGE == 1;
-  const int CAP = LITE ? kGposCap : (LDS_STORE ? kCapL : (ARENA ? 0x7fffffff : A.gcap));
+  const int CAP = LITE ? A.gpos_cap : (LDS_STORE ? kCapL : (ARENA ? 0x7fffffff : A.gcap));
   float4* L = nullptr;  // ARENA: this sample's list
   float* pbase;
   // stage 0: sorted positions of the cropped list in LDS; stage 1: the list arena (L)
@@ -440,7 +448,7 @@ k_sweep(SweepArgs A) {
   float* PZ = pbase + 2 * (size_t)CAP;
   int* POS = reinterpret_cast<int*>(pbase + (LITE ? 0 : 3) * (size_t)(LITE ? kCapL : CAP));
   int* gpos = nullptr;
-  if (LITE) gpos = A.gpos + (size_t)blockIdx.x * kGposCap;
+  if (LITE) gpos = A.gpos + (size_t)blockIdx.x * A.gpos_cap;
 
   const HandConst& hc = *A.hc;
   // frame mode: grid description, cloud minimum and slot base come from memory (uniform loads)
@@ -569,7 +577,7 @@ k_sweep(SweepArgs A) {
         kcand += S.red.i[0][k][0];
       }
     }
-    if (STAGE == 0 && kcand > 2 * kGposCap) {
+    if (STAGE == 0 && kcand > 2 * A.gpos_cap) {
       // Dense neighbourhood: the cropped list is about 0.6 of the candidates, so it will not fit
       // this stage -- hand the sample to the global-scratch stage before the crop pass instead of
       // after it.  Only a routing decision: both stages compute the same result.
@@ -1230,6 +1238,14 @@ k_sweep(SweepArgs A) {
   }
 }
 
+// Which capacity the next run's stage 0 gets (see kGposCap): the big slice while the long-list stage sees only
+// a few samples per run, the small one when a sizeable part of them overflows anyway.
+void sweep_adapt_gpos(ag2_ctx* c, size_t n_samples, size_t n_overflow) {
+  if (c->sweep_gpos_cap <= 0) c->sweep_gpos_cap = kGposCap;
+  if (n_overflow * 4 > n_samples) c->sweep_gpos_cap = kGposCap;
+  else if (n_overflow > 0 && n_overflow * 16 <= n_samples) c->sweep_gpos_cap = kGposCapBig;
+}
+
 static size_t sweep_lds_bytes(int stage) {
   size_t b = sweep_ctl_bytes(stage);
   if (stage == 0) b += (size_t)kLdsCap * (size_t)kStage0PointBytes;
@@ -1360,7 +1376,9 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   A.pairs = c->d_pairs.as<SweepPair>();
   const int grid = (int)std::min<size_t>(s, 256 * kStage0WgPerCu);
   // first stage: one workgroup per sample
-  AG2_HIP(c, c->d_gpos.reserve((size_t)256 * kStage0WgPerCu * kGposCap * 6));
+  if (c->sweep_gpos_cap <= 0) c->sweep_gpos_cap = kGposCap;
+  A.gpos_cap = c->sweep_gpos_cap;
+  AG2_HIP(c, c->d_gpos.reserve((size_t)256 * kStage0WgPerCu * (size_t)A.gpos_cap * 4));
   A.gpos = c->d_gpos.as<int>();
   hipLaunchKernelGGL(fn_lds, dim3(grid), dim3(kSweepThreads0), lds, c->stream, A);
   AG2_HIP(c, hipGetLastError());

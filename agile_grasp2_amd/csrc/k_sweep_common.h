@@ -46,8 +46,8 @@ struct SweepArgs {
   int* overflow;             // stage 0 appends, stage 1 works through it (length: st->n_overflow)
   float* gscratch;           // global variant: 6 * gcap floats per block
   int gcap;
-  int* gpos;                 // stage 0: kGposCap positions per workgroup, then kGposCap u16 in-box
-                             // indices per workgroup (lists a little longer than the LDS stage)
+  int* gpos;                 // stage 0: gpos_cap positions per workgroup (lists longer than the LDS stage)
+  int gpos_cap;              // ... the longest list stage 0 keeps; longer ones go to the long-list stage
   float min_z;
   int flags;                 // bit0: no row tightening (exact K2 accounting, diagnostic)
   unsigned long long* prof;  // optional per-phase cycle sums (AG2_SWEEP_PROF=1), else nullptr
