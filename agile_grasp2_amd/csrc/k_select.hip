@@ -38,44 +38,59 @@ __global__ void k_slot_scatter(const unsigned* __restrict__ pref, int n_slots,
   if (pref[i + 1] != pref[i]) list[pref[i]] = i;
 }
 
-// The same in ONE launch for tables of up to 64 Ki slots (modes 0 and 1): a single 1024-thread
-// workgroup, each thread a contiguous run of <= 64 slots whose flags it keeps in a 64-bit mask
-// between the counting and the writing pass.  Five launches (flags, 3 x scan, scatter) and a copy
-// become one; at S*R = 40 000 slots the table is latency-, not bandwidth-sized.
+// The same in ONE launch for tables of up to 64 Ki slots (modes 0 and 1): each thread a contiguous run of
+// 16 slots whose flags it keeps in a mask between the counting and the writing pass.  Five launches
+// (flags, 3 x scan, scatter) and a copy become one; at S*R = 40 000 slots the table is latency-, not
+// bandwidth-sized.
 // Only the per-slot state byte is read (k_sweep: 0 empty, 1 hypothesis that survives the prune,
 // 4 hypothesis pruned away), 16 slots per load, never the 176-byte records.
 // With desc_off / desc_cnt the image descriptors (arena offset, point count) of the listed slots are
 // written in the same pass (one launch less between the sweep and the renderer).
 // With st_hyp the run's hypothesis statistics (count, points, largest list: what k_hyp_stats gathers
 // from the same state bytes) are taken along: one launch less between the sweep and the read-back.
-__global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __restrict__ keep,
-                                                        int n_slots, int mode, int* __restrict__ list,
-                                                        unsigned* __restrict__ count,
-                                                        const ag2_hypothesis* __restrict__ table,
-                                                        const long long* __restrict__ tab_off,
-                                                        long long* __restrict__ desc_off,
-                                                        int* __restrict__ desc_cnt, DevStats* st_hyp) {
-  __shared__ unsigned wsum[16], wcnt[16], wmax[16];
-  __shared__ unsigned long long wpts[16];
-  const int t = threadIdx.x;
-  const int per = (((n_slots + 1023) / 1024) + 15) & ~15;  // 16 .. 64, a multiple of 16
-  const int s0 = t * per;
-  unsigned long long mask = 0ull, occ = 0ull;
-  for (int i = 0; i < per; i += 16) {
-    if (s0 + i < n_slots) {  // the buffer is 16-byte padded past n_slots (DevBuf slack)
-      const uint4 v = *reinterpret_cast<const uint4*>(keep + s0 + i);
-      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+// Several 256-thread workgroups, each owning 4 096 consecutive slots (16 per thread: one 16-byte load).  A
+// workgroup needs the number of listed slots in front of its chunk; with at most 16 chunks it simply counts
+// them itself from the state bytes (<= 60 KB of L2-resident reads per workgroup) -- no inter-workgroup
+// hand-over, no second launch.  (One 1 024-thread workgroup over all slots took 22 us at configuration 2:
+// 40 slots per thread and a walk over up to ten occupied slots per thread, on one CU.)
+constexpr int kCmpThreads = 256;
+constexpr int kCmpChunk = kCmpThreads * 16;
+__device__ __forceinline__ unsigned listed16(const uint4& v, int mode, int valid, unsigned* occ_out) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  unsigned m = 0u, occ = 0u;
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const unsigned b = (w[k >> 2] >> (8 * (k & 3))) & 255u;
-        const bool in = s0 + i + k < n_slots;
-        const bool f = in && (mode == 1 ? (b == 1u) : (b != 0u));
-        mask |= f ? (1ull << (i + k)) : 0ull;
-        occ |= (in && b != 0u) ? (1ull << (i + k)) : 0ull;
-      }
-    }
+  for (int k = 0; k < 16; k++) {
+    const unsigned b = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+    const bool in = k < valid;
+    const bool f = in && (mode == 1 ? (b == 1u) : (b != 0u));
+    m |= f ? (1u << k) : 0u;
+    occ |= (in && b != 0u) ? (1u << k) : 0u;
   }
-  const unsigned tot = (unsigned)__popcll(mask);
+  if (occ_out) *occ_out = occ;
+  return m;
+}
+__global__ void __launch_bounds__(kCmpThreads) k_compact_small(const unsigned char* __restrict__ keep,
+                                                               int n_slots, int mode, int* __restrict__ list,
+                                                               unsigned* __restrict__ count,
+                                                               const ag2_hypothesis* __restrict__ table,
+                                                               const long long* __restrict__ tab_off,
+                                                               long long* __restrict__ desc_off,
+                                                               int* __restrict__ desc_cnt, DevStats* st_hyp) {
+  __shared__ unsigned wsum[4], wcnt[4], wmax[4], wbef[4];
+  __shared__ unsigned long long wpts[4];
+  const int t = threadIdx.x;
+  const int w0 = blockIdx.x * kCmpChunk;  // (all slots in front of it exist: w0 <= n_slots)
+  // listed slots in front of this workgroup's chunk
+  unsigned before = 0u;
+  for (int i = t * 16; i < w0; i += kCmpChunk)
+    before += (unsigned)__popc(listed16(*reinterpret_cast<const uint4*>(keep + i), mode, 16, nullptr));
+  before = (unsigned)wave_sum_i((int)before);
+  if (lane_id() == 0) wbef[wave_id()] = before;
+  // this thread's 16 slots (the buffer is 16-byte padded past n_slots: DevBuf slack)
+  const int s0 = w0 + t * 16;
+  unsigned mask = 0u, occ = 0u;
+  if (s0 < n_slots) mask = listed16(*reinterpret_cast<const uint4*>(keep + s0), mode, min(16, n_slots - s0), &occ);
+  const unsigned tot = (unsigned)__popc(mask);
   unsigned inc = tot;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -86,30 +101,31 @@ __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __r
   __syncthreads();
   unsigned woff = 0, all = 0;
 #pragma unroll
-  for (int w = 0; w < 16; w++) {
+  for (int w = 0; w < 4; w++) {
     if (w < wave_id()) woff += wsum[w];
     all += wsum[w];
   }
-  unsigned pos = woff + inc - tot;
+  const unsigned base = wbef[0] + wbef[1] + wbef[2] + wbef[3];
+  unsigned pos = base + woff + inc - tot;
   // ONE walk over the occupied slots of the thread's run, four at a time with their gathers in flight
   // together (few slots are occupied; one slot per step was a chain of dependent round trips): the
   // point count feeds the statistics, and for a listed slot the descriptor as well.
   unsigned hc = 0, hm = 0;
   unsigned long long hp = 0;
-  const unsigned long long walk = st_hyp ? occ : mask;
-  for (unsigned long long m = walk; m;) {
+  const unsigned walk = st_hyp ? occ : mask;
+  for (unsigned m = walk; m;) {
     int sl[4];
     unsigned p[4];
     long long off[4];
     bool listed[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int b = m ? __ffsll((long long)m) - 1 : 0;
+      const int b = m ? __ffs((int)m) - 1 : 0;
       sl[u] = m ? s0 + b : -1;
-      listed[u] = m && ((mask >> b) & 1ull);
+      listed[u] = m && ((mask >> b) & 1u);
       p[u] = (sl[u] >= 0 && (st_hyp || desc_off)) ? (unsigned)table[sl[u]].n_points : 0u;
       off[u] = (listed[u] && desc_off) ? tab_off[sl[u]] : 0ll;
-      m &= m - 1ull;  // (0 stays 0)
+      m &= m - 1u;  // (0 stays 0)
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -141,16 +157,16 @@ __global__ void __launch_bounds__(1024) k_compact_small(const unsigned char* __r
     __syncthreads();
   }
   if (t == 0) {
-    *count = all;
+    if (blockIdx.x == gridDim.x - 1) *count = base + all;  // the last chunk knows the total
     if (st_hyp) {
       unsigned c = 0, mx = 0;
       unsigned long long pp = 0;
-      for (int w = 0; w < 16; w++) {
+      for (int w = 0; w < 4; w++) {
         c += wcnt[w];
         pp += wpts[w];
         mx = max(mx, wmax[w]);
       }
-      if (c) {  // (added, like k_hyp_stats: the one-kernel sweep counts into the same fields itself)
+      if (c) {  // (added, like k_hyp_stats)
         atomicAdd(&st_hyp->n_hyp, c);
         atomicAdd(&st_hyp->sum_p, pp);
         atomicMax(&st_hyp->max_p, mx);
@@ -184,7 +200,7 @@ int compact_slots_async(ag2_ctx* c, size_t n_slots, int mode, DevBuf& out_list, 
       d_off = c->d_desc.as<long long>();
       c->desc_stride = n_slots;
     }
-    hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, c->stream,
+    hipLaunchKernelGGL(k_compact_small, dim3((unsigned)((n_slots + kCmpChunk - 1) / kCmpChunk)), dim3(kCmpThreads), 0, c->stream,
                        c->d_tab_keep.as<unsigned char>(), (int)n_slots, mode, out_list.as<int>(), d_count,
                        c->d_table.as<ag2_hypothesis>(), c->d_tab_off.as<long long>(), d_off,
                        d_off ? (int*)(d_off + n_slots) : (int*)nullptr,
