@@ -69,30 +69,62 @@ __device__ __forceinline__ unsigned quantise(double ax, double ay, double az) {
   return packed;
 }
 
+// two u16 lanes of a dword at once (v_pk_max_u16 / v_pk_sub_u16 / v_pk_min_u16 / v_pk_add_u16)
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(unsigned v) {
+  us2 r;
+  __builtin_memcpy(&r, &v, 4);
+  return r;
+}
+__device__ __forceinline__ unsigned as_u32(us2 v) {
+  unsigned r;
+  __builtin_memcpy(&r, &v, 4);
+  return r;
+}
+
 // :202-203 3x3 rect dilate (border taps ignored), :206 BGR2RGB swap; staged so that the global
-// store is coalesced dwords
+// store is coalesced dwords.  A pixel is b0 | b1 << 8 | b2 << 16; split once into (b0, b2) as two u16
+// lanes and b1, a per-channel max of two pixels is one packed and one plain max.  A thread owns a
+// column and 15 consecutive rows of it: the horizontal maxima of its 17 rows (three reads each) stay
+// in registers for the vertical pass -- 51 LDS reads and ~130 instructions for 15 pixels, where nine
+// taps with three masked maxima each cost ~100 instructions per pixel (this pass was the largest part
+// of the renderer for the typical image).
 template <int NT = kImgThreads>
 __device__ __forceinline__ void dilate_store(const unsigned* __restrict__ pix,
                                              unsigned char* __restrict__ obuf,
                                              unsigned char* __restrict__ out_img, int tid) {
-  for (int p = tid; p < kCells; p += NT) {
-    const int r = p / kImg, cc = p % kImg;
-    unsigned m0 = 0, m1 = 0, m2 = 0;
+  constexpr int kStrip = 15, kStrips = kImg / kStrip;
+  static_assert(kStrips * kStrip == kImg, "rows per strip");
+  for (int s = tid; s < kImg * kStrips; s += NT) {
+    const int cc = s % kImg, r0 = (s / kImg) * kStrip;
+    us2 he[kStrip + 2];    // horizontal max of rows r0 - 1 .. r0 + kStrip: channels 0 and 2
+    unsigned ho[kStrip + 2];  // ... channel 1
 #pragma unroll
-    for (int dr = -1; dr <= 1; dr++)
-#pragma unroll
-      for (int dc = -1; dc <= 1; dc++) {
-        const int rr = r + dr, c2 = cc + dc;
-        if (rr >= 0 && rr < kImg && c2 >= 0 && c2 < kImg) {
-          const unsigned v = pix[rr * kImg + c2];
-          m0 = max(m0, v & 255u);
-          m1 = max(m1, (v >> 8) & 255u);
-          m2 = max(m2, (v >> 16) & 255u);
-        }
+    for (int k = 0; k < kStrip + 2; k++) {
+      const int rr = r0 - 1 + k;
+      us2 e = as_us2(0u);
+      unsigned o = 0u;
+      if (rr >= 0 && rr < kImg) {
+        const unsigned* row = pix + rr * kImg;
+        const unsigned v1 = row[cc];
+        const unsigned v0 = (cc > 0) ? row[cc - 1] : 0u;       // (0 never wins a max: border taps ignored)
+        const unsigned v2 = (cc < kImg - 1) ? row[cc + 1] : 0u;
+        e = __builtin_elementwise_max(__builtin_elementwise_max(as_us2(v0 & 0x00FF00FFu), as_us2(v1 & 0x00FF00FFu)),
+                                      as_us2(v2 & 0x00FF00FFu));
+        o = max(max(v0 & 0xFF00u, v1 & 0xFF00u), v2 & 0xFF00u);
       }
-    obuf[p * 3 + 2] = (unsigned char)m0;
-    obuf[p * 3 + 1] = (unsigned char)m1;
-    obuf[p * 3 + 0] = (unsigned char)m2;
+      he[k] = e;
+      ho[k] = o;
+    }
+#pragma unroll
+    for (int k = 0; k < kStrip; k++) {
+      const unsigned e = as_u32(__builtin_elementwise_max(__builtin_elementwise_max(he[k], he[k + 1]), he[k + 2]));
+      const unsigned o = max(max(ho[k], ho[k + 1]), ho[k + 2]);
+      const int p = (r0 + k) * kImg + cc;
+      obuf[p * 3 + 2] = (unsigned char)(e & 255u);
+      obuf[p * 3 + 1] = (unsigned char)(o >> 8);
+      obuf[p * 3 + 0] = (unsigned char)(e >> 16);
+    }
   }
   __syncthreads();
   unsigned* dst = reinterpret_cast<unsigned*>(out_img);
@@ -254,12 +286,17 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
         if (c >= 0) {
           const unsigned short cs = (unsigned short)c;
           int r = 0, b0 = 0;
+          // two ids per instruction: d = id - own id (wraps; zero iff equal), min(d, 1) is 1 per id that
+          // DIFFERS, summed in two u16 lanes (at most 4 per group and lane, 128 groups: no overflow)
+          const us2 cs2 = as_us2((unsigned)cs | ((unsigned)cs << 16)), one2 = as_us2(0x00010001u);
+          us2 differ = as_us2(0u);
           for (; b0 + 8 <= b; b0 += 8) {
             const uint4 w = *reinterpret_cast<const uint4*>(&S.cid[b0]);
             const unsigned ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int j = 0; j < 8; j++) r += ((unsigned short)(ww[j >> 1] >> (16 * (j & 1))) == cs) ? 1 : 0;
+            for (int j = 0; j < 4; j++) differ += __builtin_elementwise_min((us2)(as_us2(ww[j]) - cs2), one2);
           }
+          r = b0 - ((int)differ.x + (int)differ.y);
           if (b0 < b) {
             const uint4 w = *reinterpret_cast<const uint4*>(&S.cid[b0]);
             const unsigned ww[4] = {w.x, w.y, w.z, w.w};
