@@ -29,6 +29,7 @@ static_assert((((kOStage + 3) / 4 + 63) & ~63) / 64 <= 16, "mask words per wave"
 struct OrientShared {
   double fs[20], fsr[20];
   double depths[kMaxDepths];
+  double depths_b[kMaxDepths];     // depths[i] - hand_depth: where the hand's back is at deepen step i
   Red<kONW> red;
   unsigned long long inmask[kONW][kOMaskWords];
   int next_w[2];
@@ -60,7 +61,10 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     S.fs[tid] = hc.fs[tid];
     S.fsr[tid] = hc.fsr[tid];
   }
-  if (tid < kMaxDepths) S.depths[tid] = hc.depths[tid];
+  if (tid < kMaxDepths) {
+    S.depths[tid] = hc.depths[tid];
+    S.depths_b[tid] = hc.depths[tid] - hc.hand_depth;  // the very f64 difference the reference's test forms
+  }
   __syncthreads();
   const int n_depths = hc.n_depths;
   const double hand_depth = hc.hand_depth;
@@ -146,8 +150,16 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     };
     // pass B: first depth step that fails (some point under the finger pads or behind the hand)
     // (the same pass yields surface = min y over ALL rotated points, finger_hand.cpp:158)
+    // The first failing step of ONE point is a search, not a scan: step di fails the point when
+    // y < depths[di] && (zone || y < depths[di] - hand_depth), both tables ascend, so it is the first index
+    // of the table that decides -- depths[] under a finger pad, depths_b[] elsewhere -- with y below its
+    // entry.  The steps are 5 mm apart (finger_hand.cpp:122), which places an estimate; the exact f64
+    // comparisons against the table then settle it (the same comparisons the scan made: same result).  The
+    // scan cost a thread ten iterations per point until one of ITS points failed a step -- pass B was a
+    // third of this kernel's time.
     int kfail = n_depths;
     double miny = __builtin_inf();
+    const double depth0 = S.depths[0], depth0_b = S.depths_b[0];
     for (int c = 0; c < nchunks; c++) {
       const int clen = (c == 0) ? min(kOStage, K) : stage(c);
       for (int j = tid; j < clen; j += NT) {
@@ -155,12 +167,13 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
         rot_xy(j, x, y);
         miny = (y < miny) ? y : miny;
         const bool zone = (x > fl0 && x < fl1) || (x > fr0 && x < fr1);
-        for (int di = 0; di < kfail; di++) {
-          const double d = S.depths[di];
-          if (y < d && (zone || y < d - hand_depth)) {
-            kfail = di;
-            break;
-          }
+        const double* tab = zone ? S.depths : S.depths_b;
+        const double tq = (y - (zone ? depth0 : depth0_b)) * 200.0;
+        int e = (tq < 0.0) ? 0 : ((tq >= (double)n_depths) ? n_depths : (int)tq + 1);
+        if (e < kfail + 3) {  // (an estimate three or more above the current minimum cannot lower it: it is off by at most one)
+          while (e > 0 && y < tab[e - 1]) e--;
+          while (e < n_depths && !(y < tab[e])) e++;
+          kfail = min(kfail, e);
         }
       }
     }
