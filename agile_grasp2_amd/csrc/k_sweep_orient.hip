@@ -22,6 +22,7 @@ namespace ag2 {
 constexpr int kOThreads = 256;
 constexpr int kONW = kOThreads / kWave;
 constexpr int kOMaskWords = 16;    // 64-bit membership ballots of one wave's quarter of a chunk
+constexpr int kOMaskChunks = 8;    // chunks whose ballots are kept from pass C for pass D (lists up to 19 456 points)
 // lists are staged in LDS in chunks of this many points (the usual list is one chunk)
 constexpr int kOStage = 2432;
 static_assert((((kOStage + 3) / 4 + 63) & ~63) / 64 <= 16, "mask words per wave");
@@ -31,7 +32,8 @@ struct OrientShared {
   double depths[kMaxDepths];
   double depths_b[kMaxDepths];     // depths[i] - hand_depth: where the hand's back is at deepen step i
   Red<kONW> red;
-  unsigned long long inmask[kONW][kOMaskWords];
+  unsigned long long inmask[kONW][kOMaskChunks * kOMaskWords];
+  int chunk_cnt[kOMaskChunks][kONW];  // members per (chunk, wave) of a list of several chunks
   int next_w[2];
   long long arena_off;
   struct {
@@ -209,7 +211,8 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
       jb = min(wid * seg, clen);
       je = min(jb + seg, clen);
     };
-    auto members = [&](int clen, double& mn, double& mx) -> int {  // this wave's count in the chunk
+    // (mbase: where in inmask[wid] the chunk's ballots go -- a list of up to kOMaskChunks chunks keeps them all)
+    auto members = [&](int clen, double& mn, double& mx, int mbase) -> int {  // this wave's count in the chunk
       int jb, je, cnt = 0;
       seg_of(clen, jb, je);
       for (int j0 = jb; j0 < je; j0 += 64) {
@@ -225,16 +228,19 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
           }
         }
         const unsigned long long mask = __ballot(in);
-        if (lane == 0) S.inmask[wid][(j0 - jb) >> 6] = mask;
+        if (lane == 0) S.inmask[wid][mbase + ((j0 - jb) >> 6)] = mask;
         cnt += __popcll(mask);
       }
       return cnt;
     };
     int cnt = 0;
     double mnx = __builtin_inf(), mxx = -__builtin_inf();
+    const bool keep_masks = nchunks > 1 && nchunks <= kOMaskChunks;  // (uniform)
     for (int c = 0; c < nchunks; c++) {
       const int clen = (nchunks > 1) ? stage(c) : K;  // (a single chunk is still staged from pass B)
-      cnt += members(clen, mnx, mxx);
+      const int mine = members(clen, mnx, mxx, keep_masks ? c * kOMaskWords : 0);
+      if (keep_masks && lane == 0) S.chunk_cnt[c][wid] = mine;
+      cnt += mine;
     }
     mnx = wave_min_d(mnx);
     mxx = wave_max_d(mxx);
@@ -283,9 +289,8 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     double e[8] = {-__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf(),
                    -__builtin_inf(), __builtin_inf(), -__builtin_inf(), __builtin_inf()};
     // e: lmaxy lminy lmaxz lminz rmaxy rminy rmaxz rminz
-    auto emit = [&](int bpos, int jl, int jg) {  // member jl of the staged chunk = list entry jg
-      const double p0 = (double)S.u.st.px[jl], p1 = (double)S.u.st.py[jl], p2 = (double)S.u.st.pz[jl];
-      const float4 nn = A.nrm[__float_as_int(plist[lslot(jg)].w)];  // hand_search.cpp:211, :394: the point's normal
+    auto emit_p = [&](int bpos, double p0, double p1, double p2, int npos) {  // the member at ordered position bpos
+      const float4 nn = A.nrm[npos];  // hand_search.cpp:211, :394: the point's normal
       const double q0 = (double)nn.x, q1 = (double)nn.y, q2 = (double)nn.z;
       double X[3], Y[3], U[3];
 #pragma unroll
@@ -313,6 +318,10 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
         e[6] = (U[2] > e[6]) ? U[2] : e[6]; e[7] = (U[2] < e[7]) ? U[2] : e[7];
       }
     };
+    auto emit = [&](int bpos, int jl, int jg) {  // member jl of the staged chunk = list entry jg
+      emit_p(bpos, (double)S.u.st.px[jl], (double)S.u.st.py[jl], (double)S.u.st.pz[jl],
+             __float_as_int(plist[lslot(jg)].w));
+    };
     if (nchunks == 1) {
       // the usual case: the masks of pass C give every member its ordered position; the members are
       // listed (16-bit indices) so that ALL threads share the arithmetic of the emission
@@ -329,6 +338,33 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
         const int j = (int)S.u.st.box16[b];
         emit(b, j, j);
       }
+    } else if (keep_masks) {
+      // a list of a few chunks: the ballots of pass C are all still there, so this pass touches only the
+      // MEMBERS -- gathered from the arena, at their ordered positions (chunk, then wave, then lane = list
+      // order) -- instead of staging every chunk again and rotating all of its points a third time (that
+      // was 38 % of this kernel at configuration 3)
+      int run = 0;  // members in front of this wave's quarter of chunk c
+      for (int c = 0; c < nchunks; c++) {
+        const int c0 = c * kOStage, clen = min(kOStage, K - c0);
+        int mine_base = run;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+          const int ck = S.chunk_cnt[c][k];  // (written before the barrier behind pass C's reduction)
+          if (k < wid) mine_base += ck;
+          run += ck;
+        }
+        int jb, je;
+        seg_of(clen, jb, je);
+        int at = mine_base;
+        for (int j0 = jb; j0 < je; j0 += 64) {
+          const unsigned long long mask = S.inmask[wid][c * kOMaskWords + ((j0 - jb) >> 6)];
+          if ((mask >> lane) & 1ull) {
+            const float4 v = plist[lslot(c0 + j0 + lane)];
+            emit_p(at + __popcll(mask & lt_mask), (double)v.x, (double)v.y, (double)v.z, __float_as_int(v.w));
+          }
+          at += __popcll(mask);
+        }
+      }
     } else {
       // a long list: chunk by chunk, every wave emits the members of its quarter at their ordered
       // positions (count per wave -> one LDS hop -> offsets)
@@ -336,7 +372,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
       for (int c = 0; c < nchunks; c++) {
         const int clen = stage(c);
         double d0 = 0.0, d1 = 0.0;
-        const int mine = members(clen, d0, d1);
+        const int mine = members(clen, d0, d1, 0);
         red_sel ^= 1;
         if (lane == 0) S.red.i[red_sel][wid][0] = mine;
         __syncthreads();
