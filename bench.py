@@ -171,8 +171,8 @@ def stream_legs(seed, n_frames, n_warm, S=None, only=None, host_leg=True):
                                                     voxel_size=scene.VOXEL)
             dt = time.perf_counter() - t0
             out.append(sel.tobytes())
-            if name == "stepwise" and not only:
-                pre[k] = (torch.from_numpy(d.get_cloud()[0]).cuda(), d.get_samples())
+            if name == "stepwise" and not only:   # (kept on the host until the leg is over: a device allocation
+                pre[k] = (d.get_cloud()[0], d.get_samples())   #  between two frames can stall the next one)
             if k >= n_warm:
                 lat.append(dt * 1e3)
                 scored += n_sc
@@ -187,6 +187,9 @@ def stream_legs(seed, n_frames, n_warm, S=None, only=None, host_leg=True):
         results[name] = out
         legs[name]["hypotheses_last_frame"] = int(d.counters().n_hypotheses)
         d.close()
+        if name == "stepwise" and not only:
+            pre = {k: (torch.from_numpy(c).cuda(), i) for k, (c, i) in pre.items()}
+            torch.cuda.synchronize()
     if only:
         return {"leg": only, **legs[only]}
     same = (results["graph"] == results["stepwise"] and results["plain"] == results["stepwise"]
