@@ -1196,8 +1196,11 @@ k_sweep(SweepArgs A) {
     unsigned long long todo = __ballot(hand_l != 0u);               // hand_search.cpp:370
     {
       if (todo) {  // (uniform: every wave holds the same gates)
-        if (!ARENA) {
-          if (tid == 0) {
+        // the two reservations -- room for the list, places in the pair queue -- go out together: one round
+        // trip instead of two on the critical path of a sample that passes
+        if (tid == 0) {
+          const unsigned pbase = atomicAdd(&A.st->n_pairs, (unsigned)__popcll(todo));
+          if (!ARENA) {
             long long loff = (long long)atomicAdd(&A.st->list_top, (unsigned long long)K);
             if (loff + K > A.list_cap) {
               atomicOr(&A.st->err_flags, 2u);  // the host grows the list arena and repeats the run
@@ -1205,32 +1208,45 @@ k_sweep(SweepArgs A) {
             }
             S.arena_off = loff;
           }
-          __syncthreads();
+          S.flag = (int)pbase;
         }
+        __syncthreads();
         const long long loff = S.arena_off;  // (ARENA: where the crop put the list)
+        const unsigned base = (unsigned)S.flag;
         if (loff >= 0) {
-          for (int j = tid; !ARENA && j < K; j += NT) {
-            float x, y, z;
-            ldp(j, x, y, z);
-            A.lists[loff + j] = make_float4(x, y, z, __int_as_float(pos_at(j)));
-          }
-          if (wid == 0) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(&A.st->n_pairs, (unsigned)__popcll(todo));
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            if (hand_l != 0u) {
-              SweepPair pr;
-              pr.t = t;
-              pr.oi = lane;
-              pr.hand = hand_l;
-              pr.K = K;
-              pr.list_off = loff;
-              pr.segs.end[0] = ge0; pr.segs.end[1] = ge1; pr.segs.end[2] = ge2;
-              pr.segs.shift[0] = gs0; pr.segs.shift[1] = gs1; pr.segs.shift[2] = gs2;
-              pr.pad[0] = pr.pad[1] = 0;
-              A.pairs[base + (unsigned)__popcll(todo & lt_mask)] = pr;
+          if constexpr (!ARENA) {
+            // four points requested before the first is stored (the position comes from LDS, the point from
+            // L2: one point per iteration was a chain of seven exposed round trips per thread)
+            for (int j0 = tid; j0 < K; j0 += 4 * NT) {
+              float4 v4[4];
+              int ps[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                ps[u] = pos_at(min(j0 + u * NT, K - 1));
+                v4[u] = A.pts[ps[u]];
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int j = j0 + u * NT;
+                if (j < K)  // (p - q in float: the value ldp() hands to the passes)
+                  A.lists[loff + j] = make_float4(v4[u].x - q.x, v4[u].y - q.y, v4[u].z - q.z, __int_as_float(ps[u]));
+              }
             }
           }
+        }
+        // (the queue places were taken together with the list's room: when that room was refused -- the run is
+        // then repeated with a larger arena -- the places are filled with pairs k_sweep_orient skips: K = 0)
+        if (wid == 0 && hand_l != 0u) {
+          SweepPair pr;
+          pr.t = t;
+          pr.oi = lane;
+          pr.hand = hand_l;
+          pr.K = (loff >= 0) ? K : 0;
+          pr.list_off = (loff >= 0) ? loff : 0;
+          pr.segs.end[0] = ge0; pr.segs.end[1] = ge1; pr.segs.end[2] = ge2;
+          pr.segs.shift[0] = gs0; pr.segs.shift[1] = gs1; pr.segs.shift[2] = gs2;
+          pr.pad[0] = pr.pad[1] = 0;
+          A.pairs[base + (unsigned)__popcll(todo & lt_mask)] = pr;
         }
       }
     }

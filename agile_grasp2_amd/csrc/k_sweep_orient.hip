@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     if (tid == 0) nxt = gridDim.x + atomicAdd(&A.st->work_next[2], 1u);
     const SweepPair pr = A.pairs[w];
     const int t = pr.t, oi = pr.oi, K = pr.K;
+    if (K <= 0) continue;  // (uniform) a place whose list found no room in the arena: the run is being repeated
     const unsigned hand = pr.hand;
     const float4* plist = A.lists + pr.list_off;
     // (the list's segments: the same in every lane, kept in scalar registers)
