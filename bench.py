@@ -814,7 +814,9 @@ def main():
             return scored
 
         legs_pipe = {}
-        for name, sub in (("headline_cloud_from_host", lambda: pipe.submit(xyz, idx, seed=args.seed)),
+        for name, sub in (("headline_cloud_resident", lambda: pipe.submit(sample_idx=idx, seed=args.seed, dptr=xyz_dev.data_ptr(),
+                                                                          n=xyz.shape[0], stride=12)),
+                          ("headline_cloud_from_host", lambda: pipe.submit(xyz, idx, seed=args.seed)),
                           ("raw_cloud_from_host", (lambda: pipe.submit_raw(raw, num_samples=S, sample_seed=args.seed,
                                                                            seed=args.seed, voxel_size=scene.VOXEL))
                            if voxelised else None)):

@@ -321,3 +321,34 @@ def test_pipe_returns_the_bytes_of_the_synchronous_calls(raw):
         for dp in dbufs:
             hip.hipFree(dp)
     sync.close()
+
+
+def test_raw_frames_that_are_empty_or_fully_filtered():
+    """A raw frame with no points, one whose points all lie outside the workspace, and an ordinary one in
+    between: no error, nothing selected, and the stream goes on (the reference returns an empty list for
+    an empty cloud, grasp_detector.cpp:86-91)."""
+    from agile_grasp2_amd import capi
+    raws, ws = scene.make_stream(95, 30000, 3, voxel=None)
+    prm = scene_params(ws, min_score_diff=-1e30, num_selected=20)
+    d = capi.Detector(**prm)
+    d.lenet_load(make_lenet_weights(7))
+    outside = (raws[0] + np.float32([10.0, 0.0, 0.0])).astype(np.float32)
+    seq = [raws[0], np.zeros((0, 3), np.float32), raws[1], outside, raws[2], raws[0]]
+    counts = []
+    for k, raw in enumerate(seq):
+        sel, n_sc, n_vox = d.detect_frame_raw(raw, num_samples=150, sample_seed=k, seed=k)
+        counts.append((len(sel), n_sc, n_vox))
+    assert counts[1] == (0, 0, 0) and counts[3] == (0, 0, 0), counts
+    assert all(c[2] > 1000 and c[1] > 0 for i, c in enumerate(counts) if i not in (1, 3)), counts
+    # the pipe takes the same frames
+    pipe = capi.Pipe(depth=2, **prm)
+    pipe.lenet_load(make_lenet_weights(7))
+    got = []
+    for k, raw in enumerate(seq):
+        pipe.submit_raw(raw, num_samples=150, sample_seed=k, seed=k)
+        if k >= 1:
+            got.append(pipe.wait())
+    got.append(pipe.wait())
+    assert [(len(s), a, v) for s, a, v in got] == counts
+    pipe.close()
+    d.close()

@@ -116,3 +116,26 @@ def test_hip_invariants_at_config2_size():
     b = d.generate_hypotheses(sample_idx=idx[2500:], slot_base=2500, seed=4)
     assert np.concatenate([a, b]).tobytes() == h.tobytes()
     d.close()
+
+
+def test_raw_cloud_generators_voxelise_back():
+    """The harness's raw-cloud generators (bench.py's front-end leg, the cfg5 stream): raw_from_voxels gives
+    a cloud whose voxelisation (CloudCamera::voxelizeCloud, cloud_camera.cpp:124-168) is the voxel cloud it was
+    made from, byte for byte -- in numpy and through the oracle's preprocess_cloud --, and make_stream(voxel=None)
+    gives raw frames that voxelise to about 0.4 of their size."""
+    from oracle import api
+    vox, ws = scene.make_scene(seed=5, n_target=20000)
+    x = vox.astype(np.float64)
+    inside = ((x[:, 0] > ws[0]) & (x[:, 0] < ws[1]) & (x[:, 1] > ws[2]) & (x[:, 1] < ws[3]) &
+              (x[:, 2] > ws[4]) & (x[:, 2] < ws[5]))
+    assert inside.all()   # (this scene lies inside its workspace: the lattice origin stays where it was)
+    raw = scene.raw_from_voxels(vox, 5)
+    assert 2.4 * len(vox) < len(raw) < 2.7 * len(vox)
+    assert scene.voxelize(raw).tobytes() == vox.tobytes()
+    o = api.Oracle(workspace=list(ws), num_threads=2)
+    assert o.preprocess_cloud(raw, voxel_size=scene.VOXEL) == len(vox)
+    assert o.get_cloud()[0].tobytes() == vox.tobytes()
+    frames, _ = scene.make_stream(3, 30000, 2, voxel=None)
+    for f in frames:
+        assert abs(len(f) - 30000) < 600
+        assert 0.3 * len(f) < len(scene.voxelize(f)) < 0.6 * len(f)
