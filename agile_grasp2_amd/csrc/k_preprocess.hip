@@ -465,6 +465,8 @@ __global__ void __launch_bounds__(256) k_vox_mark_frame(const float4* __restrict
   const float4 p = raw[i];
   if (!ws_keep(p, ws, do_filter)) return;
   const long long key = vox_key(p, v);
+  // (a load first, skipping the atomic when the bit is already set -- two to three points share a voxel --
+  // measured SLOWER: 61 against 41 us for 765 k points in random order; the atomics are not what limits it)
   atomicOr(&bitmap[key >> 5], 1u << (key & 31));
 }
 
