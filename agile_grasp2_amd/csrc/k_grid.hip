@@ -7,6 +7,10 @@
 #include "ag2_internal.h"
 #include "k_grid_common.h"
 
+#ifndef AG2_SCAN_PER
+#define AG2_SCAN_PER 8
+#endif
+
 namespace ag2 {
 
 __global__ void k_init_stats(DevStats* st) {
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ x
   if (i < n) key[i] = make_int2(k, r);
 }
 
-// ---- exclusive scan of uint32, one pass (2048 elements per tile) ---------------------------------
+// ---- exclusive scan of uint32, one pass (kScanTile elements per tile) ----------------------------
 // Chained scan with look-back: a workgroup draws its tile from a ticket counter (so every
 // predecessor it waits for is already running, whatever the dispatch order), scans the tile,
 // publishes the tile total, and wave 0 looks back over the predecessors' records -- 64 at a time --
@@ -161,6 +165,8 @@ __global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ x
 // POPC: the input is the population count of src[i] (i < n - 1; element n - 1 counts as zero, so
 // data[n - 1] receives the total) -- the voxel front end's rank-per-bitmap-word scan, without a pass that
 // writes the counts first.
+constexpr int kScanPer = AG2_SCAN_PER;          // elements per thread
+constexpr int kScanTile = 256 * kScanPer;       // ... per tile
 template <bool POPC>
 __global__ void __launch_bounds__(256) k_scan_chained(unsigned* __restrict__ data, int n,
                                                       unsigned* __restrict__ ctl,
@@ -171,11 +177,11 @@ __global__ void __launch_bounds__(256) k_scan_chained(unsigned* __restrict__ dat
   if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[0], 1u);
   __syncthreads();
   const int tile = (int)s_tile;
-  const int base = tile * 2048 + threadIdx.x * 8;
-  unsigned v[8];
+  const int base = tile * kScanTile + threadIdx.x * kScanPer;
+  unsigned v[kScanPer];
   unsigned tot = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < kScanPer; k++) {
     if (POPC) v[k] = (base + k < n - 1) ? (unsigned)__popc(src[base + k]) : 0u;
     else v[k] = (base + k < n) ? data[base + k] : 0u;
     tot += v[k];
@@ -228,19 +234,19 @@ __global__ void __launch_bounds__(256) k_scan_chained(unsigned* __restrict__ dat
   __syncthreads();
   unsigned run = s_prefix + woff + inc - tot;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < kScanPer; k++) {
     if (base + k < n) data[base + k] = run;
     run += v[k];
   }
 }
 
-size_t scan_ctl_words(int n) { return 2 + 2 * ((size_t)n / 2048 + 1) + 2; }
+size_t scan_ctl_words(int n) { return 2 + 2 * ((size_t)n / kScanTile + 1) + 2; }
 
 // zeroed_ctl: scan_ctl_words(n) zeroed words the caller cleared together with its own buffers
 // (saves the fill); nullptr = the scan clears its own.
 int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n, unsigned* zeroed_ctl) {
   if (n <= 0) return 0;
-  const int nb = (n + 2047) / 2048;
+  const int nb = (n + kScanTile - 1) / kScanTile;
   if (!zeroed_ctl) {
     const size_t words = scan_ctl_words(n);
     AG2_HIP(c, c->d_scan.reserve(words * sizeof(unsigned)));
@@ -256,7 +262,7 @@ int scan_exclusive_u32(ag2_ctx* c, unsigned* d, int n, unsigned* zeroed_ctl) {
 // rank[w] = number of set bits in bitmap[0 .. w), w = 0 .. words (rank[words] = all of them)
 int scan_popc_u32(ag2_ctx* c, const unsigned* bitmap, int words, unsigned* rank, unsigned* zeroed_ctl) {
   const int n = words + 1;
-  const int nb = (n + 2047) / 2048;
+  const int nb = (n + kScanTile - 1) / kScanTile;
   if (!zeroed_ctl) {
     const size_t w = scan_ctl_words(n);
     AG2_HIP(c, c->d_scan.reserve(w * sizeof(unsigned)));
