@@ -367,9 +367,12 @@ void learn_shapes(ag2_ctx* c, ag2_frame_state* f, const FrameIn& in, size_t n_vo
   const size_t n_cloud = in.raw ? n_vox : n;
   c->fm_n_max = std::max(c->fm_n_max, n_cloud + n_cloud / 8 + 1024);
   c->fm_s_max = in.raw ? s_used : std::max(c->fm_s_max, s_used);
+  // cell table: this frame's grid with 4 cells (4 cm) of room per axis and a fifth on top -- the scan, the cell
+  // sort and the fill run over the whole table, so generous room costs every frame (2.3 x the cells cost the
+  // headline cloud 40 us per frame); a frame that outgrows it is repeated step by step and the table grows
   long long cells = 1;
-  for (int a = 0; a < 3; a++) cells *= (long long)(c->grid.dims[a] + 8);
-  cells = std::min<long long>(cells + cells / 2, 1ll << 30);
+  for (int a = 0; a < 3; a++) cells *= (long long)(c->grid.dims[a] + 4);
+  cells = std::min<long long>(cells + cells / 5, 1ll << 30);
   c->fm_cap_cells = std::max<size_t>(c->fm_cap_cells, (size_t)cells);
   if (in.raw) {
     f->fs.raw_max = std::max(f->fs.raw_max, n + n / 8 + 1024);
