@@ -1115,6 +1115,54 @@ std::vector<GraspHypothesis> GraspDetector::detectImpl(const CloudCamera& cloud_
   return out;
 }
 
+std::vector<GraspHypothesis> GraspDetector::detectGraspPosesInFrame(const PointCloudRGB::Ptr& raw_cloud) {
+  std::vector<GraspHypothesis> out;
+  if (!raw_cloud || raw_cloud->size() == 0) {  // grasp_detector.cpp:86-91
+    fprintf(stderr, "Point cloud is empty!\n");
+    return out;
+  }
+  const bool one_call = p_.antipodal_mode == PREDICTION && p_.voxelize && !use_incoming_samples_ && indices_.empty() &&
+                        p_.devices.size() <= 1 && num_samples_ > 0 && classifier_ && classifier_->ok();
+  if (!one_call) {  // the two calls, as the file path of the node makes them (grasp_detection_node.cpp:97-121)
+    CloudCamera cc(raw_cloud, (int)raw_cloud->size());
+    preprocessPointCloud(cc);
+    return detectGraspPoses(cc);
+  }
+  std::shared_ptr<ag2::Context> ctx = contextFor(1);
+  if (!ctx) {
+    fprintf(stderr, "GraspDetector: %s\n", err_.c_str());
+    return out;
+  }
+  ag2_ctx* c = ctx->get();
+  int rc = 0;
+  if (weights_in_ctx_ != c) {  // once per context: packing the weights is host work of milliseconds
+    rc = ag2_lenet_load(c, classifier_->blob(0).data(), classifier_->blob(1).data(), classifier_->blob(2).data(),
+                        classifier_->blob(3).data(), classifier_->blob(4).data(), classifier_->blob(5).data(),
+                        classifier_->blob(6).data(), classifier_->blob(7).data());
+    weights_in_ctx_ = rc ? nullptr : c;
+  }
+  const int hs_inliers = handle_search_.getMinInliers();
+  if (!rc) rc = ag2_set_min_inliers(c, hs_inliers > 0 ? hs_inliers : 0);  // (clustered frames run step by step inside the library)
+  const size_t cap = std::max<size_t>(1, (size_t)num_samples_ * (size_t)p_.num_orientations);
+  std::vector<ag2_hypothesis> recs(cap);
+  size_t n = 0, n_scored = 0, n_vox = 0;
+  if (!rc)
+    rc = ag2_detect_frame_raw(c, &raw_cloud->points[0].x, /*on_device=*/0, raw_cloud->size(), sizeof(ag2::PointXYZRGBA),
+                              p_.workspace.size() >= 6 ? 1 : 0, voxel_size_, (size_t)num_samples_, p_.seed, p_.seed,
+                              /*do_prune=*/1, recs.data(), recs.size(), &n, &n_scored, &n_vox);
+  resident_ctx_ = nullptr;  // (the context's cloud is this frame's processed cloud, not a CloudCamera's)
+  if (rc) {
+    err_ = ag2_last_error(c);
+    fprintf(stderr, "GraspDetector::detectGraspPosesInFrame: %s\n", err_.c_str());
+    return out;
+  }
+  (void)ag2_get_stage_times(c, &times_);
+  (void)ag2_get_counters(c, &counters_);
+  out.reserve(n);
+  for (size_t h = 0; h < n; h++) out.push_back(GraspHypothesis(recs[h]));
+  return out;
+}
+
 // Params::devices: the sample list cut into contiguous ranges, one per device; every device holds the whole
 // cloud (a 300 k-point cloud is 4.8 MB) and runs grid, normals and detect for its range with the samples'
 // positions in the WHOLE list as slot base -- so its hypotheses are those of the one-device run

@@ -73,6 +73,15 @@ class GraspDetector {
   std::vector<GraspHypothesis> detectGraspPoses(const CloudCamera& cloud_cam, bool clusters_grasps = true);
   // grasp_detector.cpp:285-350
   void preprocessPointCloud(CloudCamera& cloud_cam);
+  // One frame of a sensor stream, as a live topic needs it (the reference's topic path,
+  // grasp_detection_node.cpp:123-143, calls detectGraspPoses on the cloud as it arrives; its file path :97-121
+  // preprocesses first): preprocessPointCloud -- workspace filter, voxel grid, uniform sub-sampling of
+  // num_samples points -- followed by detectGraspPoses, in ONE GPU call (ag2_detect_frame_raw: filter, voxel
+  // grid, sub-sampling and the whole per-frame pipeline in one captured sequence, one host synchronisation).
+  // The same hands as the two calls on a CloudCamera of this cloud.  Needs what those calls need for the GPU
+  // front end: one camera, voxelize, no incoming samples or indices, antipodal_mode PREDICTION; any other
+  // setting takes the two calls.
+  std::vector<GraspHypothesis> detectGraspPosesInFrame(const PointCloudRGB::Ptr& raw_cloud);
 
   static bool isScoreGreater(const GraspHypothesis& a, const GraspHypothesis& b) {
     return a.getScore() > b.getScore();
@@ -133,6 +142,7 @@ class GraspDetector {
   HandleSearch handle_search_;
   std::shared_ptr<ag2::Context> ctx_;
   int ctx_cams_ = 0;
+  const ag2_ctx* weights_in_ctx_ = nullptr;          // detectGraspPosesInFrame: the context that holds the LeNet weights
   std::vector<std::shared_ptr<ag2::Context>> peers_;  // contexts of Params::devices[1 ...]
   int peers_cams_ = 0;
   // cloud left in the context by preprocessPointCloud: detectGraspPoses does not upload it again

@@ -81,6 +81,57 @@ static int run_preprocess(const char* raw_path, const char* params_path, const c
   return 0;
 }
 
+// test_host_api --frames <raw.f32> <params.txt> <out.bin>: GraspDetector::detectGraspPosesInFrame three times on
+// the same raw cloud (the first call runs step by step, the second at fixed shapes, the third replays the graph)
+// beside preprocessPointCloud + detectGraspPoses on a second detector.  Output: for each of the four runs
+// int64 n, then {int32 slot, int32 orientation, double score} per grasp.
+static int run_frames(const char* raw_path, const char* params_path, const char* out_path) {
+  const std::vector<float> xyz = read_all<float>(raw_path);
+  std::ifstream pf(params_path);
+  const std::string ptext((std::istreambuf_iterator<char>(pf)), std::istreambuf_iterator<char>());
+  GraspDetector::Params prm;
+  std::string err;
+  if (!GraspDetector::Params::fromKeyValueText(ptext, &prm, &err)) {
+    fprintf(stderr, "params: %s\n", err.c_str());
+    return 2;
+  }
+  PointCloudRGB::Ptr cloud(new PointCloudRGB);
+  cloud->points.resize(xyz.size() / 3);
+  for (size_t i = 0; i < cloud->size(); i++) {
+    cloud->points[i].x = xyz[3 * i];
+    cloud->points[i].y = xyz[3 * i + 1];
+    cloud->points[i].z = xyz[3 * i + 2];
+  }
+  std::ofstream out(out_path, std::ios::binary);
+  auto dump = [&](const std::vector<GraspHypothesis>& sel) {
+    const int64_t ns = (int64_t)sel.size();
+    put(out, &ns, 1);
+    for (const GraspHypothesis& h : sel) {
+      const int32_t so[2] = {h.getSampleSlot(), h.getOrientation()};
+      const double sc = h.getScore();
+      put(out, so, 2);
+      put(out, &sc, 1);
+    }
+  };
+  GraspDetector frames(prm);
+  size_t total = 0;
+  for (int k = 0; k < 3; k++) {
+    const std::vector<GraspHypothesis> sel = frames.detectGraspPosesInFrame(cloud);
+    if (!frames.lastError().empty()) {
+      fprintf(stderr, "frame %d: %s\n", k, frames.lastError().c_str());
+      return 3;
+    }
+    total += sel.size();
+    dump(sel);
+  }
+  GraspDetector two(prm);
+  CloudCamera cc(cloud, (int)cloud->size());
+  two.preprocessPointCloud(cc);
+  dump(two.detectGraspPoses(cc));
+  printf("frames ok: %zu grasps in three frames\n", total);
+  return 0;
+}
+
 // test_host_api --importance <cloud.f32> <idx.i32> <params.txt> <out.bin>:
 // ImportanceSampling::detectGraspPoses (importance_sampling.cpp:30-118) on a preprocessed cloud
 static int run_importance(const char* cloud_path, const char* idx_path, const char* params_path,
@@ -255,6 +306,7 @@ int main(int argc, char** argv) {
     return run_modes(argv[2], argv[3], argv[4], argv[5], argc == 7 ? argv[6] : nullptr);
   if (argc == 3 && std::string(argv[1]) == "--constants") return run_constants(argv[2]);
   if (argc == 5 && std::string(argv[1]) == "--preprocess") return run_preprocess(argv[2], argv[3], argv[4]);
+  if (argc == 5 && std::string(argv[1]) == "--frames") return run_frames(argv[2], argv[3], argv[4]);
   if (argc == 4 && std::string(argv[1]) == "--caffemodel") return run_caffemodel(argv[2], argv[3]);
   if (argc == 4 && std::string(argv[1]) == "--pcd") return run_pcd(argv[2], argv[3]);
   if (argc == 6 && std::string(argv[1]) == "--importance") return run_importance(argv[2], argv[3], argv[4], argv[5]);

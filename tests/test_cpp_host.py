@@ -303,6 +303,42 @@ def test_cpp_detect_on_several_devices_equals_one_device(tmp_path, small_scene, 
     assert np.all(np.diff(b["score"]) <= 0)   # the merge's own order: score descending
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("min_inliers", [0, 1])
+def test_cpp_frames_of_the_raw_cloud_equal_the_two_calls(tmp_path, min_inliers):
+    """GraspDetector::detectGraspPosesInFrame (ag2_detect_frame_raw behind the mirror: filter + voxel grid +
+    sub-sampling + detect in one captured GPU sequence) three times on one raw cloud -- step by step, at fixed
+    shapes, as a graph replay -- against preprocessPointCloud + detectGraspPoses on a second detector: the same
+    bytes every time.  With min_inliers > 0 the frames run step by step inside the library (clustering is not
+    part of the captured sequence) and must agree as well."""
+    tmp = str(tmp_path)
+    exe = build_driver(tmp)
+    raw, ws = scene.make_scene(seed=12, n_target=50000, voxel=None, spacing=0.0015)
+    w = make_lenet_weights(7)
+    wpath, lpath = os.path.join(tmp, "w.ag2w"), os.path.join(tmp, "labels.txt")
+    save_ag2w(wpath, w)
+    open(lpath, "w").write("0\n1\n")
+    raw.astype("<f4").tofile(os.path.join(tmp, "raw.f32"))
+    text = params_text(ws, wpath, lpath, 5) + f"num_samples = 400\nvoxelize = true\nmin_inliers = {min_inliers}\n"
+    text = text.replace("num_selected = 1000", "num_selected = 25")
+    open(os.path.join(tmp, "params.txt"), "w").write(text)
+    outp = os.path.join(tmp, "out.bin")
+    r = subprocess.run([exe, "--frames", os.path.join(tmp, "raw.f32"), os.path.join(tmp, "params.txt"), outp],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "frames ok" in r.stdout
+    buf = open(outp, "rb").read()
+    dt = np.dtype([("slot", "<i4"), ("orient", "<i4"), ("score", "<f8")])
+    runs, off = [], 0
+    for _ in range(4):
+        (n,) = struct.unpack_from("<q", buf, off)
+        off += 8
+        runs.append(np.frombuffer(buf, dtype=dt, count=n, offset=off).tobytes())
+        off += n * dt.itemsize
+        assert n > 0 and n <= 25
+    assert runs[0] == runs[1] == runs[2] == runs[3]
+
+
 def test_launch_xml_and_keyvalue_readers(tmp_path):
     """Params readers accept the reference's own launch file text (parameter NAMES are the
     contract; the file is read at test time from /root/reference when present, else a literal
