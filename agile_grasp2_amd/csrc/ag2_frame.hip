@@ -190,7 +190,7 @@ unsigned long long frame_signature(const ag2_ctx* c, const ag2_frame_state* f) {
                         c->d_logits.p, c->d_act1.p, c->d_fcpart.p, c->d_sel.p, c->d_flags.p, c->d_desc.p,
                         c->d_scan.p, f->h_pin, c->net.w1x.p, c->net.w2x.p, c->net.w3x.p,
                         c->net.b1.p, c->net.b2.p, c->net.b3.p, c->net.w4.p, c->net.b4.p, (const void*)c->stream,
-                        c->d_raw.p, c->d_bitmap.p, c->d_wrank.p, c->d_preframe.p, c->d_cand.p, c->d_samples.p};
+                        c->d_raw.p, c->d_bitmap.p, c->d_wrank.p, c->d_preframe.p, c->d_cand.p, c->d_samples.p, c->d_rlist.p};
   unsigned cell_bits = 0;
   memcpy(&cell_bits, &f->fs.cell, 4);
   const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points, c->list_ints, f->cap_img,

@@ -219,6 +219,7 @@ struct ag2_ctx {
   const unsigned* d_last_nsel = nullptr;  // ... and its count on the device
   ag2::DevBuf d_flags;     // uint32 flags / prefix for slot compaction
   ag2::DevBuf d_desc;      // image descriptors: int64 arena offset[n] then int32 count[n]
+  ag2::DevBuf d_rlist;     // renderers of the larger images: 8 counters, then one image list per renderer (k_image.hip)
   ag2::DevBuf d_cluster;   // ag2_hypothesis: clustered hands, compacted (k_cluster.hip)
   ag2::DevBuf d_cluster_tmp;  // ag2_hypothesis: moved hands before the compaction
   int min_inliers = 0;     // HandleSearch::setMinInliers; 0 = no clustering inside ag2_detect

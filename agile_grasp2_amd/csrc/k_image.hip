@@ -10,7 +10,10 @@
 // Round r then adds the normals of all rank-r points to their leader's accumulator -- distinct
 // cells within a round, list order across rounds -- and only the leaders quantise a pixel.  34 KB of
 // LDS: four workgroups per CU.
-// k_render_sorted (1024 < P <= 16384): cell-major sort of the points in LDS, then one run per cell.
+// k_render_counted (1024 < P <= 4096): cell-major order by a stable counting sort in LDS (ranks from
+// wave ballots), then one run per cell, added in a counted loop.
+// k_render_sorted (4096 < P <= 16384): the same order from a bitonic network over (cell, position) keys.
+// The images of these two are listed per renderer first (k_render_classify) and handed out one at a time.
 // k_render (any P): every cell is owned by one thread (cell % 256) which adds the normals of its
 // points in list order; two passes of 30 image rows, 76 KB of LDS.
 // Quantisation to u8 happens BEFORE the 3x3 dilate: v -> sat(rint(255 v)) is monotone, so
@@ -146,6 +149,48 @@ __device__ __forceinline__ double block_min_y(const double* __restrict__ pts, in
 #pragma unroll
   for (int k = 1; k < NT / kWave; k++) miny = (red[k] < miny) ? red[k] : miny;
   return miny;
+}
+
+// The images of one renderer as a dense list, handed out through a counter: a renderer's images differ by a
+// factor of four in their point counts, and a static deal of a few of them to every workgroup ends with most
+// of the GPU waiting for the unluckiest one.  list == nullptr: all images in turn, each kernel skipping the
+// others' by the point count (when only one renderer runs there is nothing to balance).
+struct ImgQueue {
+  const int* list;        // image indices of this renderer
+  const unsigned* count;  // how many
+  unsigned* next;         // zero at launch; a workgroup takes gridDim.x + (this++) when it is done with an image
+};
+__device__ __forceinline__ int img_queue_next(const ImgQueue& q, int w, int* s_next, int& it) {
+  if (!q.list) return w + (int)gridDim.x;
+  if (threadIdx.x == 0) s_next[it & 1] = (int)gridDim.x + (int)atomicAdd(q.next, 1u);
+  __syncthreads();
+  const int v = __builtin_amdgcn_readfirstlane(s_next[it & 1]);
+  it++;
+  return v;
+}
+
+// kinds: 0 = (kSparseMax, kSortedMax], 1 = (kSortedMax, kSortedMaxBig], 2 = beyond; ctr[kind] = list length
+__global__ void __launch_bounds__(256) k_render_classify(const long long* __restrict__ desc_off,
+                                                         const int* __restrict__ desc_cnt, int n_img,
+                                                         const unsigned* __restrict__ d_n, int cap,
+                                                         unsigned* __restrict__ ctr, int* __restrict__ lists) {
+  if (d_n) n_img = min(n_img, (int)*d_n);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int kind = -1;
+  if (i < n_img) {
+    const int P = (desc_off[i] >= 0) ? desc_cnt[i] : 0;
+    kind = (P <= kSparseMax) ? -1 : ((P <= 4096) ? 0 : ((P <= 16384) ? 1 : 2));
+  }
+  const unsigned long long lt = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const unsigned long long m = __ballot(kind == k);
+    if (m == 0ull) continue;
+    unsigned base = 0;
+    if (lane_id() == 0) base = atomicAdd(&ctr[k], (unsigned)__popcll(m));
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (kind == k) lists[(size_t)k * cap + base + (unsigned)__popcll(m & lt)] = i;
+  }
 }
 
 __global__ void __launch_bounds__(kImgThreads) k_render(const double* __restrict__ arena,
@@ -356,13 +401,14 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
   }
 }
 
-// k_render_sorted (kSparseMax < P <= kSortedMax, dense clouds): the points' (cell, list position)
+// k_render_sorted (kSortedMax < P <= kSortedMaxBig, dense clouds; AG2_RENDER_BITONIC=1: also the range of
+// k_render_counted below, for A/B): the points' (cell, list position)
 // keys are sorted in LDS (bitonic, the position in the low bits keeps list order inside a cell), so
 // every cell's points sit together; the thread that finds the head of a run adds the run's normals
 // in list order -- the same f64 sums as the reference's scan over all points for each cell, at
 // O(P log^2 P) instead of O(3600 P).
-// Two instantiations: up to 4096 points (48 KB of LDS, three workgroups per CU) and up to 16384
-// (96 KB, one per CU); NBITS = bits of the list position inside a key.
+// Two instantiations: up to 16384 points (96 KB of LDS, one workgroup per CU) and up to 4096 (48 KB, three per
+// CU: the A/B twin of k_render_counted); NBITS = bits of the list position inside a key.
 constexpr int kSortedMax = 4096, kSortedMaxBig = 16384;
 constexpr int kWalk = 768;         // sorted positions whose normals are staged in LDS at a time
 template <int NMAX, int NT>
@@ -446,14 +492,18 @@ __global__ void __launch_bounds__(NT) k_render_sorted(const double* __restrict__
                                                                const long long* __restrict__ desc_off,
                                                                const int* __restrict__ desc_cnt,
                                                                int n_img, const unsigned* __restrict__ d_n,
-                                                               int p_min, unsigned char* __restrict__ out) {
+                                                               int p_min, unsigned char* __restrict__ out, ImgQueue q) {
   static_assert((1 << NBITS) >= NMAX && NBITS + 12 < 32, "key layout");
   if (d_n) n_img = min(n_img, (int)*d_n);  // frame mode: the list length is read on the device
+  __shared__ int s_qnext[2];
+  int qit = 0;
+  const int n_work = q.list ? (int)*q.count : n_img;
   constexpr unsigned kPosMask = (1u << NBITS) - 1u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_sorted[];
   SortedShared<NMAX, NT>& S = *reinterpret_cast<SortedShared<NMAX, NT>*>(smem_sorted);
   const int tid = threadIdx.x;
-  for (int im = blockIdx.x; im < n_img; im += gridDim.x) {
+  for (int w = blockIdx.x; w < n_work; w = img_queue_next(q, w, s_qnext, qit)) {
+    const int im = q.list ? q.list[w] : w;
     const long long off = desc_off[im];
     const int P = (off >= 0) ? desc_cnt[im] : 0;
     if (P < p_min || P > NMAX) continue;  // the other renderers' images (uniform)
@@ -570,6 +620,217 @@ __global__ void __launch_bounds__(NT) k_render_sorted(const double* __restrict__
   }
 }
 
+// k_render_counted (kSparseMax < P <= kSortedMax): the same cell-major order by COUNTING instead of comparing.
+// Each wave owns a contiguous quarter of the list and takes it in chunks of 64 consecutive positions.  In
+// a chunk the lanes that share a cell find each other with twelve ballots (one per bit of the cell id: after
+// bit k a lane's mask keeps the lanes whose bit k equals its own), which gives a point its rank among the
+// chunk's points of its cell -- list order, data-independent cost: a cell with hundreds of points (a surface
+// seen edge-on) costs what sixty-four different cells cost.  Rank in the chunk + the wave's running count
+// of the cell (one u16 per wave and cell in LDS) + the counts of the waves before it + the cell's first
+// slot (a scan over the 3 600 cell totals) = the point's slot in (cell, list position) order: a stable
+// counting sort, ~1 400 instructions per wave for 2 300 points where the bitonic network takes ~4 000.
+// The walk then has every cell's run as a pair of slots, so a thread adds a run's normals in a COUNTED
+// loop (the loads of the next terms run ahead of the chain of additions; the network version found a
+// run's end by reading keys as it went -- one LDS round trip per term, the longest run of a chunk on the
+// critical path).  Cells are dealt to threads modulo 256; the sums are the reference's, term by term.
+constexpr int kCWaves = kImgThreads / kWave;
+struct CountedShared {
+  unsigned short pos[kSortedMax];       // list positions in (cell, list position) order
+  unsigned short start[kCells + 8];     // first slot of every cell; start[kCells] = points kept
+  union {
+    unsigned short hist[kCWaves][kCells];  // sort: running count / first slot of (wave, cell)
+    struct {
+      unsigned pix[kCells];
+      double nbuf[kWalk * 3];              // normals of kWalk slots; the staged output image afterwards
+    } w;
+  } u;
+  double red[kCWaves];
+  int part[kCWaves];
+};
+static_assert(sizeof(CountedShared) * 3 <= 160 * 1024, "k_render_counted: three workgroups per CU");
+static_assert(kCells % 15 == 0 && kCells / 15 <= kImgThreads, "scan: 15 cells per thread");
+static_assert(kSortedMax / kCWaves / kWave == 16, "sixteen chunks per wave at most");
+
+__global__ void __launch_bounds__(kImgThreads, 3) k_render_counted(const double* __restrict__ arena,
+                                                                const long long* __restrict__ desc_off,
+                                                                const int* __restrict__ desc_cnt, int n_img,
+                                                                const unsigned* __restrict__ d_n, int p_min,
+                                                                unsigned char* __restrict__ out, ImgQueue q) {
+  if (d_n) n_img = min(n_img, (int)*d_n);  // frame mode: the list length is read on the device
+  __shared__ CountedShared S;
+  __shared__ int s_qnext[2];
+  int qit = 0;
+  const int n_work = q.list ? (int)*q.count : n_img;
+  constexpr int NT = kImgThreads, NW = kCWaves, kChunks = 16;
+  const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int w = blockIdx.x; w < n_work; w = img_queue_next(q, w, s_qnext, qit)) {
+    const int im = q.list ? q.list[w] : w;
+    const long long off = desc_off[im];
+    const int P = (off >= 0) ? desc_cnt[im] : 0;
+    if (P < p_min || P > kSortedMax) continue;  // the other renderers' images (uniform)
+    const double* pts = arena + (size_t)off * 6;
+    __syncthreads();  // previous image's readers of S are done
+    // this wave's quarter of the list: seg positions (a multiple of 64) from wid * seg on
+    const int seg = ((P + NT - 1) / NT) * kWave, nc = seg / kWave;
+    const int b0 = wid * seg + lane;
+    double px[kChunks], py[kChunks];
+    double miny = __builtin_inf();  // learning.cpp:148-149  y <- y - min y
+#pragma unroll
+    for (int c = 0; c < kChunks; c++) {
+      const int b = b0 + c * kWave;
+      px[c] = 0.0;
+      py[c] = __builtin_inf();
+      if (c < nc && b < P) {
+        px[c] = pts[(size_t)b * 6];
+        py[c] = pts[(size_t)b * 6 + 1];
+      }
+    }
+    for (int i = tid; i < NW * kCells / 2; i += NT) reinterpret_cast<unsigned*>(&S.u.hist[0][0])[i] = 0u;
+#pragma unroll
+    for (int c = 0; c < kChunks; c++) miny = (py[c] < miny) ? py[c] : miny;
+    miny = wave_min_d(miny);
+    if (lane == 0) S.red[wid] = miny;
+    __syncthreads();  // (also: the counts are zero)
+    miny = S.red[0];
+#pragma unroll
+    for (int k = 1; k < NW; k++) miny = (S.red[k] < miny) ? S.red[k] : miny;
+    // cell and rank of this thread's points (rank: among the points of its cell in this wave's quarter)
+    short cid[kChunks];
+    unsigned short rank[kChunks];
+#pragma unroll
+    for (int c = 0; c < kChunks; c++) {
+      cid[c] = -1;
+      rank[c] = 0;
+      if (c < nc) {  // uniform
+        const int b = b0 + c * kWave;
+        if (b < P) cid[c] = cell_id(px[c], py[c], miny);
+        const bool valid = cid[c] >= 0;
+        const int cell = valid ? (int)cid[c] : 0;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 12; bit++) {
+          const bool mine = (cell >> bit) & 1;
+          const unsigned long long bb = __ballot(mine);
+          m &= mine ? bb : ~bb;
+        }
+        if (valid) {
+          const int before = (int)S.u.hist[wid][cell];
+          rank[c] = (unsigned short)(before + __popcll(m & lt_mask));
+          if ((m >> lane) == 1ull) S.u.hist[wid][cell] = (unsigned short)(before + __popcll(m));  // the group's last lane
+        }
+      }
+    }
+    __syncthreads();
+    // first slot of every cell (scan over the cell totals), then of every (wave, cell)
+    {
+      constexpr int kPerT = 15;
+      const int c0 = tid * kPerT;
+      int tot[kPerT], sum = 0;
+      if (c0 < kCells) {
+#pragma unroll
+        for (int q = 0; q < kPerT; q++) {
+          int t = 0;
+#pragma unroll
+          for (int w = 0; w < NW; w++) t += (int)S.u.hist[w][c0 + q];
+          tot[q] = t;
+          sum += t;
+        }
+      }
+      int incl = sum;  // inclusive scan over the wave
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const int o = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += o;
+      }
+      if (lane == kWave - 1) S.part[wid] = incl;
+      __syncthreads();
+      int base = incl - sum;
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+        if (w < wid) base += S.part[w];
+      if (c0 < kCells) {
+#pragma unroll
+        for (int q = 0; q < kPerT; q++) {
+          S.start[c0 + q] = (unsigned short)base;
+          int run = base;
+#pragma unroll
+          for (int w = 0; w < NW; w++) {
+            const int h = (int)S.u.hist[w][c0 + q];
+            S.u.hist[w][c0 + q] = (unsigned short)run;
+            run += h;
+          }
+          base += tot[q];
+        }
+        if (c0 + kPerT == kCells) S.start[kCells] = (unsigned short)base;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kChunks; c++)
+      if (c < nc && cid[c] >= 0) S.pos[(int)S.u.hist[wid][cid[c]] + (int)rank[c]] = (unsigned short)(b0 + c * kWave);
+    __syncthreads();  // the counts are dead: their area becomes the pixel map and the normal stage
+    const int kept = (int)S.start[kCells];
+    for (int i = tid; i < kCells; i += NT) S.u.w.pix[i] = 0u;  // image.setTo(0)
+    // Runs of equal cells, kWalk slots at a time.  The normals of a window are gathered into LDS by all
+    // threads first (independent loads); a thread then adds the runs of ITS cells (cell % 256 == tid) that lie
+    // in the window, in slot order (:166-179).  A run that crosses the window's end stays open in the thread's
+    // accumulators: it is the last of the window, and the first of the next one for the same thread.
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    constexpr int kG = (kWalk + NT - 1) / NT;  // gathers per thread: issued together, stored a window later
+    double g[kG][3];
+    auto gather = [&](int c0) {  // requests the normals of the window that starts at slot c0
+      const int cn = min(kWalk, kept - c0);
+#pragma unroll
+      for (int u = 0; u < kG; u++) {
+        const int t = tid + u * NT;
+        g[u][0] = g[u][1] = g[u][2] = 0.0;
+        if (t < cn) {
+          const double* y = pts + (size_t)S.pos[c0 + t] * 6 + 3;
+          g[u][0] = y[0];
+          g[u][1] = y[1];
+          g[u][2] = y[2];
+        }
+      }
+    };
+    if (kept > 0) gather(0);
+    for (int c0 = 0; c0 < kept; c0 += kWalk) {
+      const int cn = min(kWalk, kept - c0);
+      __syncthreads();  // previous window's readers of nbuf are done (first window: the pixel map is clear)
+#pragma unroll
+      for (int u = 0; u < kG; u++) {
+        const int t = tid + u * NT;
+        if (t < cn) {
+          S.u.w.nbuf[3 * t] = g[u][0];
+          S.u.w.nbuf[3 * t + 1] = g[u][1];
+          S.u.w.nbuf[3 * t + 2] = g[u][2];
+        }
+      }
+      __syncthreads();
+      if (c0 + kWalk < kept) gather(c0 + kWalk);  // the next window's normals travel while this one is added up
+      for (int cell = tid; cell < kCells; cell += NT) {
+        const int s0 = (int)S.start[cell], s1 = (int)S.start[cell + 1];
+        const int a = max(s0, c0), b = min(s1, c0 + cn);
+        if (a >= b) continue;
+        if (a == s0) ax = ay = az = 0.0;
+        const double* nb = S.u.w.nbuf + 3 * (a - c0);
+        const int len = b - a;
+        for (int j = 0; j < len; j++) {
+          ax = ax + nb[3 * j];
+          ay = ay + nb[3 * j + 1];
+          az = az + nb[3 * j + 2];
+        }
+        if (b == s1) {  // the run is complete: quantise, write at (59 - row, col)
+          const int row = kImg - 1 - cell / kImg, col = cell % kImg;
+          S.u.w.pix[row * kImg + col] = quantise(ax, ay, az);
+        }
+      }
+    }
+    __syncthreads();
+    dilate_store<NT>(S.u.w.pix, reinterpret_cast<unsigned char*>(S.u.w.nbuf), out + (size_t)im * (kCells * 3), tid);
+  }
+}
+
 // max_p: an upper bound of the images' point counts (the sweep's statistics have it): renderers
 // none of whose images can occur are not launched.
 // largest point count the renderers launched for an upper bound of max_p can take
@@ -597,15 +858,30 @@ int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, con
   // images with at most kSparseMax points (nearly all) ...
   hipLaunchKernelGGL(k_render_sparse, dim3((int)std::min<size_t>(n_img, 256 * 6)), dim3(kImgThreads), 0,
                      c->stream, d_arena, d_off, d_cnt, (int)n_img, d_n, d_out);
-  // ... the rest; each kernel skips the others' images by the point count alone
-  if (max_p > kSparseMax)
+  // ... the rest: one list per renderer, handed out image by image (ImgQueue)
+  static const bool bitonic = getenv("AG2_RENDER_BITONIC") != nullptr;  // (A/B: the sorting-network renderer)
+  static const bool no_queue = getenv("AG2_RENDER_STATIC") != nullptr;  // (A/B: images dealt statically)
+  ImgQueue q[3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  if (max_p > kSparseMax && !no_queue) {
+    AG2_HIP(c, c->d_rlist.reserve(32 + 3 * n_img * 4));
+    unsigned* ctr = c->d_rlist.as<unsigned>();
+    int* lists = reinterpret_cast<int*>(ctr + 8);
+    AG2_HIP(c, hipMemsetAsync(ctr, 0, 32, c->stream));
+    hipLaunchKernelGGL(k_render_classify, dim3((unsigned)((n_img + 255) / 256)), dim3(256), 0, c->stream, d_off, d_cnt,
+                       (int)n_img, d_n, (int)n_img, ctr, lists);
+    for (int k = 0; k < 3; k++) q[k] = ImgQueue{lists + (size_t)k * n_img, ctr + k, ctr + 4 + k};
+  }
+  if (max_p > kSparseMax && !bitonic)
+    hipLaunchKernelGGL(k_render_counted, dim3((int)std::min<size_t>(n_img, 256 * 3)), dim3(kImgThreads), 0, c->stream,
+                       d_arena, d_off, d_cnt, (int)n_img, d_n, kSparseMax + 1, d_out, q[0]);
+  if (max_p > kSparseMax && bitonic)
     hipLaunchKernelGGL((k_render_sorted<kSortedMax, 12, kImgThreads>), dim3((int)std::min<size_t>(n_img, 256 * 3)),
                        dim3(kImgThreads), sizeof(SortedShared<kSortedMax, kImgThreads>), c->stream, d_arena, d_off, d_cnt,
-                       (int)n_img, d_n, kSparseMax + 1, d_out);
+                       (int)n_img, d_n, kSparseMax + 1, d_out, q[0]);
   if (max_p > kSortedMax)
     hipLaunchKernelGGL((k_render_sorted<kSortedMaxBig, 14, 1024>), dim3((int)std::min<size_t>(n_img, 256)),
                        dim3(1024), sizeof(SortedShared<kSortedMaxBig, 1024>), c->stream, d_arena, d_off,
-                       d_cnt, (int)n_img, d_n, kSortedMax + 1, d_out);
+                       d_cnt, (int)n_img, d_n, kSortedMax + 1, d_out, q[1]);
   if (max_p > kSortedMaxBig)
     hipLaunchKernelGGL(k_render, dim3((int)std::min<size_t>(n_img, 256 * 2)), dim3(kImgThreads), lds, c->stream,
                        d_arena, d_off, d_cnt, (int)n_img, d_n, kSortedMaxBig + 1, d_out);
