@@ -285,7 +285,7 @@ __global__ void k_scatter(const int2* __restrict__ key, int n, const unsigned* _
 
 // Within a cell the arrival order is whatever the atomics produced; restore ascending original
 // index so the layout is deterministic ((key, index) order).
-// A workgroup owns 256 consecutive cells = one contiguous span of perm.  The span is worked through
+// A workgroup owns kSortCells consecutive cells = one contiguous span of perm.  The span is worked through
 // in batches of whole cells that fit the LDS stage (usually one batch: cells of a 3 mm voxel cloud
 // hold ~10-30 points; un-voxelised clouds with hundreds of points per cell take several), each batch
 // rank-sorted with one thread per ELEMENT: every element counts the smaller indices in its own cell
@@ -293,6 +293,8 @@ __global__ void k_scatter(const int2* __restrict__ key, int n, const unsigned* _
 // Only a single cell larger than the stage is sorted in place in global memory by one thread.
 // The sorted float4 cloud is written from here as well (sorted[pos] = xyz[perm[pos]]): the final
 // position of every element is known at this point, so no separate gather pass re-reads perm.
+constexpr int kSortCells = 64;       // cells per workgroup (a 300 k-point voxel cloud has ~30 k cells: at 256 cells
+                                     // per workgroup half the CUs had none)
 constexpr int kSortStage = 6144;     // ints of LDS: values [0, n) + packed cell (start | length << 16) [n, 2n)
 constexpr int kSortBatch = kSortStage / 2;
 static_assert(kSortBatch <= 65535, "cell start and length are packed into 16 bits each");
@@ -301,9 +303,9 @@ __global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ 
                                                    const float4* __restrict__ xyz,
                                                    float4* __restrict__ sorted) {
   __shared__ int stage[kSortStage];
-  __shared__ int cs[257];  // sorted position at which each of the workgroup's cells starts
-  const int c0 = blockIdx.x * 256, tid = threadIdx.x;
-  for (int t = tid; t <= 256; t += 256) cs[t] = (int)cell[min(c0 + t, ncells)];
+  __shared__ int cs[kSortCells + 1];  // sorted position at which each of the workgroup's cells starts
+  const int c0 = blockIdx.x * kSortCells, tid = threadIdx.x;
+  if (tid <= kSortCells) cs[tid] = (int)cell[min(c0 + tid, ncells)];
   // one all-NaN point behind the sorted cloud: what k_normals reads where a load step reaches past
   // the end of its span (cell[ncells] = number of valid points)
   if (blockIdx.x == 0 && tid == 0) {
@@ -312,10 +314,10 @@ __global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ 
   }
   __syncthreads();
   int cb = 0;  // first cell of the batch (everything below is uniform across the workgroup)
-  while (cb < 256 && cs[256] > cs[cb]) {
+  while (cb < kSortCells && cs[kSortCells] > cs[cb]) {
     const int lo = cs[cb];
-    // largest ce in [cb, 256] with cs[ce] - lo <= kSortBatch (cs is non-decreasing)
-    int a = cb, b = 256;
+    // largest ce in [cb, kSortCells] with cs[ce] - lo <= kSortBatch (cs is non-decreasing)
+    int a = cb, b = kSortCells;
     while (a < b) {
       const int m = (a + b + 1) >> 1;
       if (cs[m] - lo <= kSortBatch) a = m; else b = m - 1;
@@ -351,8 +353,19 @@ __global__ void __launch_bounds__(256) k_cell_sort(const unsigned* __restrict__ 
         const int v = stage[i];
         const int be = stage[n + i];
         const int st = be & 0xFFFF, len = (int)((unsigned)be >> 16);
+        // (eight independent reads per round trip: a cell of an un-voxelised cloud holds a hundred points and
+        // more, and one dependent LDS read per comparison left this kernel waiting for latency)
         int rank = 0;
-        for (int k = 0; k < len; k++) rank += (stage[st + k] < v) ? 1 : 0;
+        const int* cellv = stage + st;
+        int k = 0;
+        for (; k + 8 <= len; k += 8) {
+          int u[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) u[q] = cellv[k + q];
+#pragma unroll
+          for (int q = 0; q < 8; q++) rank += (u[q] < v) ? 1 : 0;
+        }
+        for (; k < len; k++) rank += (cellv[k] < v) ? 1 : 0;
         perm[lo + st + rank] = v;  // indices within a cell are distinct: ranks are a permutation
         sorted[lo + st + rank] = xyz[v];
       }
@@ -432,7 +445,7 @@ int launch_grid_frame(ag2_ctx* c, unsigned* cell, unsigned* zeroed_ctl) {
   if (rc) return rc;
   hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, c->stream, c->d_key.as<int2>(), n, cell,
                      c->d_perm.as<int>());
-  hipLaunchKernelGGL(k_cell_sort, dim3((cap + 255) / 256), dim3(256), 0, c->stream, cell, cap,
+  hipLaunchKernelGGL(k_cell_sort, dim3((cap + kSortCells - 1) / kSortCells), dim3(256), 0, c->stream, cell, cap,
                      c->d_perm.as<int>(), c->d_xyz_in.as<float4>(), c->d_sorted.as<float4>());
   AG2_HIP(c, hipGetLastError());
   return 0;
@@ -529,7 +542,7 @@ int build_grid(ag2_ctx* c) {
   if (rc) return rc;
   hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, c->stream, c->d_key.as<int2>(), n, cell,
                      c->d_perm.as<int>());
-  hipLaunchKernelGGL(k_cell_sort, dim3(((int)ncells + 255) / 256), dim3(256), 0, c->stream, cell,
+  hipLaunchKernelGGL(k_cell_sort, dim3(((int)ncells + kSortCells - 1) / kSortCells), dim3(256), 0, c->stream, cell,
                      (int)ncells, c->d_perm.as<int>(), xyz, c->d_sorted.as<float4>());
   AG2_HIP(c, hipGetLastError());
   return 0;
