@@ -36,6 +36,7 @@ struct OrientShared {
   int chunk_cnt[kOMaskChunks][kONW];  // members per (chunk, wave) of a list of several chunks
   int next_w[2];
   long long arena_off;
+  double smp[3];                   // the sample (for the record, which one thread writes at the very end)
   struct {
     struct {
       float px[kOStage], py[kOStage], pz[kOStage];  // the staged chunk: centred coordinates ...
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
       __syncthreads();  // the readers of the chunk that is being replaced are done
 #pragma unroll
       for (int h = 0; h < 2; h++) {  // five loads in flight per thread, twice
+        if (h * kHalf * NT >= clen) break;  // (uniform) a short chunk is all in the first round trip
         float4 v[kHalf];
 #pragma unroll
         for (int k = 0; k < kHalf; k++) v[k] = plist[lslot(c0 + min(tid + (h * kHalf + k) * NT, clen - 1))];
@@ -124,6 +126,13 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     const double* fr = A.frames + (size_t)t * 12;
     // frame = [normal binormal curvature_axis] as columns, hand_search.cpp:325-326
     const double F[3][3] = {{fr[3], fr[6], fr[9]}, {fr[4], fr[7], fr[10]}, {fr[5], fr[8], fr[11]}};
+    // (requested with the frame: read at the record it was one more round trip on the pair's critical path;
+    // S.smp's reader of the previous pair is behind the barrier of next_work)
+    if (tid == 0) {
+      S.smp[0] = fr[0];
+      S.smp[1] = fr[1];
+      S.smp[2] = fr[2];
+    }
     const int nvalid = __popc(hand);
     // rot = [c -s 0; s c 0; 0 0 1], frame_rot = frame * rot, hand_search.cpp:356-357
     const double cs = hc.cos_t[oi], sn = hc.sin_t[oi];
@@ -395,10 +404,21 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     }
     nl = wave_sum_i(nl);
     nr = wave_sum_i(nr);
+    // (a side none of the wave's members lies on has its four extents at their initial values in every lane:
+    // nothing to reduce -- the usual case, and sixteen of this phase's twenty DPP reductions)
+    if (nl > 0) {  // uniform
 #pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-      e[k] = wave_max_d(e[k]);
-      e[k + 1] = wave_min_d(e[k + 1]);
+      for (int k = 0; k < 4; k += 2) {
+        e[k] = wave_max_d(e[k]);
+        e[k + 1] = wave_min_d(e[k + 1]);
+      }
+    }
+    if (nr > 0) {  // uniform
+#pragma unroll
+      for (int k = 4; k < 8; k += 2) {
+        e[k] = wave_max_d(e[k]);
+        e[k + 1] = wave_min_d(e[k + 1]);
+      }
     }
     red_sel ^= 1;
     if (lane == 0) {
@@ -431,7 +451,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
         if (top_y > bot_y && top_z > bot_z) label = 2;
       }
       ag2_hypothesis h;
-      const double smp[3] = {fr[0], fr[1], fr[2]};  // (read here, by the one thread that needs it)
+      const double smp[3] = {S.smp[0], S.smp[1], S.smp[2]};
       const double ys[3] = {surface, bottom, top};
       double* dstv[3] = {h.surface, h.bottom, h.top};
       for (int k = 0; k < 3; k++)                                   // finger_hand.cpp:189-199
