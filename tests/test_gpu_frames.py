@@ -70,6 +70,37 @@ def test_frames_equal_the_stepwise_path(use_graph):
     ds.close()
 
 
+def test_frames_of_a_dense_cloud_use_the_renderers_for_large_images():
+    """An un-voxelised cloud: most images hold more than 1 024 points, so every frame classifies its images
+    by renderer and hands them out through the counters in device memory (k_render_classify, ImgQueue) -- inside
+    the captured sequence the counters are cleared by a memset node of the graph.  Replays must return the
+    bytes of the step-by-step path, and the step-by-step images those of the oracle."""
+    from oracle import api
+    xyz, ws = scene.make_scene(seed=4, n_target=120000, kind="objects", voxel=None)
+    idxs = [scene.draw_samples(40 + k, xyz.shape[0], 120) for k in range(4)]
+    df, ds = _pair(ws, num_orientations=16, min_score_diff=-1e30, num_selected=100000)
+    df.stream_configure(0, 0, True)
+    big = 0
+    for k, idx in enumerate(idxs):
+        got, gn = df.detect_frame(xyz, idx, seed=k)
+        want, wn = _stepwise(ds, xyz, idx, seed=k)
+        assert gn == wn and got.tobytes() == want.tobytes(), k
+        big += int((want["n_points"] > 1024).sum())
+    assert big > 20          # the large-image renderers ran in every mode
+    fi = df.frame_info()
+    assert fi.frames == 4 and fi.graph_replays >= 1 and fi.fallbacks == 0
+    # the images themselves against the oracle (the step path of the last frame)
+    o = api.Oracle(**scene_params(ws, num_orientations=16))
+    o.set_cloud(xyz)
+    o.compute_normals()
+    ho = o.generate_hypotheses(sample_idx=idxs[-1], seed=3)
+    hg = ds.generate_hypotheses(sample_idx=idxs[-1], seed=3)
+    assert hg.tobytes() == ho.tobytes() and int((ho["n_points"] > 1024).sum()) > 5
+    assert np.array_equal(ds.render_images(0, len(ho)), o.render_images(0, len(ho)))
+    df.close()
+    ds.close()
+
+
 def test_frames_everything_selected_and_no_prune():
     """num_selected < 0 keeps every record above the threshold; do_prune off scores every hypothesis."""
     frames = _clouds(4, 12000, 200, kinds=("tabletop", "objects"))
