@@ -272,20 +272,20 @@ __global__ void __launch_bounds__(kImgThreads) k_render(const double* __restrict
 // latency of its largest image: the rank loop, ~15 barriers and a dependent read of its point list).
 struct SparseShared {
   union {
+    unsigned short hist[kImgThreads / kWave][kCells];  // rank phase: points of (wave, cell) so far
     double acc[kSparseMax * 3];
     struct {
       unsigned pix[kCells];
       unsigned char obuf[kCells * 3];
     } img;
   } u;
-  short cid[kSparseMax];
   unsigned short lead[kCells];  // list position of each occupied cell's first point
   double red[kImgThreads / kWave];
   int max_rank;
 };
 static_assert(sizeof(SparseShared) * 4 <= 160 * 1024, "k_render_sparse: four workgroups per CU");
 
-__global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __restrict__ arena,
+__global__ void __launch_bounds__(kImgThreads, 4) k_render_sparse(const double* __restrict__ arena,
                                                                const long long* __restrict__ desc_off,
                                                                const int* __restrict__ desc_cnt,
                                                                int n_img, const unsigned* __restrict__ d_n,
@@ -301,70 +301,72 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
     const double* pts = arena + (size_t)(off >= 0 ? off : 0) * 6;
     __syncthreads();  // previous image's readers of S are done
     const double miny = block_min_y(pts, P, S.red, tid);
+    // Every wave owns a contiguous quarter of the list (seg positions, a multiple of 64), in chunks of 64
+    // consecutive positions: (wave, chunk, lane) order is list order.
+    const int seg = ((P + kImgThreads - 1) / kImgThreads) * kWave, nc = seg / kWave;
+    const int b_first = wave_id() * seg + lane_id();
     double yv[kPer][3];
+    short myc[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
-      const int b = tid + k * kImgThreads;
-      short c = -1;
+      const int b = b_first + k * kWave;
+      myc[k] = -1;
       yv[k][0] = yv[k][1] = yv[k][2] = 0.0;
-      if (b < P) {
+      if (k < nc && b < P) {
         const double* p = pts + (size_t)b * 6;
-        c = cell_id(p[0], p[1], miny);
+        myc[k] = cell_id(p[0], p[1], miny);
         yv[k][0] = p[3]; yv[k][1] = p[4]; yv[k][2] = p[5];
       }
-      S.cid[b] = c;
     }
+    for (int i = tid; i < (kImgThreads / kWave) * kCells / 2; i += kImgThreads)
+      reinterpret_cast<unsigned*>(&S.u.hist[0][0])[i] = 0u;
     if (tid == 0) S.max_rank = 0;
     __syncthreads();
-    // rank of every point among the earlier points of its cell: a count only -- whole groups of eight
-    // ids (one LDS read, the same address in every lane) without any index test, the group that
-    // straddles the point itself masked.  This loop is the renderer's critical path (P^2 / 2 compares
-    // for the largest image, and the kernel lasts as long as its largest image).
+    // Rank of every point among the earlier points of its cell, by COUNTING (round 3; before: every point
+    // compared its cell id with those of all earlier points -- P^2 / 2 compares for the largest image, and the
+    // kernel lasts as long as its largest image).  In a chunk the lanes that share a cell find each other with
+    // twelve ballots (after bit k a lane's mask keeps the lanes whose bit k of the cell id equals its own): the
+    // rank inside the chunk; + the wave's count of the cell so far (u16 per wave and cell) = the rank inside
+    // the wave's quarter; + the totals of the waves in front = the rank.  Data-independent: ~100 instructions
+    // per chunk whatever the cells hold.
+    const unsigned long long lt_mask = (lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()));
     int my_rank[kPer], my_lead[kPer], mx = 0;
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
-      const int b = tid + k * kImgThreads;
       my_rank[k] = -1;  // beyond the list, or a dropped point (:156)
-      my_lead[k] = b;
-      if (b < P) {
-        const int c = S.cid[b];
-        if (c >= 0) {
-          const unsigned short cs = (unsigned short)c;
-          int r = 0, b0 = 0;
-          // two ids per instruction: d = id - own id (wraps; zero iff equal), min(d, 1) is 1 per id that
-          // DIFFERS, summed in two u16 lanes (at most 4 per group and lane, 128 groups: no overflow)
-          const us2 cs2 = as_us2((unsigned)cs | ((unsigned)cs << 16)), one2 = as_us2(0x00010001u);
-          us2 differ = as_us2(0u);
-          for (; b0 + 8 <= b; b0 += 8) {
-            const uint4 w = *reinterpret_cast<const uint4*>(&S.cid[b0]);
-            const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+      my_lead[k] = b_first + k * kWave;
+      if (k < nc) {  // uniform
+        const bool valid = myc[k] >= 0;
+        const int cell = valid ? (int)myc[k] : 0;
+        unsigned long long m = __ballot(valid);
 #pragma unroll
-            for (int j = 0; j < 4; j++) differ += __builtin_elementwise_min((us2)(as_us2(ww[j]) - cs2), one2);
-          }
-          r = b0 - ((int)differ.x + (int)differ.y);
-          if (b0 < b) {
-            const uint4 w = *reinterpret_cast<const uint4*>(&S.cid[b0]);
-            const unsigned ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-              r += ((unsigned short)(ww[j >> 1] >> (16 * (j & 1))) == cs && b0 + j < b) ? 1 : 0;
-          }
-          my_rank[k] = r;
-          mx = max(mx, r);
-          if (r == 0) S.lead[c] = (unsigned short)b;  // the cell's first point: one writer per cell
+        for (int bit = 0; bit < 12; bit++) {
+          const bool mine = (cell >> bit) & 1;
+          const unsigned long long bb = __ballot(mine);
+          m &= mine ? bb : ~bb;
+        }
+        if (valid) {
+          const int before = (int)S.u.hist[wave_id()][cell];
+          my_rank[k] = before + __popcll(m & lt_mask);
+          if ((m >> lane_id()) == 1ull) S.u.hist[wave_id()][cell] = (unsigned short)(before + __popcll(m));
         }
       }
-      if (b < kSparseMax) {  // every leader starts from 0.0 like the reference's running sum
-        S.u.acc[3 * b] = 0.0;
-        S.u.acc[3 * b + 1] = 0.0;
-        S.u.acc[3 * b + 2] = 0.0;
-      }
     }
-    if (mx > 0) atomicMax(&S.max_rank, mx);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kPer; k++)
-      if (my_rank[k] > 0) my_lead[k] = S.lead[S.cid[tid + k * kImgThreads]];
+      if (my_rank[k] >= 0) {
+        for (int w = 0; w < wave_id(); w++) my_rank[k] += (int)S.u.hist[w][myc[k]];
+        mx = max(mx, my_rank[k]);
+        if (my_rank[k] == 0) S.lead[myc[k]] = (unsigned short)(b_first + k * kWave);  // one writer per cell
+      }
+    if (mx > 0) atomicMax(&S.max_rank, mx);
+    __syncthreads();  // the counts are dead: their area becomes the accumulators
+    for (int i = tid; i < kSparseMax * 3; i += kImgThreads) S.u.acc[i] = 0.0;  // every leader starts from 0.0
+#pragma unroll
+    for (int k = 0; k < kPer; k++)
+      if (my_rank[k] > 0) my_lead[k] = S.lead[myc[k]];
+    __syncthreads();
     const int rounds = S.max_rank;
     for (int r = 0; r <= rounds; r++) {  // :166-179, list order within each cell
 #pragma unroll
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
     unsigned qv[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
-      const int b = tid + k * kImgThreads;
+      const int b = b_first + k * kWave;
       qv[k] = (my_rank[k] == 0) ? quantise(S.u.acc[3 * b], S.u.acc[3 * b + 1], S.u.acc[3 * b + 2]) : 0u;
     }
     __syncthreads();
@@ -391,8 +393,7 @@ __global__ void __launch_bounds__(kImgThreads) k_render_sparse(const double* __r
 #pragma unroll
     for (int k = 0; k < kPer; k++)
       if (my_rank[k] == 0) {  // written at (59 - row, col)
-        const int b = tid + k * kImgThreads;
-        const int cell = S.cid[b];
+        const int cell = myc[k];
         const int row = kImg - 1 - cell / kImg, col = cell % kImg;
         S.u.img.pix[row * kImg + col] = qv[k];
       }
