@@ -36,9 +36,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
 #include <vector>
 
 #include "ag2_internal.h"
@@ -50,79 +47,8 @@ namespace ag2 {
 
 }  // namespace ag2
 
-// The copy of a host cloud into the page-locked stage, on the caller's thread and three helpers: one core
-// moves ~10 GB/s, and a 9 MB raw cloud copied by the caller alone was the longest step of a submit (0.7 - 1.1 ms
-// against 0.55 ms of GPU time per cloud with two frames in flight).  The helpers sleep on a condition variable
-// between frames; clouds below 1 MB are copied by the caller.
-class StageCopier {
- public:
-  ~StageCopier() {
-    {
-      std::lock_guard<std::mutex> l(m_);
-      quit_ = true;
-    }
-    go_.notify_all();
-    for (std::thread& t : th_)
-      if (t.joinable()) t.join();
-  }
-  void copy(void* dst, const void* src, size_t bytes) {
-    if (bytes < ((size_t)1 << 20)) {
-      memcpy(dst, src, bytes);
-      return;
-    }
-    if (th_.empty())
-      for (int k = 0; k < kHelpers; k++) th_.emplace_back([this, k] { run(k); });
-    {
-      std::lock_guard<std::mutex> l(m_);
-      dst_ = (char*)dst;
-      src_ = (const char*)src;
-      bytes_ = bytes;
-      pending_ = kHelpers;
-      gen_++;
-    }
-    go_.notify_all();
-    slice(0, (char*)dst, (const char*)src, bytes);
-    std::unique_lock<std::mutex> l(m_);
-    done_.wait(l, [this] { return pending_ == 0; });
-  }
-
- private:
-  static constexpr int kHelpers = 3;
-  static void slice(int part, char* dst, const char* src, size_t bytes) {
-    const size_t per = ((bytes / (kHelpers + 1)) + 4095) & ~(size_t)4095;
-    const size_t a = std::min(bytes, per * (size_t)part), b = (part == kHelpers) ? bytes : std::min(bytes, a + per);
-    if (b > a) memcpy(dst + a, src + a, b - a);
-  }
-  void run(int k) {
-    unsigned long long seen = 0;
-    for (;;) {
-      std::unique_lock<std::mutex> l(m_);
-      go_.wait(l, [&] { return quit_ || gen_ != seen; });
-      if (quit_) return;
-      seen = gen_;
-      char* d = dst_;
-      const char* s = src_;
-      const size_t b = bytes_;
-      l.unlock();
-      slice(k + 1, d, s, b);
-      l.lock();
-      if (--pending_ == 0) done_.notify_one();
-    }
-  }
-  std::vector<std::thread> th_;
-  std::mutex m_;
-  std::condition_variable go_, done_;
-  char* dst_ = nullptr;
-  const char* src_ = nullptr;
-  size_t bytes_ = 0;
-  unsigned long long gen_ = 0;
-  int pending_ = 0;
-  bool quit_ = false;
-};
-
 struct ag2_frame_state {
   bool use_graph = true;
-  StageCopier copier;        // (its helper threads end with the frame state)
   bool shapes_known = false;
   size_t cap_img = 0;        // images rendered / scored per frame at most (learned: a multiple of what the
                              // frames so far needed, in whole batches of 256; at most fm_s_max * R)
@@ -546,7 +472,7 @@ int frame_submit(ag2_ctx* c, const FrameIn& in) {
       f->h_stage_bytes = want;
     }
     AG2_HIP(c, f->d_raw.reserve(bytes));
-    f->copier.copy(f->h_stage, in.xyz, bytes);
+    memcpy(f->h_stage, in.xyz, bytes);
     AG2_HIP(c, hipMemcpyAsync(f->d_raw.p, f->h_stage, bytes, hipMemcpyHostToDevice, c->stream));
     d_xyz = f->d_raw.p;
   }
