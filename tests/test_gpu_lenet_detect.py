@@ -230,6 +230,33 @@ def test_one_round_trip_detect_equals_the_step_by_step_form(small_scene):
     e.close()
 
 
+@pytest.mark.parametrize("num_selected", [5, 64, 1000])
+def test_device_top_k_breaks_ties_by_list_position(small_scene, num_selected):
+    """All-zero weights: every image scores exactly 0.0, so the order of the selection is nothing but the
+    tie rule -- list position, ascending (the step-by-step form's host sort, grasp_detector.cpp:239-252) --
+    in the one-round-trip form (k_topk on the device: ranks from 64-bit keys) as in the step-by-step one.  A second weight set makes every score one of two values (ip2 bias only)."""
+    from agile_grasp2_amd import capi
+    xyz, ws, idx = small_scene
+    w0 = {k: np.zeros_like(v) for k, v in make_lenet_weights(5).items()}
+    for bias in (0.0, 0.5):
+        w = {k: v.copy() for k, v in w0.items()}
+        w["ip2_b"][1] = bias                                  # score = b[1] - b[0] for every image
+        d = capi.Detector(**scene_params(ws, num_selected=num_selected, min_score_diff=0.0))
+        d.set_cloud(xyz)
+        d.compute_normals()
+        d.lenet_load(w)
+        ref_sel, ref_all = d.detect(sample_idx=idx, seed=3, do_prune=False)              # step by step
+        assert len(ref_all) > 70 and np.all(ref_all["score"] == bias)
+        want = ref_all[:min(num_selected, len(ref_all))]                                 # list order
+        assert [(int(r["sample_slot"]), int(r["orientation"])) for r in ref_sel] == \
+            [(int(r["sample_slot"]), int(r["orientation"])) for r in want]
+        for rep in range(2):
+            sel, n_scored = d.detect(sample_idx=idx, seed=3, do_prune=False, want_all=False)  # one round trip
+            assert n_scored == len(ref_all) and sel.tobytes() == ref_sel.tobytes(), (bias, rep)
+        assert d.counters().detect_one_trip == 2
+        d.close()
+
+
 def test_banded_convolutions_equal_the_whole_image_kernel_bit_for_bit(monkeypatch):
     """k_lenet_conv_x3b (default: a third of an image per workgroup, two workgroups per CU) runs every
     output through the same chain of MFMAs in the same k order as k_lenet_conv_x3 (AG2_LENET_WHOLE=1:
