@@ -377,7 +377,11 @@ class Detector:
             ptr, on_dev = C.c_void_p(dptr), 1
         self.n = int(n)
         cap = max(1, len(si) * int(self.params.num_orientations))
-        sel = np.zeros(cap, dtype=HYP_DTYPE)
+        nsel = int(self.params.num_selected)   # (a buffer of the selection's size, kept between calls: as in detect)
+        cap = cap if nsel < 0 else max(1, min(cap, nsel))
+        if getattr(self, "_sel_buf", None) is None or len(self._sel_buf) < cap:
+            self._sel_buf = np.zeros(cap, dtype=HYP_DTYPE)
+        sel = self._sel_buf
         ns, na = C.c_size_t(0), C.c_size_t(0)
         self._ck(self.L.ag2_detect_frame(self.h, ptr, C.c_int(on_dev), C.c_size_t(n), C.c_size_t(stride),
                                          _ptr(si), C.c_size_t(len(si)), C.c_uint64(seed),
