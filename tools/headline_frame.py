@@ -21,7 +21,7 @@ legs = sys.argv[1:] or ["stepwise", "frame_graph", "frame_plain"]
 for name in legs:
     d = capi.Detector(**bench.launch_params(ws, R))
     d.lenet_load(w)
-    d.set_stage_timing(0)
+    d.set_stage_timing(int(os.environ.get("TIMING", "0")))
     if name != "stepwise":
         d.stream_configure(0, 0, name == "frame_graph")
 
