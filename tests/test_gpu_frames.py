@@ -201,6 +201,12 @@ def test_raw_frames_equal_the_oracle_and_the_stepwise_path(use_graph):
     from agile_grasp2_amd import capi
     from oracle import api
     raws, ws0 = scene.make_stream(40, 50000, 6, voxel=None)   # one scene, its objects drifting
+    # what a depth sensor delivers besides points: NaN where a pixel has no return, now and then an infinity --
+    # in every frame at other places, so that the replayed sequence meets them where the captured one had points
+    for k, r in enumerate(raws):
+        r[3 + k::97, k % 3] = np.nan
+        r[11 + 2 * k::389] = np.inf
+        r[17 + k::1013, (k + 1) % 3] = -np.inf
     frames = [(r, ws0) for r in raws]
     ws = np.array(ws0, dtype=np.float64)
     ws[1] -= 0.03   # the workspace filter has something to cut (a strip of the table)
