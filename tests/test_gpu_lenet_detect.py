@@ -6,6 +6,8 @@ separate mul/add, K permuted for the LDS layout): |diff| <= 1e-4 * max|logit| + 
 tolerance the oracle itself is pinned to torch with.  Selection: the set and order of selected
 hypotheses must be identical; scores within the same tolerance.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -224,7 +226,8 @@ def test_one_round_trip_detect_equals_the_step_by_step_form(small_scene):
     # the counters say which form served the calls: bare #2 in one trip; busy #1 launched at the bare
     # table's shapes (256 images), found > 300 and ran again; busy #2 in one trip at the new shapes
     cd, ce = d.counters(), e.counters()
-    assert (cd.detect_one_trip, cd.detect_redone) == (2, 1), (cd.detect_one_trip, cd.detect_redone)
+    if not os.environ.get("AG2_DETECT_STEPWISE"):   # (the A/B switch keeps every call step by step)
+        assert (cd.detect_one_trip, cd.detect_redone) == (2, 1), (cd.detect_one_trip, cd.detect_redone)
     assert (ce.detect_one_trip, ce.detect_redone) == (0, 0)
     d.close()
     e.close()
@@ -253,7 +256,7 @@ def test_device_top_k_breaks_ties_by_list_position(small_scene, num_selected):
         for rep in range(2):
             sel, n_scored = d.detect(sample_idx=idx, seed=3, do_prune=False, want_all=False)  # one round trip
             assert n_scored == len(ref_all) and sel.tobytes() == ref_sel.tobytes(), (bias, rep)
-        assert d.counters().detect_one_trip == 2
+        assert d.counters().detect_one_trip == (0 if os.environ.get("AG2_DETECT_STEPWISE") else 2)
         d.close()
 
 
