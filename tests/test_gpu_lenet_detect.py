@@ -260,6 +260,33 @@ def test_device_top_k_breaks_ties_by_list_position(small_scene, num_selected):
         d.close()
 
 
+def test_detect_with_more_than_8192_scored_images():
+    """Beyond 8 192 scored images the threshold / compaction runs as flags + chained scan + gather instead of
+    the one-workgroup kernel, and beyond 4 096 selected records the device top-k leaves its key stage for the
+    general compare loop (k_score_flags, k_gather_selected, k_topk / host sort): the selection must be the
+    scored list filtered by the threshold and stably sorted by score (grasp_detector.cpp:200-252)."""
+    from agile_grasp2_amd import capi
+    xyz, ws = scene.make_scene(seed=5, n_target=250000, kind="tabletop", voxel=None)
+    idx = scene.draw_samples(5, xyz.shape[0], 6000)
+    w = make_lenet_weights(5)
+    for nsel, thr in ((200, 0.0), (6000, -1e30)):
+        d = capi.Detector(**scene_params(ws, num_orientations=16, min_score_diff=thr, num_selected=nsel))
+        d.set_cloud(xyz)
+        d.compute_normals()
+        d.lenet_load(w)
+        sel, allh = d.detect(sample_idx=idx, seed=1, do_prune=False)
+        assert len(allh) > 8192, len(allh)
+        passing = allh[allh["score"] >= thr]
+        assert len(passing) > (4096 if thr < 0 else 1000)
+        want = passing[np.argsort(-passing["score"], kind="stable")][:nsel].copy()
+        want["full_antipodal"] = 1                      # grasp_detector.cpp:205
+        assert len(sel) == len(want) and sel.tobytes() == want.tobytes(), nsel
+        # the same without the list of all scored records (the device picks the top-k where it can)
+        sel2, n2 = d.detect(sample_idx=idx, seed=1, do_prune=False, want_all=False)
+        assert n2 == len(allh) and sel2.tobytes() == sel.tobytes(), nsel
+        d.close()
+
+
 def test_banded_convolutions_equal_the_whole_image_kernel_bit_for_bit(monkeypatch):
     """k_lenet_conv_x3b (default: a third of an image per workgroup, two workgroups per CU) runs every
     output through the same chain of MFMAs in the same k order as k_lenet_conv_x3 (AG2_LENET_WHOLE=1:
