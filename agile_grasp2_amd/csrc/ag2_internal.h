@@ -367,7 +367,6 @@ int launch_lenet_fc1_x3(ag2_ctx* c, size_t n, int* n_pad_out, int* ksplit_out,
 // k_cluster.hip
 int cluster_async(ag2_ctx* c, const ag2_hypothesis* d_in, size_t n_max, const unsigned* d_n,
                   int min_inliers, unsigned* d_count);
-int launch_scatter_scores(ag2_ctx* c, const int* d_list, size_t n_img);
 // k_image.hip
 int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, const int* d_cnt,
                   size_t n_img, uint8_t* d_out, int max_p, const unsigned* d_n = nullptr);

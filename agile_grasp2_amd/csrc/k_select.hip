@@ -388,18 +388,6 @@ __global__ void k_image_descs(const ag2_hypothesis* __restrict__ table,
   desc_cnt[i] = table[s].n_points;
 }
 
-// score = ip2[1] - ip2[0] (grasp_detector.cpp:200), written back into the table slot; keep := 2
-// marks "scored".
-__global__ void k_scatter_scores(const float* __restrict__ logits, const int* __restrict__ list,
-                                 int n, ag2_hypothesis* __restrict__ table,
-                                 unsigned char* __restrict__ keep) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int s = list[i];
-  const float sc = logits[2 * i + 1] - logits[2 * i];
-  table[s].score = (double)sc;
-  keep[s] = 2;
-}
 
 __global__ void k_gather_records(const ag2_hypothesis* __restrict__ table,
                                  const long long* __restrict__ tab_off,
@@ -603,13 +591,5 @@ int make_image_descs(ag2_ctx* c, const int* d_list, size_t n) {
   return 0;
 }
 
-int launch_scatter_scores(ag2_ctx* c, const int* d_list, size_t n_img) {
-  if (n_img == 0) return 0;
-  hipLaunchKernelGGL(k_scatter_scores, dim3(((int)n_img + 255) / 256), dim3(256), 0, c->stream,
-                     c->d_logits.as<float>(), d_list, (int)n_img, c->d_table.as<ag2_hypothesis>(),
-                     c->d_tab_keep.as<unsigned char>());
-  AG2_HIP(c, hipGetLastError());
-  return 0;
-}
 
 }  // namespace ag2

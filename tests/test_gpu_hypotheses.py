@@ -132,6 +132,31 @@ def test_sixteen_orientations_filter_half(small_scene):
     d.close()
 
 
+@pytest.mark.parametrize("n_orient", [20, 32])
+def test_more_than_sixteen_orientations(small_scene, n_orient):
+    """17 .. 32 orientations run the sweep kernels' third instantiation (k_sweep<0, 32> / <1, 32>: per-orientation
+    state in 32 register slots), on the LDS stage (the voxelised small scene) and on the long-list stage
+    (a dense un-voxelised cloud)."""
+    xyz, ws, idx = small_scene
+    o, d = make_pair(xyz, ws, num_orientations=n_orient)
+    got = d.generate_hypotheses(sample_idx=idx, seed=11)
+    want = o.generate_hypotheses(sample_idx=idx, seed=11)
+    assert len(want) > 10 and want["orientation"].max() >= 16
+    assert_hyps_equal(got, want)
+    assert got.tobytes() == want.tobytes()
+    check_lists_and_images(o, d, want)
+    d.close()
+    dense, wsd = scene.make_scene(seed=4, n_target=120000, kind="objects", voxel=None)
+    idd = scene.draw_samples(4, dense.shape[0], 40)
+    o, d = make_pair(dense, wsd, num_orientations=n_orient)
+    got = d.generate_hypotheses(sample_idx=idd, seed=12)
+    want = o.generate_hypotheses(sample_idx=idd, seed=12)
+    assert d.counters().n_overflow_samples > 0
+    assert_hyps_equal(got, want)
+    assert got.tobytes() == want.tobytes()
+    d.close()
+
+
 def test_config1_scene_500_samples():
     """BASELINE config 1 size: ~50k points, 500 samples, 8 orientations."""
     xyz, ws = scene.make_scene(seed=21, n_target=50000)
