@@ -32,7 +32,7 @@ struct FrameArgs {
   unsigned long long seed;
   unsigned long long slot_base;
   unsigned long long sample_seed;  // ag2_detect_frame_raw: seed of the uniform sub-sampling
-  unsigned long long pad;
+  unsigned long long seq;          // the frame's sequence number: k_topk writes it behind the results (FrameOut::done_seq)
 };
 
 // Per-context constants, built on the host (ag2_context.hip derive_constants) and read through a

@@ -36,6 +36,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "ag2_internal.h"
@@ -88,6 +89,7 @@ struct ag2_frame_state {
     std::vector<ag2_hypothesis> recs;
     size_t n_selected = 0, n_scored = 0, n_voxels = 0;
   } pend;
+  unsigned seq = 0;              // sequence number of the last frame enqueued at fixed shapes (FrameArgs::seq)
   char* h_stage = nullptr;       // page-locked staging of a cloud handed over in host memory (true async H2D)
   size_t h_stage_bytes = 0;
 };
@@ -104,9 +106,11 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
                                                        const unsigned* __restrict__ d_n, int cap,
                                                        int k_want, int k_cap,
                                                        ag2_hypothesis* __restrict__ out, FrameOut* fo,
-                                                       const DevStats* __restrict__ st,
+                                                       DevStats* __restrict__ st,
                                                        const GridDesc* __restrict__ gp,
-                                                       const PreFrame* __restrict__ pfp) {
+                                                       const PreFrame* __restrict__ pfp, unsigned seq,
+                                                       unsigned* done_flag, const FrameArgs* __restrict__ fa) {
+  if (fa) seq = (unsigned)fa->seq;  // frame mode: the sequence number of THIS replay (the argument is frozen in the graph)
   // out / fo: page-locked host memory seen through its device view -- the last kernel of a frame
   // writes the results where the host reads them, no copy operation follows
   __shared__ double sc[kTopkThreads];
@@ -120,8 +124,25 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
     if (pfp) fo->pre = *pfp;
   }
   k = min(k, k_cap);
+  // Every workgroup reports when its writes into host memory are out; the last one writes the call's sequence
+  // number behind them (page-locked memory), which the host may poll instead of waiting for the stream
+  // (wait_topk).
+  auto report = [&]() {
+    if (!done_flag) return;  // uniform
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      if (atomicAdd(&st->topk_blocks, 1u) == gridDim.x - 1u) {
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned*>(done_flag) = seq;
+      }
+    }
+  };
   const int base = blockIdx.x * kTopkThreads;
-  if (base >= n) return;  // uniform
+  if (base >= n) {  // uniform
+    report();
+    return;
+  }
   const int i = base + threadIdx.x;
   __shared__ unsigned long long keys[kRankKeys];
   __shared__ int inexact;
@@ -146,13 +167,46 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
     }
   }
   if (i < n && rank < k) out[rank] = recs[i];
+  report();
+}
+
+// Polling returns ~10 us earlier than the runtime's wait for the kernel's completion signal (the results
+// behind which the flag sits are in host memory by then; two such waits per detect step: 0.713 -> 0.692 ms).
+// After 5 ms of polling the stream is waited for the ordinary way (long runs do not spin on a core); AG2_POLL=0
+// turns the polling off.
+int wait_flag(ag2_ctx* c, size_t flag_off, unsigned want) {
+  if (!c->h_pin_dev) {
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  return wait_flag_at(c, reinterpret_cast<const volatile unsigned*>(pin_small(c) + flag_off), want);
+}
+int wait_flag_at(ag2_ctx* c, const volatile unsigned* flag, unsigned want) {
+  static const bool poll = [] { const char* e = getenv("AG2_POLL"); return !e || atoi(e) != 0; }();
+  if (poll && flag) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      for (int spin = 0; spin < 2048; spin++) {
+        if (*flag == want) {
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
+          return 0;
+        }
+        __builtin_ia32_pause();
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+    }
+  }
+  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 int launch_topk(ag2_ctx* c, const ag2_hypothesis* d_recs, const unsigned* d_n, size_t cap, size_t k_cap,
                 ag2_hypothesis* d_out, FrameOut* d_fo, const GridDesc* gp, const PreFrame* pfp) {
   hipLaunchKernelGGL(k_topk, dim3((unsigned)((std::max<size_t>(cap, 1) + kTopkThreads - 1) / kTopkThreads)),
                      dim3(kTopkThreads), 0, c->stream, d_recs, d_n, (int)cap, c->p.num_selected, (int)k_cap, d_out,
-                     d_fo, c->d_stats.as<DevStats>(), gp, pfp);
+                     d_fo, c->d_stats.as<DevStats>(), gp, pfp, (++c->topk_seq == 0u ? ++c->topk_seq : c->topk_seq),
+                     c->h_pin_dev ? reinterpret_cast<unsigned*>(pin_small_dev(c) + kPinDoneFlag) : (unsigned*)nullptr,
+                     (const FrameArgs*)nullptr);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
@@ -164,16 +218,24 @@ int frame_pin_reserve(ag2_ctx* c, ag2_frame_state* f) {
   const size_t off_out = (off_idx + c->fm_s_max * 4 + 63) & ~size_t(63);
   const size_t off_rec = (off_out + sizeof(FrameOut) + 63) & ~size_t(63);
   const size_t need = off_rec + f->k_cap * sizeof(ag2_hypothesis) + 64;
+  const bool moved = off_out != f->off_out;
   f->off_idx = off_idx;
   f->off_out = off_out;
   f->off_rec = off_rec;
-  if (need <= f->h_pin_bytes) return 0;
+  if (need <= f->h_pin_bytes) {
+    if (moved) {  // the results' place holds something else: below every sequence number before it is polled
+      AG2_HIP(c, hipStreamSynchronize(c->stream));
+      reinterpret_cast<FrameOut*>(f->h_pin + off_out)->done_seq = 0u;
+    }
+    return 0;
+  }
   AG2_HIP(c, hipStreamSynchronize(c->stream));
   if (f->h_pin) (void)hipHostFree(f->h_pin);
   f->h_pin = nullptr;
   f->h_pin_bytes = 0;
   AG2_HIP(c, hipHostMalloc((void**)&f->h_pin, need, hipHostMallocDefault));
   f->h_pin_bytes = need;
+  reinterpret_cast<FrameOut*>(f->h_pin + off_out)->done_seq = 0u;
   void* dv = nullptr;
   AG2_HIP(c, hipHostGetDevicePointer(&dv, f->h_pin, 0));
   c->fm_args_dev = (const FrameArgs*)dv;
@@ -300,7 +362,8 @@ int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
   hipLaunchKernelGGL(k_topk, dim3((unsigned)((cap_img + kTopkThreads - 1) / kTopkThreads)), dim3(kTopkThreads), 0,
                      c->stream, c->d_sel.as<ag2_hypothesis>(), &st->n_sel, (int)cap_img, c->p.num_selected,
                      (int)f->k_cap, d_rec, d_fo, st, gp,
-                     f->raw ? c->d_preframe.as<PreFrame>() : (const PreFrame*)nullptr);
+                     f->raw ? c->d_preframe.as<PreFrame>() : (const PreFrame*)nullptr, 0u, &d_fo->done_seq,
+                     c->fm_args_dev);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
@@ -526,6 +589,8 @@ int frame_submit(ag2_ctx* c, const FrameIn& in) {
   fa->seed = in.seed;
   fa->slot_base = 0;
   fa->sample_seed = in.sample_seed;
+  if (++f->seq == 0u) f->seq = 1u;  // (zero is what the flag starts from)
+  fa->seq = f->seq;
   if (!in.raw) {
     int32_t* hidx = (int32_t*)(f->h_pin + f->off_idx);
     memcpy(hidx, in.sample_idx, in.s * 4);
@@ -562,11 +627,11 @@ int frame_wait(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selec
   const int R = c->p.num_orientations;
   if (!p.finished) {
     const FrameIn in = pending_in(p);
-    if (hipStreamSynchronize(c->stream) != hipSuccess) {
-      p.active = false;
-      return set_err(c, AG2_ERR_HIP, "frame: hipStreamSynchronize failed");
-    }
     const FrameOut* fo = (const FrameOut*)(f->h_pin + f->off_out);
+    if (wait_flag_at(c, &fo->done_seq, f->seq) != 0) {  // (k_topk's flag behind the results, then the stream)
+      p.active = false;
+      return AG2_ERR_HIP;
+    }
     const unsigned flags = fo->st.err_flags;
     const bool bad = (flags & (1u | 2u | 8u)) != 0 || fo->g.ncells < 0 || fo->topk_overflow != 0 ||
                      (size_t)fo->st.n_list > std::min(f->cap_img, c->fm_s_max * (size_t)R) ||
@@ -600,6 +665,7 @@ int frame_wait(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selec
           const unsigned long long sig0 = frame_signature(c, f);
           const int lvl = c->stage_timing;
           c->stage_timing = 0;
+          (void)hipStreamSynchronize(c->stream);  // (the results were polled for: let the runtime see the stream idle)
           hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
           int rc2 = (e == hipSuccess) ? enqueue_frame(c, f, in.do_prune) : AG2_ERR_HIP;
           hipGraph_t g = nullptr;

@@ -52,6 +52,7 @@ struct DevStats {
   alignas(128) unsigned int n_pairs;          // split sweep: (sample, orientation) pairs queued for k_sweep_orient
   alignas(128) unsigned int n_overflow;       // samples handed on to the long-list stage
   alignas(128) unsigned int work_next[3];     // k_sweep work queues, one per stage (items beyond the first grid)
+  unsigned int topk_blocks;                   // k_topk: workgroups that have written their part (the last one writes the done flag)
   // --- per cloud (zeroed by k_init_stats when the grid is rebuilt) ---
   alignas(128) unsigned int bounds[7];        // ordered-int min xyz, max xyz, n_valid
   unsigned int pad1;
@@ -202,6 +203,9 @@ struct ag2_ctx {
   size_t list_ints = 0;    // capacity of d_lists in points; grown on demand like the arena
   int sweep_gcap = 1 << 16;  // points per workgroup of that scratch; grows to the longest list met
   int sweep_g2 = 1024;       // workgroups of the stage that uses it
+  unsigned bounds_seq = 0;   // ... of the last k_bounds launch that wrote its partials into the small area
+  ag2::DevBuf d_donectr;     // workgroup counter of that k_bounds (self-resetting)
+  unsigned topk_seq = 0;     // sequence number of the last k_topk launch (the done flag in the page-locked small area)
   int sweep_gpos_cap = 0;    // longest list the sweep's first stage keeps (k_sweep.hip: kGposCap / kGposCapBig, adaptive)
   ag2::DevBuf d_list;      // int compacted slot ids (hypotheses in order)
   ag2::DevBuf d_list2;     // int compacted slot ids after prune / for scoring
@@ -270,7 +274,10 @@ int collect_normals_stats(ag2_ctx* c);
 int after_cloud(ag2_ctx* c);
 // page-locked staging of at least `bytes` (+ kPinSmall bytes in front for small read-backs); growing
 // synchronises the stream first.  Layout: [0, kPinSmall) small area, [kPinSmall, ...) bulk area.
-constexpr size_t kPinSmall = 4096;
+constexpr size_t kPinSmall = 8192;
+// offsets in the small area of the sequence numbers a kernel's last workgroup writes behind its results for the
+// host to poll (wait_flag): k_topk's, k_bounds'
+constexpr size_t kPinDoneFlag = 4096, kPinBoundsFlag = 4096 + 64;
 int pin_reserve(ag2_ctx* c, size_t bulk_bytes);
 inline char* pin_small(ag2_ctx* c) { return (char*)c->h_pin; }
 inline char* pin_bulk(ag2_ctx* c) { return (char*)c->h_pin + kPinSmall; }
@@ -337,10 +344,16 @@ struct FrameOut {
   unsigned n_out;  // records that follow (top-k)
   unsigned topk_overflow;
   PreFrame pre;    // ag2_detect_frame_raw: what the front end of the frame found (voxels, flags)
+  unsigned done_seq;  // frame mode: FrameArgs::seq, written last by the last workgroup of k_topk (frame_wait polls it)
 };
 // ag2_frame.hip: top num_selected of d_recs[0 .. min(*d_n, cap)) by (score desc, position asc) -> d_out, *d_fo
 int launch_topk(ag2_ctx* c, const ag2_hypothesis* d_recs, const unsigned* d_n, size_t cap, size_t k_cap,
                 ag2_hypothesis* d_out, FrameOut* d_fo, const GridDesc* gp, const PreFrame* pfp = nullptr);
+// waits until the word at flag_off of the page-locked small area holds `want` (a kernel's last workgroup writes
+// it behind the kernel's results), polling for up to ~2 ms, then for the stream the ordinary way
+int wait_flag(ag2_ctx* c, size_t flag_off, unsigned want);
+int wait_flag_at(ag2_ctx* c, const volatile unsigned* flag, unsigned want);  // the same for a word anywhere in page-locked memory
+inline int wait_topk(ag2_ctx* c) { return wait_flag(c, kPinDoneFlag, c->topk_seq); }
 int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool run_cleared = false);
 void sweep_adapt_gpos(ag2_ctx* c, size_t n_samples, size_t n_overflow);
 int launch_hyp_stats(ag2_ctx* c, size_t n_slots);  // k_sweep_orient.hip: n_hyp, sum_p, max_p from the slot table

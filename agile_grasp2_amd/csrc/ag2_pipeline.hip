@@ -203,7 +203,13 @@ int detect_speculative(ag2_ctx* c, const int32_t* sample_idx, const double* samp
   rc = launch_topk(c, c->d_sel.as<ag2_hypothesis>(), &st->n_sel, cap_img, k_cap, d_rec, d_fo, nullptr);
   if (rc) return rc;
   AG2_HIP(c, stage_event(c, 7));
-  AG2_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->stage_timing >= 2) {  // (event 7 is behind k_topk: wait for the stream)
+    AG2_HIP(c, hipStreamSynchronize(c->stream));
+  } else {
+    rc = wait_topk(c);
+    if (rc) return rc;
+    if (c->stage_timing == 1) AG2_HIP(c, stage_sync(c, 11));  // (long complete; the runtime takes note of it)
+  }
   FrameOut fo;
   memcpy(&fo, pin_bulk(c), sizeof(FrameOut));
   const DevStats& hs = fo.st;

@@ -42,7 +42,8 @@ static_assert(kBoundsBlocks * 32 <= (int)kPinSmall, "extent partials must fit th
 template <bool PACK>
 __global__ void __launch_bounds__(256) k_bounds(const char* __restrict__ src, size_t stride,
                                                 float4* __restrict__ xyz, int n, int n_pad,
-                                                int* __restrict__ part, DevStats* st) {
+                                                int* __restrict__ part, DevStats* st,
+                                                unsigned* done_ctr, unsigned* done_flag, unsigned seq) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *st = DevStats{};
   int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
   int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
@@ -97,6 +98,19 @@ __global__ void __launch_bounds__(256) k_bounds(const char* __restrict__ src, si
       v = (k < 3) ? min(v, o) : (k < 6 ? max(v, o) : v + o);
     }
     part[blockIdx.x * 8 + k] = v;
+  }
+  // partials in page-locked memory: the last workgroup writes the call's sequence number behind them, which the
+  // host polls instead of waiting for the stream (wait_flag); the counter is left at zero for the next launch
+  if (done_flag) {  // uniform
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      if (atomicAdd(done_ctr, 1u) == gridDim.x - 1u) {
+        *done_ctr = 0u;
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned*>(done_flag) = seq;
+      }
+    }
   }
 }
 
@@ -412,8 +426,20 @@ int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes
         c->bounds_in_pin = true;
       }
     }
+    unsigned* ctr = nullptr;
+    unsigned* flag = nullptr;
+    if (c->bounds_in_pin) {
+      if (!c->d_donectr.p) {
+        AG2_HIP(c, c->d_donectr.reserve(64));
+        AG2_HIP(c, hipMemsetAsync(c->d_donectr.p, 0, 64, c->stream));
+      }
+      ctr = c->d_donectr.as<unsigned>();
+      flag = reinterpret_cast<unsigned*>(pin_small_dev(c) + kPinBoundsFlag);
+      if (++c->bounds_seq == 0u) c->bounds_seq = 1u;  // (zero is what the flag starts from)
+    }
     hipLaunchKernelGGL(k_bounds<true>, dim3(nb), dim3(256), 0, c->stream, (const char*)d_xyz,
-                       stride_bytes, dst, (int)n, (int)n_pad, part, c->d_stats.as<DevStats>());
+                       stride_bytes, dst, (int)n, (int)n_pad, part, c->d_stats.as<DevStats>(), ctr, flag,
+                       c->bounds_seq);
     c->bounds_blocks = nb;
   } else {
     hipLaunchKernelGGL(k_pack_xyz, dim3(((int)n + 255) / 256), dim3(256), 0, c->stream,
@@ -480,13 +506,18 @@ int build_grid(ag2_ctx* c) {
       nb = std::min((n + 255) / 256, kBoundsBlocks);
       AG2_HIP(c, c->d_bounds.reserve((size_t)kBoundsBlocks * 8 * 4));
       hipLaunchKernelGGL(k_bounds<false>, dim3(nb), dim3(256), 0, c->stream, (const char*)nullptr,
-                         (size_t)0, c->d_xyz_in.as<float4>(), n, n, c->d_bounds.as<int>(), st);
+                         (size_t)0, c->d_xyz_in.as<float4>(), n, n, c->d_bounds.as<int>(), st, (unsigned*)nullptr,
+                         (unsigned*)nullptr, 0u);
     }
-    if (!(packed_blocks && c->bounds_in_pin))  // (else the pack kernel wrote them into pin_small itself)
+    if (packed_blocks && c->bounds_in_pin) {  // the pack kernel wrote them into pin_small itself, its flag behind them
+      const int rcw = wait_flag(c, kPinBoundsFlag, c->bounds_seq);
+      if (rcw) return rcw;
+    } else {
       AG2_HIP(c, hipMemcpyAsync(pin_small(c), c->d_bounds.p, (size_t)nb * 32, hipMemcpyDeviceToHost,
                                 c->stream));
+      AG2_HIP(c, hipStreamSynchronize(c->stream));
+    }
     c->bounds_in_pin = false;
-    AG2_HIP(c, hipStreamSynchronize(c->stream));
     const int* part = (const int*)pin_small(c);
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
     int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
