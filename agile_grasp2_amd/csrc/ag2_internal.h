@@ -203,6 +203,9 @@ struct ag2_ctx {
   size_t list_ints = 0;    // capacity of d_lists in points; grown on demand like the arena
   int sweep_gcap = 1 << 16;  // points per workgroup of that scratch; grows to the longest list met
   int sweep_g2 = 1024;       // workgroups of the stage that uses it
+  size_t cell_bytes_last = 0;     // bytes of d_cell the last grid build cleared (counters + scan control words)
+  size_t cell_bytes_prezeroed = 0;  // ... and how many the pack of the CURRENT cloud has cleared ahead of its grid build
+  const void* cell_prezeroed_at = nullptr;
   unsigned bounds_seq = 0;   // ... of the last k_bounds launch that wrote its partials into the small area
   ag2::DevBuf d_donectr;     // workgroup counter of that k_bounds (self-resetting)
   unsigned topk_seq = 0;     // sequence number of the last k_topk launch (the done flag in the page-locked small area)
