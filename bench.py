@@ -460,11 +460,16 @@ def main():
         step()
     sync()
     acc_sweep = [0.0, 0.0]
+    # (only the sweep's events are recorded in here; the stage times are read into ONE preallocated record
+    # through the bare C call: building a ctypes structure per step was ~5 us of idle GPU between steps)
+    import ctypes
+    t = capi.Times()
+    read_times, t_ref = d.L.ag2_get_stage_times, ctypes.byref(t)
     t0 = time.perf_counter()
     scored = 0
     for _ in range(args.steps):
         scored += step()
-        t = d.times()  # (only the sweep's events are recorded in here: two reads, no loop over the fields)
+        read_times(d.h, t_ref)
         acc_sweep[0] += t.sweep_ms
         acc_sweep[1] += t.sweep_overflow_ms
     sync()
