@@ -206,6 +206,8 @@ struct ag2_ctx {
   size_t cell_bytes_last = 0;     // bytes of d_cell the last grid build cleared (counters + scan control words)
   size_t cell_bytes_prezeroed = 0;  // ... and how many the pack of the CURRENT cloud has cleared ahead of its grid build
   const void* cell_prezeroed_at = nullptr;
+  int cell_count_ahead_cap = 0;   // > 0: pack_device_xyz also queued k_cell_count (grid derived on the device from the
+                                  // extent partials) for grids of at most this many cells; build_grid skips its own
   unsigned bounds_seq = 0;   // ... of the last k_bounds launch that wrote its partials into the small area
   ag2::DevBuf d_donectr;     // workgroup counter of that k_bounds (self-resetting)
   unsigned topk_seq = 0;     // sequence number of the last k_topk launch (the done flag in the page-locked small area)
