@@ -245,7 +245,7 @@ void ag2_destroy(ag2_ctx* c) {
                     &c->d_overflow, &c->d_gscratch, &c->d_list, &c->d_list2, &c->d_images,
                     &c->d_logits, &c->d_act1, &c->d_fcpart, &c->d_tmp, &c->d_sel, &c->d_merge, &c->d_gather, &c->d_xchg, &c->d_flags, &c->d_desc,
                     &c->d_raw, &c->d_raw_nrm, &c->d_pre, &c->d_pflags, &c->d_bitmap, &c->d_wrank,
-                    &c->d_first, &c->d_prestats, &c->d_hist, &c->d_samples, &c->d_preframe, &c->d_cand, &c->d_cluster, &c->d_cluster_tmp, &c->d_rlist, &c->d_donectr, &c->net.w1p, &c->net.b1,
+                    &c->d_first, &c->d_prestats, &c->d_hist, &c->d_samples, &c->d_preframe, &c->d_cand, &c->d_cluster, &c->d_cluster_tmp, &c->d_rlist, &c->net.w1p, &c->net.b1,
                     &c->net.w2p, &c->net.b2, &c->net.w3p, &c->net.b3, &c->net.w4, &c->net.b4,
                     &c->net.w1x, &c->net.w2x, &c->net.w3x};
   for (DevBuf* b : bufs) b->release();

@@ -596,7 +596,7 @@ int frame_submit(ag2_ctx* c, const FrameIn& in) {
     memcpy(hidx, in.sample_idx, in.s * 4);
     for (size_t i = in.s; i < c->fm_s_max; i++) hidx[i] = -1;
   }
-  if (c->d_xyz_in.reserve(c->fm_n_max * 16) != hipSuccess || c->d_bounds.reserve((size_t)128 * 8 * 4) != hipSuccess ||
+  if (c->d_xyz_in.reserve(c->fm_n_max * 16) != hipSuccess || c->d_bounds.reserve((size_t)kBoundsBlocks * 8 * 4) != hipSuccess ||
       c->d_griddesc.reserve(sizeof(GridDesc)) != hipSuccess)
     return fail(set_err(c, AG2_ERR_HIP, "frame: device allocation failed"));
   if (in.raw) rc = front_pack_raw(c, d_xyz, n, in.stride, f->fs);

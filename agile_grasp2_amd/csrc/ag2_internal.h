@@ -208,8 +208,8 @@ struct ag2_ctx {
   const void* cell_prezeroed_at = nullptr;
   int cell_count_ahead_cap = 0;   // > 0: pack_device_xyz also queued k_cell_count (grid derived on the device from the
                                   // extent partials) for grids of at most this many cells; build_grid skips its own
-  unsigned bounds_seq = 0;   // ... of the last k_bounds launch that wrote its partials into the small area
-  ag2::DevBuf d_donectr;     // workgroup counter of that k_bounds (self-resetting)
+  unsigned bounds_seq = 0;   // ... of the last extent pass whose follower raises the flag in the small area
+  bool bounds_flag_armed = false;
   unsigned topk_seq = 0;     // sequence number of the last k_topk launch (the done flag in the page-locked small area)
   int sweep_gpos_cap = 0;    // longest list the sweep's first stage keeps (k_sweep.hip: kGposCap / kGposCapBig, adaptive)
   ag2::DevBuf d_list;      // int compacted slot ids (hypotheses in order)
@@ -279,10 +279,10 @@ int collect_normals_stats(ag2_ctx* c);
 int after_cloud(ag2_ctx* c);
 // page-locked staging of at least `bytes` (+ kPinSmall bytes in front for small read-backs); growing
 // synchronises the stream first.  Layout: [0, kPinSmall) small area, [kPinSmall, ...) bulk area.
-constexpr size_t kPinSmall = 8192;
+constexpr size_t kPinSmall = 20480;
 // offsets in the small area of the sequence numbers a kernel's last workgroup writes behind its results for the
 // host to poll (wait_flag): k_topk's, k_bounds'
-constexpr size_t kPinDoneFlag = 4096, kPinBoundsFlag = 4096 + 64;
+constexpr size_t kPinDoneFlag = 16384, kPinBoundsFlag = 16384 + 64;  // (the first 16 KB: the extent partials)
 int pin_reserve(ag2_ctx* c, size_t bulk_bytes);
 inline char* pin_small(ag2_ctx* c) { return (char*)c->h_pin; }
 inline char* pin_bulk(ag2_ctx* c) { return (char*)c->h_pin + kPinSmall; }
@@ -356,6 +356,7 @@ int launch_topk(ag2_ctx* c, const ag2_hypothesis* d_recs, const unsigned* d_n, s
                 ag2_hypothesis* d_out, FrameOut* d_fo, const GridDesc* gp, const PreFrame* pfp = nullptr);
 // waits until the word at flag_off of the page-locked small area holds `want` (a kernel's last workgroup writes
 // it behind the kernel's results), polling for up to ~2 ms, then for the stream the ordinary way
+constexpr int kBoundsBlocks = 128;  // workgroups of the extent pass = 32-byte records of partials (4 KB)
 int wait_flag(ag2_ctx* c, size_t flag_off, unsigned want);
 int wait_flag_at(ag2_ctx* c, const volatile unsigned* flag, unsigned want);  // the same for a word anywhere in page-locked memory
 inline int wait_topk(ag2_ctx* c) { return wait_flag(c, kPinDoneFlag, c->topk_seq); }

@@ -35,17 +35,19 @@ __global__ void k_pack_xyz(const char* __restrict__ src, size_t stride, int n,
 // writes ONE partial record (min xyz, max xyz as order-preserving ints, count) that the host reduces
 // after the read-back it needs anyway -- no atomics, nothing to initialise.  Block 0 also clears the
 // device statistics of the previous cloud.
-constexpr int kBoundsBlocks = 128;  // 128 records x 32 B = the small page-locked read-back area
-static_assert(kBoundsBlocks * 32 <= (int)kPinSmall, "extent partials must fit the small read-back area");
+static_assert(kBoundsBlocks * 32 <= (int)kPinDoneFlag, "extent partials must fit the small read-back area in front of the flags");
 // n_pad > n (frame mode): xyz[n .. n_pad) is filled with non-finite points, which no later stage
 // ever sees as a point -- the launches of a captured frame run over the fixed maximum n_pad.
 template <bool PACK>
 __global__ void __launch_bounds__(256) k_bounds(const char* __restrict__ src, size_t stride,
                                                 float4* __restrict__ xyz, int n, int n_pad,
                                                 int* __restrict__ part, DevStats* st,
-                                                unsigned* done_ctr, unsigned* done_flag, unsigned seq,
-                                                int* __restrict__ part_dev) {
+                                                int* __restrict__ part_dev, uint4* __restrict__ zero16, int n_zero16) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *st = DevStats{};
+  // (the grid build's counters and scan words, cleared here instead of by a fill of their own between this pass
+  // and the counting pass: see pack_device_xyz)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero16; i += gridDim.x * blockDim.x)
+    zero16[i] = make_uint4(0u, 0u, 0u, 0u);
   int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
   int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   int cnt = 0;
@@ -101,19 +103,6 @@ __global__ void __launch_bounds__(256) k_bounds(const char* __restrict__ src, si
     part[blockIdx.x * 8 + k] = v;
     if (part_dev) part_dev[blockIdx.x * 8 + k] = v;  // (a copy in device memory for the k_cell_count queued behind)
   }
-  // partials in page-locked memory: the last workgroup writes the call's sequence number behind them, which the
-  // host polls instead of waiting for the stream (wait_flag); the counter is left at zero for the next launch
-  if (done_flag) {  // uniform
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence_system();
-      if (atomicAdd(done_ctr, 1u) == gridDim.x - 1u) {
-        *done_ctr = 0u;
-        __threadfence_system();
-        *reinterpret_cast<volatile unsigned*>(done_flag) = seq;
-      }
-    }
-  }
 }
 
 // key[i] = (cell key or -1, arrival rank inside the cell): the rank the counting atomic hands out
@@ -122,6 +111,8 @@ __global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ x
                                                     GridFromParts fp, int2* __restrict__ key,
                                                     unsigned* __restrict__ cell) {
   __shared__ GridDesc g_sh;
+  if (fp.done_flag && blockIdx.x == 0 && threadIdx.x == 0)  // (k_bounds is complete: tell the polling host)
+    *reinterpret_cast<volatile unsigned*>(fp.done_flag) = fp.done_seq;
   if (fp.part) {  // frame mode (uniform): the description from the extent partials of k_bounds
     if (wave_id() == 0) {
       const GridDesc gd = grid_from_partials(fp);
@@ -428,32 +419,22 @@ int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes
         c->bounds_in_pin = true;
       }
     }
-    unsigned* ctr = nullptr;
-    unsigned* flag = nullptr;
-    if (c->bounds_in_pin) {
-      if (!c->d_donectr.p) {
-        AG2_HIP(c, c->d_donectr.reserve(64));
-        AG2_HIP(c, hipMemsetAsync(c->d_donectr.p, 0, 64, c->stream));
-      }
-      ctr = c->d_donectr.as<unsigned>();
-      flag = reinterpret_cast<unsigned*>(pin_small_dev(c) + kPinBoundsFlag);
-      if (++c->bounds_seq == 0u) c->bounds_seq = 1u;  // (zero is what the flag starts from)
-    }
     const bool ahead = !c->fm_on && c->bounds_in_pin && c->cell_bytes_last && c->d_cell.p && n_pad == n;
+    const size_t guess = ahead ? std::min(c->d_cell.bytes & ~size_t(15), (c->cell_bytes_last + c->cell_bytes_last / 4 + 15) & ~size_t(15)) : 0;
     hipLaunchKernelGGL(k_bounds<true>, dim3(nb), dim3(256), 0, c->stream, (const char*)d_xyz,
-                       stride_bytes, dst, (int)n, (int)n_pad, part, c->d_stats.as<DevStats>(), ctr, flag,
-                       c->bounds_seq, ahead ? c->d_bounds.as<int>() : (int*)nullptr);
+                       stride_bytes, dst, (int)n, (int)n_pad, part, c->d_stats.as<DevStats>(),
+                       ahead ? c->d_bounds.as<int>() : (int*)nullptr,
+                       ahead ? c->d_cell.as<uint4>() : (uint4*)nullptr, (int)(guess / 16));
     c->bounds_blocks = nb;
     // The grid build clears its cell counters and scan words before it counts -- a fill whose size it learns
-    // from the extent.  Queued HERE, behind the extent pass and at the size of the previous cloud's grid plus a
-    // quarter, it runs while the host is still reading the extent back: build_grid then finds the words clear
-    // (a cloud whose grid outgrows the guess gets its fill as before).
+    // from the extent.  Done HERE, by the extent pass itself and at the size of the previous cloud's grid plus a
+    // quarter, it costs no launch and nothing waits for it: build_grid then finds the words clear (a cloud whose
+    // grid outgrows the guess gets its fill as before).
     c->cell_bytes_prezeroed = 0;
     c->cell_count_ahead_cap = 0;
+    c->bounds_flag_armed = false;
     // (same box, back to back: 0.6686 against 0.6714 ms per step)
     if (ahead) {
-      const size_t guess = std::min(c->d_cell.bytes & ~size_t(15), (c->cell_bytes_last + c->cell_bytes_last / 4 + 15) & ~size_t(15));
-      AG2_HIP(c, hipMemsetAsync(c->d_cell.p, 0, guess, c->stream));
       c->cell_bytes_prezeroed = guess;
       c->cell_prezeroed_at = c->d_cell.p;
       // ... and the counting pass itself: it derives the grid from the extent partials on the device (the
@@ -474,6 +455,13 @@ int pack_device_xyz(ag2_ctx* c, const void* d_xyz, size_t n, size_t stride_bytes
         for (int a = 0; a < 3; a++) fp.org[a] = c->origin[a];
         fp.cap_cells = (int)std::min<size_t>(cap, (size_t)1 << 30);
         fp.out = c->d_griddesc.as<GridDesc>();
+        // (the host polls this word instead of waiting for the stream: written by the first thread of the kernel
+        // BEHIND the extent pass, it says the partials are complete -- no fence per workgroup inside k_bounds, which
+        // on this GPU is a write-back of the L2 each)
+        if (++c->bounds_seq == 0u) c->bounds_seq = 1u;  // (zero is what the flag starts from)
+        fp.done_flag = reinterpret_cast<unsigned*>(pin_small_dev(c) + kPinBoundsFlag);
+        fp.done_seq = c->bounds_seq;
+        c->bounds_flag_armed = true;
         hipLaunchKernelGGL(k_cell_count, dim3(((int)n + 255) / 256), dim3(256), 0, c->stream, dst, (int)n, GridDesc{}, fp,
                            c->d_key.as<int2>(), c->d_cell.as<unsigned>());
         c->cell_count_ahead_cap = fp.cap_cells;
@@ -549,12 +537,17 @@ int build_grid(ag2_ctx* c) {
       nb = std::min((n + 255) / 256, kBoundsBlocks);
       AG2_HIP(c, c->d_bounds.reserve((size_t)kBoundsBlocks * 8 * 4));
       hipLaunchKernelGGL(k_bounds<false>, dim3(nb), dim3(256), 0, c->stream, (const char*)nullptr,
-                         (size_t)0, c->d_xyz_in.as<float4>(), n, n, c->d_bounds.as<int>(), st, (unsigned*)nullptr,
-                         (unsigned*)nullptr, 0u, (int*)nullptr);
+                         (size_t)0, c->d_xyz_in.as<float4>(), n, n, c->d_bounds.as<int>(), st, (int*)nullptr,
+                         (uint4*)nullptr, 0);
     }
-    if (packed_blocks && c->bounds_in_pin) {  // the pack kernel wrote them into pin_small itself, its flag behind them
-      const int rcw = wait_flag(c, kPinBoundsFlag, c->bounds_seq);
-      if (rcw) return rcw;
+    if (packed_blocks && c->bounds_in_pin) {  // the pack kernel wrote them into pin_small itself
+      if (c->bounds_flag_armed) {               // ... and the kernel queued behind it raises the flag
+        const int rcw = wait_flag(c, kPinBoundsFlag, c->bounds_seq);
+        if (rcw) return rcw;
+      } else {
+        AG2_HIP(c, hipStreamSynchronize(c->stream));
+      }
+      c->bounds_flag_armed = false;
     } else {
       AG2_HIP(c, hipMemcpyAsync(pin_small(c), c->d_bounds.p, (size_t)nb * 32, hipMemcpyDeviceToHost,
                                 c->stream));

@@ -15,6 +15,8 @@ struct GridFromParts {
   float org[3];
   int cap_cells;
   GridDesc* out;
+  unsigned* done_flag;    // page-locked word (or nullptr): the kernel that derives the grid writes done_seq there first --
+  unsigned done_seq;      // it runs behind k_bounds, so the host polling the word finds the extent partials complete
 };
 
 // ncells <= 0 tells every consumer "no grid": -1 more cells than the captured table holds, -2 a point
