@@ -127,11 +127,12 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
   // Every workgroup reports when its writes into host memory are out; the last one writes the call's sequence
   // number behind them (page-locked memory), which the host may poll instead of waiting for the stream
   // (wait_topk).
-  auto report = [&]() {
+  // (a system-scope fence is a write-back of the L2 on this GPU: only workgroups that wrote something pay for one)
+  auto report = [&](bool wrote) {
     if (!done_flag) return;  // uniform
     __syncthreads();
     if (threadIdx.x == 0) {
-      __threadfence_system();
+      if (wrote) __threadfence_system();
       if (atomicAdd(&st->topk_blocks, 1u) == gridDim.x - 1u) {
         __threadfence_system();
         *reinterpret_cast<volatile unsigned*>(done_flag) = seq;
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
   };
   const int base = blockIdx.x * kTopkThreads;
   if (base >= n) {  // uniform
-    report();
+    report(blockIdx.x == 0);  // (workgroup 0 wrote the statistics)
     return;
   }
   const int i = base + threadIdx.x;
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
     }
   }
   if (i < n && rank < k) out[rank] = recs[i];
-  report();
+  report(true);
 }
 
 // Polling returns ~10 us earlier than the runtime's wait for the kernel's completion signal (the results
