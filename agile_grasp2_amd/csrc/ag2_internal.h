@@ -211,6 +211,9 @@ struct ag2_ctx {
   unsigned bounds_seq = 0;   // ... of the last extent pass whose follower raises the flag in the small area
   bool bounds_flag_armed = false;
   unsigned topk_seq = 0;     // sequence number of the last k_topk launch (the done flag in the page-locked small area)
+  int sweep_no_overflow_runs = 0;   // consecutive runs that handed no sample to the long-list stage
+  bool sweep_may_skip_stage1 = false;  // set by the one-round-trip detect around its sweep: it checks and repeats
+  bool sweep_stage1_skipped = false;   // the last sweep did not launch the long-list stage
   int sweep_gpos_cap = 0;    // longest list the sweep's first stage keeps (k_sweep.hip: kGposCap / kGposCapBig, adaptive)
   ag2::DevBuf d_list;      // int compacted slot ids (hypotheses in order)
   ag2::DevBuf d_list2;     // int compacted slot ids after prune / for scoring

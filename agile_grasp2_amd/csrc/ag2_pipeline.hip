@@ -172,7 +172,9 @@ int detect_speculative(ag2_ctx* c, const int32_t* sample_idx, const double* samp
   const size_t cap_img = std::min(c->spec_cap_img, n_slots);
   const size_t k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, cap_img) : cap_img;
   if (k_cap > cap) return kSpecRedo;  // (the step-by-step form reports the caller's short buffer)
+  c->sweep_may_skip_stage1 = true;
   int rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true, do_prune ? 1 : 0, /*defer_read=*/true);
+  c->sweep_may_skip_stage1 = false;
   if (rc) return rc;
   if (c->desc_stride == 0) return kSpecRedo;  // (no descriptors from the compaction: more than 64 Ki slots)
   DevStats* st = c->d_stats.as<DevStats>();
@@ -215,8 +217,11 @@ int detect_speculative(ag2_ctx* c, const int32_t* sample_idx, const double* samp
   const DevStats& hs = fo.st;
   // did the shapes hold?  (err_flags: a buffer of the sweep was too small; the step-by-step form grows it)
   if ((hs.err_flags & (1u | 2u | 8u)) || (size_t)hs.n_list > cap_img ||
-      (int)hs.max_p > render_capacity_for(c->spec_max_p) || fo.topk_overflow)
+      (int)hs.max_p > render_capacity_for(c->spec_max_p) || fo.topk_overflow ||
+      (c->sweep_stage1_skipped && hs.n_overflow > 0)) {  // (samples were queued for the stage that was left out)
+    c->sweep_no_overflow_runs = 0;
     return kSpecRedo;
+  }
   note_sweep(c, s, hs, 1);
   const size_t n_img = hs.n_list;
   c->cnt.n_pruned = (int64_t)n_img;

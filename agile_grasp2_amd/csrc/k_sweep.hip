@@ -1260,6 +1260,7 @@ void sweep_adapt_gpos(ag2_ctx* c, size_t n_samples, size_t n_overflow) {
   if (c->sweep_gpos_cap <= 0) c->sweep_gpos_cap = kGposCap;
   if (n_overflow * 4 > n_samples) c->sweep_gpos_cap = kGposCap;
   else if (n_overflow > 0 && n_overflow * 16 <= n_samples) c->sweep_gpos_cap = kGposCapBig;
+  c->sweep_no_overflow_runs = n_overflow ? 0 : std::min(c->sweep_no_overflow_runs + 1, 1000);
 }
 
 static size_t sweep_lds_bytes(int stage) {
@@ -1416,7 +1417,11 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   const int gcap = c->sweep_gcap, g2 = c->sweep_g2;
   A.gscratch = c->d_gscratch.as<float>();
   A.gcap = gcap;
-  hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads1), sweep_lds_bytes(1), c->stream, A);
+  // (The one-round-trip detect leaves the launch out when the context's last runs queued nothing for this stage --
+  // an empty launch is 5 us of a 0.68 ms step -- and repeats the call step by step if this run did.)
+  c->sweep_stage1_skipped = c->sweep_may_skip_stage1 && !c->fm_on && c->sweep_no_overflow_runs >= 2;
+  if (!c->sweep_stage1_skipped)
+    hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads1), sweep_lds_bytes(1), c->stream, A);
   AG2_HIP(c, hipGetLastError());
   {
     const int rc = launch_sweep_orient(c, A, n_slots);

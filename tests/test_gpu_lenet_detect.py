@@ -287,6 +287,44 @@ def test_detect_with_more_than_8192_scored_images():
         d.close()
 
 
+def test_one_round_trip_detect_when_the_long_list_stage_was_left_out():
+    """After runs that queued no sample for the sweep's long-list stage the one-round-trip detect leaves that
+    launch out; a cloud whose neighbourhoods then do need it (dense, un-voxelised) is noticed at the end of the
+    call and repeated step by step: same bytes as a fresh context, and the next call launches the stage again."""
+    from agile_grasp2_amd import capi
+    sparse, ws1 = scene.make_scene(seed=31, n_target=40000, kind="tabletop")
+    dense, ws2 = scene.make_scene(seed=4, n_target=120000, kind="objects", voxel=None)
+    wsu = [min(ws1[0], ws2[0]), max(ws1[1], ws2[1]), min(ws1[2], ws2[2]), max(ws1[3], ws2[3]),
+           min(ws1[4], ws2[4]), max(ws1[5], ws2[5])]
+    prm = scene_params(wsu, num_selected=20, min_score_diff=-1e30)
+    w = make_lenet_weights(5)
+    d, e = capi.Detector(**prm), capi.Detector(**prm)
+    for x in (d, e):
+        x.lenet_load(w)
+    s = 60
+    i1 = scene.draw_samples(1, sparse.shape[0], s)
+    i2 = scene.draw_samples(4, dense.shape[0], s)
+    d.set_cloud(sparse)
+    d.compute_normals()
+    for _ in range(4):
+        d.detect(sample_idx=i1, seed=1, do_prune=False, want_all=False)
+    assert d.counters().n_overflow_samples == 0
+    d.set_cloud(dense)
+    d.compute_normals()
+    got, n_got = d.detect(sample_idx=i2, seed=2, do_prune=False, want_all=False)
+    assert d.counters().n_overflow_samples > 0
+    again, n_again = d.detect(sample_idx=i2, seed=2, do_prune=False, want_all=False)
+    e.set_cloud(dense)
+    e.compute_normals()
+    want, want_all = e.detect(sample_idx=i2, seed=2, do_prune=False)
+    assert n_got == n_again == len(want_all) and len(want_all) > 20
+    assert got.tobytes() == want.tobytes() == again.tobytes()
+    if not os.environ.get("AG2_DETECT_STEPWISE"):
+        assert d.counters().detect_redone >= 1
+    d.close()
+    e.close()
+
+
 def test_banded_convolutions_equal_the_whole_image_kernel_bit_for_bit(monkeypatch):
     """k_lenet_conv_x3b (default: a third of an image per workgroup, two workgroups per CU) runs every
     output through the same chain of MFMAs in the same k order as k_lenet_conv_x3 (AG2_LENET_WHOLE=1:
