@@ -258,7 +258,7 @@ unsigned long long frame_signature(const ag2_ctx* c, const ag2_frame_state* f) {
   memcpy(&cell_bits, &f->fs.cell, 4);
   const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points, c->list_ints, f->cap_img,
                                      (unsigned long long)c->sweep_gcap, (unsigned long long)c->sweep_g2,
-                                     (unsigned long long)c->sweep_gpos_cap,
+                                     (unsigned long long)c->sweep_gpos_cap * 2ull + (c->fm_skip_stage1 ? 1ull : 0ull),
                                      (unsigned long long)c->p.num_selected, f->k_cap, (unsigned long long)f->cap_p,
                                      (unsigned long long)c->origin_set, (unsigned long long)f->raw, f->fs.raw_max,
                                      f->fs.cap_words, f->fs.cand_cap, (unsigned long long)cell_bits,
@@ -466,6 +466,9 @@ void learn_shapes(ag2_ctx* c, ag2_frame_state* f, const FrameIn& in, size_t n_vo
   f->cap_img = std::min(std::max(f->cap_img, want_img), c->fm_s_max * (size_t)R);
   f->k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, f->cap_img) : f->cap_img;
   f->shapes_known = c->fm_s_max * (size_t)R <= 65536;
+  // the sweep's long-list stage: left out of the sequence while no frame has queued a sample for it (a frame that
+  // does is repeated step by step and the shapes are learned again, with the stage)
+  c->fm_skip_stage1 = c->cnt.n_overflow_samples == 0;
 }
 
 FrameIn pending_in(const ag2_frame_state::Pending& p) {
@@ -636,7 +639,8 @@ int frame_wait(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selec
     const unsigned flags = fo->st.err_flags;
     const bool bad = (flags & (1u | 2u | 8u)) != 0 || fo->g.ncells < 0 || fo->topk_overflow != 0 ||
                      (size_t)fo->st.n_list > std::min(f->cap_img, c->fm_s_max * (size_t)R) ||
-                     (int)fo->st.max_p > render_capacity_for(f->cap_p) || (in.raw && fo->pre.flags != 0u);
+                     (int)fo->st.max_p > render_capacity_for(f->cap_p) || (in.raw && fo->pre.flags != 0u) ||
+                     (c->fm_skip_stage1 && fo->st.n_overflow > 0);
     if (bad) {
       if (fo->g.ncells == -2) {
         p.active = false;
@@ -647,6 +651,7 @@ int frame_wait(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selec
                               (fo->topk_overflow ? 32 : 0) |
                               ((size_t)fo->st.n_list > std::min(f->cap_img, c->fm_s_max * (size_t)R) ? 64 : 0) |
                               ((int)fo->st.max_p > render_capacity_for(f->cap_p) ? 128 : 0) |
+                              ((c->fm_skip_stage1 && fo->st.n_overflow > 0) ? (1ll << 40) : 0) |
                               (in.raw ? ((int64_t)fo->pre.flags << 8) : 0);
       f->shapes_known = false;  // learn the shapes again from the step-by-step run
       const int rc = run_pending_stepwise(c, f);

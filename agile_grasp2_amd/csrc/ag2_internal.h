@@ -258,6 +258,7 @@ struct ag2_ctx {
   size_t fm_s_max = 0;       // samples per frame (the index list is padded with -1 up to it)
   size_t fm_cap_cells = 0;   // grid cells
   ag2::DevBuf d_griddesc;    // GridDesc written by k_cell_count (from the extent partials) or by the front end
+  bool fm_skip_stage1 = false; // frame mode: the sequence leaves the sweep's long-list stage out (learned: no frame so far needed it)
   bool fm_grid_ready = false;  // frame mode behind the GPU front end: d_griddesc is written by k_vox_emit_frame
   const ag2::FrameArgs* fm_args_dev = nullptr;  // device view of the page-locked per-frame scalars
   struct ag2_frame_state* fm = nullptr;         // owned by ag2_frame.hip

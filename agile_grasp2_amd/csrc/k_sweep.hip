@@ -1419,7 +1419,8 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   A.gcap = gcap;
   // (The one-round-trip detect leaves the launch out when the context's last runs queued nothing for this stage --
   // an empty launch is 5 us of a 0.68 ms step -- and repeats the call step by step if this run did.)
-  c->sweep_stage1_skipped = c->sweep_may_skip_stage1 && !c->fm_on && c->sweep_no_overflow_runs >= 2;
+  c->sweep_stage1_skipped = c->fm_on ? c->fm_skip_stage1
+                                     : (c->sweep_may_skip_stage1 && c->sweep_no_overflow_runs >= 2);
   if (!c->sweep_stage1_skipped)
     hipLaunchKernelGGL(fn_glb, dim3(g2), dim3(kSweepThreads1), sweep_lds_bytes(1), c->stream, A);
   AG2_HIP(c, hipGetLastError());

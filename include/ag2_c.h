@@ -130,7 +130,8 @@ typedef struct ag2_frame_info {
                                block; 64 more images than max_images; 128 an in-box list longer than the captured
                                renderers take; << 8: the front end's flags (ag2_detect_frame_raw): 1 voxel lattice larger
                                than the bitmap, 2 more voxels than max_points, 4 / 8 sub-sampling candidate list, 16 no
-                               more voxels than num_samples */
+                               more voxels than num_samples; << 40: a sample needed the sweep's long-list stage, which the
+                               sequence leaves out while no frame has needed it */
 } ag2_frame_info;
 
 int ag2_abi_version(void);

@@ -101,6 +101,37 @@ def test_frames_of_a_dense_cloud_use_the_renderers_for_large_images():
     ds.close()
 
 
+def test_a_frame_that_needs_the_long_list_stage_after_frames_that_did_not():
+    """The captured sequence leaves the sweep's long-list stage out while no frame has needed it.  A frame inside
+    the learned shapes whose neighbourhoods are too long for the first stage (a dense blob of points) is noticed
+    when its results arrive, repeated step by step, and the sequence is captured again with the stage."""
+    frames = _clouds(3, 20000, 200)
+    ws = frames[0][1]
+    df, ds = _pair(ws, min_score_diff=-1e30, num_selected=40)
+    df.stream_configure(0, 0, True)
+    for k, (xyz, _, idx) in enumerate(frames):
+        got, gn = df.detect_frame(xyz, idx, seed=k)
+        want, wn = _stepwise(ds, xyz, idx, seed=k)
+        assert gn == wn and got.tobytes() == want.tobytes(), k
+    assert df.counters().n_overflow_samples == 0 and df.frame_info().graph_replays >= 1
+    rng = np.random.default_rng(5)
+    base = frames[0][0]
+    centre = base[frames[0][2][0]]
+    blob = (centre + rng.uniform(-0.03, 0.03, size=(18000, 3))).astype(np.float32)
+    mixed = np.concatenate([base[:2500], blob]).astype(np.float32)
+    idx = np.sort(rng.choice(np.arange(2500, mixed.shape[0]), 200, replace=False)).astype(np.int32)
+    before = df.frame_info().fallbacks
+    for rep in range(3):
+        got, gn = df.detect_frame(mixed, idx, seed=9)
+        want, wn = _stepwise(ds, mixed, idx, seed=9)
+        assert gn == wn and got.tobytes() == want.tobytes(), rep
+    assert ds.counters().n_overflow_samples > 0
+    fi = df.frame_info()
+    assert fi.fallbacks == before + 1 and fi.graph_replays >= 2
+    df.close()
+    ds.close()
+
+
 def test_frames_everything_selected_and_no_prune():
     """num_selected < 0 keeps every record above the threshold; do_prune off scores every hypothesis."""
     frames = _clouds(4, 12000, 200, kinds=("tabletop", "objects"))
