@@ -202,7 +202,15 @@ int detect_speculative(ag2_ctx* c, const int32_t* sample_idx, const double* samp
   if (rc) return rc;
   c->d_last_sel = c->d_sel.p;  // for ag2_export_selected_compact_device
   c->d_last_nsel = &st->n_sel;
-  rc = launch_topk(c, c->d_sel.as<ag2_hypothesis>(), &st->n_sel, cap_img, k_cap, d_rec, d_fo, nullptr);
+  const ag2_hypothesis* d_res = c->d_sel.as<ag2_hypothesis>();
+  const unsigned* d_nres = &st->n_sel;
+  if (c->min_inliers > 0) {  // grasp clusters between the threshold and the top-k (grasp_detector.cpp:228-236)
+    rc = cluster_async(c, d_res, cap_img, d_nres, c->min_inliers, &st->n_clu);
+    if (rc) return rc;
+    d_res = c->d_cluster.as<ag2_hypothesis>();
+    d_nres = &st->n_clu;
+  }
+  rc = launch_topk(c, d_res, d_nres, cap_img, k_cap, d_rec, d_fo, nullptr);
   if (rc) return rc;
   AG2_HIP(c, stage_event(c, 7));
   if (c->stage_timing >= 2) {  // (event 7 is behind k_topk: wait for the stream)
@@ -420,10 +428,10 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   (void)n_slots;
   AG2_HIP(c, stage_event(c, 8));
   // The one-round-trip form, when the previous call on this context left its shapes and nothing asks
-  // for the step-by-step one (all scored records, clustering, the multi-GPU export without read-back,
+  // for the step-by-step one (all scored records, the multi-GPU export without read-back,
   // the f32-input LeNet kernels, AG2_DETECT_STEPWISE=1 for A/B).
   static const bool spec_off = getenv("AG2_DETECT_STEPWISE") != nullptr;
-  const bool spec = !spec_off && selected && !(scored_all && cap_all) && c->min_inliers <= 0 && c->net.use_x3 &&
+  const bool spec = !spec_off && selected && !(scored_all && cap_all) && c->net.use_x3 &&
                     !c->fm_on && c->spec_cap_img > 0 && c->spec_s == s && c->spec_prune == (do_prune ? 1 : 0) &&
                     n_slots > 0 && n_slots <= 65536;
   if (spec) {

@@ -287,6 +287,28 @@ def test_detect_with_more_than_8192_scored_images():
         d.close()
 
 
+@pytest.mark.parametrize("min_inliers", [1, 3])
+def test_one_round_trip_detect_with_grasp_clusters(small_scene, min_inliers):
+    """min_inliers > 0 (the launch files' default is 5): HandleSearch::findClusters between the threshold and
+    the top-k (grasp_detector.cpp:228-236) runs inside the one-round-trip form as well -- the bytes of the
+    step-by-step form, whose clustered selection has its own tests against the oracle (tests/test_clusters.py)."""
+    from agile_grasp2_amd import capi
+    xyz, ws, idx = small_scene
+    d = capi.Detector(**scene_params(ws, num_selected=25, min_score_diff=-1e30))
+    d.set_cloud(xyz)
+    d.compute_normals()
+    d.lenet_load(make_lenet_weights(5))
+    d.set_min_inliers(min_inliers)
+    ref_sel, ref_all = d.detect(sample_idx=idx, seed=3, do_prune=False)                # step by step
+    assert len(ref_all) > 60 and 0 < len(ref_sel) <= 25
+    for rep in range(3):
+        sel, n_scored = d.detect(sample_idx=idx, seed=3, do_prune=False, want_all=False)
+        assert n_scored == len(ref_all) and sel.tobytes() == ref_sel.tobytes(), rep
+    if not os.environ.get("AG2_DETECT_STEPWISE"):
+        assert d.counters().detect_one_trip == 3
+    d.close()
+
+
 def test_one_round_trip_detect_when_the_long_list_stage_was_left_out():
     """After runs that queued no sample for the sweep's long-list stage the one-round-trip detect leaves that
     launch out; a cloud whose neighbourhoods then do need it (dense, un-voxelised) is noticed at the end of the
