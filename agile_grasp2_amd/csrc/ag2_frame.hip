@@ -253,13 +253,15 @@ unsigned long long frame_signature(const ag2_ctx* c, const ag2_frame_state* f) {
                         c->d_logits.p, c->d_act1.p, c->d_fcpart.p, c->d_sel.p, c->d_flags.p, c->d_desc.p,
                         c->d_scan.p, f->h_pin, c->net.w1x.p, c->net.w2x.p, c->net.w3x.p,
                         c->net.b1.p, c->net.b2.p, c->net.b3.p, c->net.w4.p, c->net.b4.p, (const void*)c->stream,
-                        c->d_raw.p, c->d_bitmap.p, c->d_wrank.p, c->d_preframe.p, c->d_cand.p, c->d_samples.p, c->d_rlist.p};
+                        c->d_raw.p, c->d_bitmap.p, c->d_wrank.p, c->d_preframe.p, c->d_cand.p, c->d_samples.p, c->d_rlist.p,
+                        c->d_cluster.p, c->d_cluster_tmp.p};
   unsigned cell_bits = 0;
   memcpy(&cell_bits, &f->fs.cell, 4);
   const unsigned long long vals[] = {c->fm_n_max, c->fm_s_max, c->fm_cap_cells, c->arena_points, c->list_ints, f->cap_img,
                                      (unsigned long long)c->sweep_gcap, (unsigned long long)c->sweep_g2,
                                      (unsigned long long)c->sweep_gpos_cap * 2ull + (c->fm_skip_stage1 ? 1ull : 0ull),
                                      (unsigned long long)c->p.num_selected, f->k_cap, (unsigned long long)f->cap_p,
+                                     (unsigned long long)c->min_inliers,
                                      (unsigned long long)c->origin_set, (unsigned long long)f->raw, f->fs.raw_max,
                                      f->fs.cap_words, f->fs.cand_cap, (unsigned long long)cell_bits,
                                      (unsigned long long)f->fs.filter_workspace};
@@ -357,11 +359,20 @@ int enqueue_frame(ag2_ctx* c, ag2_frame_state* f, int do_prune) {
   if (rc) return rc;
   rc = score_and_select_async(c, c->d_list2.as<int>(), cap_img, &st->n_sel, d_n);
   if (rc) return rc;
+  // -- grasp clusters between the threshold and the top-k (grasp_detector.cpp:228-236), when asked for ----
+  const ag2_hypothesis* d_res = c->d_sel.as<ag2_hypothesis>();
+  const unsigned* d_nres = &st->n_sel;
+  if (c->min_inliers > 0) {
+    rc = cluster_async(c, d_res, cap_img, d_nres, c->min_inliers, &st->n_clu);
+    if (rc) return rc;
+    d_res = c->d_cluster.as<ag2_hypothesis>();
+    d_nres = &st->n_clu;
+  }
   // -- top-k on the device, written straight into the page-locked block ------------------------------
   ag2_hypothesis* d_rec = (ag2_hypothesis*)((char*)c->fm_args_dev + f->off_rec);
   FrameOut* d_fo = (FrameOut*)((char*)c->fm_args_dev + f->off_out);
   hipLaunchKernelGGL(k_topk, dim3((unsigned)((cap_img + kTopkThreads - 1) / kTopkThreads)), dim3(kTopkThreads), 0,
-                     c->stream, c->d_sel.as<ag2_hypothesis>(), &st->n_sel, (int)cap_img, c->p.num_selected,
+                     c->stream, d_res, d_nres, (int)cap_img, c->p.num_selected,
                      (int)f->k_cap, d_rec, d_fo, st, gp,
                      f->raw ? c->d_preframe.as<PreFrame>() : (const PreFrame*)nullptr, 0u, &d_fo->done_seq,
                      c->fm_args_dev);
@@ -558,9 +569,9 @@ int frame_submit(ag2_ctx* c, const FrameIn& in) {
   if (!in.raw && in.s) p.idx.assign(in.sample_idx, in.sample_idx + in.s);
   f->info.frames++;
   const size_t s_req = in.raw ? in.num_samples : in.s;
-  // Frames the captured sequence cannot take: clustering inside detect (k_cluster is not part of
-  // it), more than 65536 table slots, an empty frame, the f32-input LeNet kernels.
-  p.unsupported = c->min_inliers > 0 || s_req * (size_t)R > 65536 || n == 0 || s_req == 0 || !c->net.use_x3;
+  // Frames the captured sequence cannot take: more than 65536 table slots, an empty frame, the f32-input LeNet
+  // kernels.
+  p.unsupported = s_req * (size_t)R > 65536 || n == 0 || s_req == 0 || !c->net.use_x3;
   if (f->shapes_known && f->raw != in.raw) {  // the stream changed its entry point: learn the shapes again
     f->shapes_known = false;
     drop_graph(f);

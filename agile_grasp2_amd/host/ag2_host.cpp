@@ -1142,7 +1142,7 @@ std::vector<GraspHypothesis> GraspDetector::detectGraspPosesInFrame(const PointC
     weights_in_ctx_ = rc ? nullptr : c;
   }
   const int hs_inliers = handle_search_.getMinInliers();
-  if (!rc) rc = ag2_set_min_inliers(c, hs_inliers > 0 ? hs_inliers : 0);  // (clustered frames run step by step inside the library)
+  if (!rc) rc = ag2_set_min_inliers(c, hs_inliers > 0 ? hs_inliers : 0);  // (the clustering is part of the captured sequence)
   const size_t cap = std::max<size_t>(1, (size_t)num_samples_ * (size_t)p_.num_orientations);
   std::vector<ag2_hypothesis> recs(cap);
   size_t n = 0, n_scored = 0, n_vox = 0;

@@ -202,7 +202,7 @@ int ag2_lenet_forward(ag2_ctx* c, const uint8_t* images_hwc, size_t n, float* ip
  * num_selected by score.  scored_all (optional) receives every scored hypothesis in order.
  * Host round trips: two on a context's first call (the sweep's statistics size the launches of the
  * renderer and of LeNet; the selected records come back and are sorted on the host), ONE from the
- * second call on when only the selection is asked for (scored_all == NULL, no clustering): the tail is
+ * second call on when only the selection is asked for (scored_all == NULL): the tail is
  * launched at the shapes the previous call left with the list length read on the device, the top
  * num_selected are picked on the device, and if the statistics that come back with them say the
  * shapes did not hold the call runs again in the two-trip form.  Same bytes either way

@@ -132,6 +132,28 @@ def test_a_frame_that_needs_the_long_list_stage_after_frames_that_did_not():
     ds.close()
 
 
+def test_frames_with_grasp_clusters():
+    """min_inliers > 0 (the launch files' default is 5): the clustering between the threshold and the top-k is part
+    of the captured sequence; replays return the bytes of the step-by-step path."""
+    frames = _clouds(5, 20000, 300)
+    ws = frames[0][1]
+    df, ds = _pair(ws, min_score_diff=-1e30, num_selected=40)
+    for d in (df, ds):
+        d.set_min_inliers(2)
+    df.stream_configure(0, 0, True)
+    total = 0
+    for k, (xyz, _, idx) in enumerate(frames):
+        got, gn = df.detect_frame(xyz, idx, seed=k)
+        want, wn = _stepwise(ds, xyz, idx, seed=k)
+        assert gn == wn and got.tobytes() == want.tobytes(), k
+        total += len(want)
+    assert total > 10
+    fi = df.frame_info()
+    assert fi.graph_replays == 3 and fi.fallbacks == 0 and fi.stepwise_runs == 1
+    df.close()
+    ds.close()
+
+
 def test_frames_everything_selected_and_no_prune():
     """num_selected < 0 keeps every record above the threshold; do_prune off scores every hypothesis."""
     frames = _clouds(4, 12000, 200, kinds=("tabletop", "objects"))
