@@ -196,6 +196,8 @@ int wait_flag_at(ag2_ctx* c, const volatile unsigned* flag, unsigned want) {
       }
       if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
     }
+    static const bool dbg = getenv("AG2_POLL_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[ag2] wait_flag: 5 ms without the flag (want %u, have %u): waiting for the stream\n", want, *flag);
   }
   AG2_HIP(c, hipStreamSynchronize(c->stream));
   return 0;
