@@ -29,7 +29,7 @@ SYMBOLS = [
     "ag2_detect_frame_raw", "ag2_get_samples", "ag2_gather_begin", "ag2_gather_selected", "ag2_merge_gathered",
     "ag2_submit_frame", "ag2_submit_frame_raw", "ag2_wait_frame", "ag2_pipe_create", "ag2_pipe_destroy",
     "ag2_pipe_last_error", "ag2_pipe_context", "ag2_pipe_lenet_load", "ag2_pipe_submit", "ag2_pipe_submit_raw",
-    "ag2_pipe_wait",
+    "ag2_pipe_wait", "ag2_set_wait_mode", "ag2_get_wait_info",
 ]
 
 
@@ -61,6 +61,11 @@ class FrameInfo(C.Structure):
         "frames", "graph_replays", "plain_runs", "stepwise_runs", "captures", "capture_failed",
         "capture_refused", "fallbacks", "max_points", "max_samples", "max_cells", "max_images", "graph_ready",
         "last_fallback")]
+
+
+class WaitInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("poll", "spin_us", "poll_fallbacks", "poll_yields", "last_submit_us",
+                                          "last_wait_us")]
 
 
 class Times(C.Structure):
@@ -472,6 +477,15 @@ class Detector:
                                                   C.byref(ns), C.byref(nt)))
         return sel[: ns.value].copy(), nt.value
 
+    def set_wait_mode(self, poll: bool = True, spin_us: int = 50):
+        """How the host waits for results: poll the flag behind them (spin spin_us, then yield), or the stream."""
+        self._ck(self.L.ag2_set_wait_mode(self.h, C.c_int(1 if poll else 0), C.c_int(int(spin_us))))
+
+    def wait_info(self) -> WaitInfo:
+        w = WaitInfo()
+        self._ck(self.L.ag2_get_wait_info(self.h, C.byref(w)))
+        return w
+
     def counters(self) -> Counters:
         c = Counters()
         self._ck(self.L.ag2_get_counters(self.h, C.byref(c)))
@@ -494,7 +508,7 @@ class Pipe:
             raise RuntimeError("ag2_pipe_create failed: no usable HIP device or bad parameters")
         self.h = C.c_void_p(h)
         self.depth = depth
-        self._cap = 1
+        self._caps = []   # one result capacity per frame in flight, oldest first (frames may differ in num_samples)
 
     def close(self):
         if getattr(self, "h", None):
@@ -530,11 +544,12 @@ class Pipe:
             n, stride, ptr, on_dev = xyz.shape[0], 12, _ptr(xyz), 0
         else:
             ptr, on_dev = C.c_void_p(dptr), 1
-        self._cap = max(1, int(num_samples) * int(self.params.num_orientations))
+        cap = max(1, int(num_samples) * int(self.params.num_orientations))
         self._ck(self.L.ag2_pipe_submit_raw(self.h, ptr, C.c_int(on_dev), C.c_size_t(n), C.c_size_t(stride),
                                             C.c_int(int(filter_workspace)), C.c_double(voxel_size),
                                             C.c_size_t(num_samples), C.c_uint64(sample_seed), C.c_uint64(seed),
                                             C.c_int(1 if do_prune else 0)))
+        self._caps.append(cap)
 
     def submit(self, xyz=None, sample_idx=None, seed=0, do_prune=True, dptr=None, n=None, stride=12):
         si = np.ascontiguousarray(sample_idx, dtype=np.int32)
@@ -543,16 +558,26 @@ class Pipe:
             n, stride, ptr, on_dev = xyz.shape[0], 12, _ptr(xyz), 0
         else:
             ptr, on_dev = C.c_void_p(dptr), 1
-        self._cap = max(1, len(si) * int(self.params.num_orientations))
+        cap = max(1, len(si) * int(self.params.num_orientations))
         self._ck(self.L.ag2_pipe_submit(self.h, ptr, C.c_int(on_dev), C.c_size_t(n), C.c_size_t(stride), _ptr(si),
                                         C.c_size_t(len(si)), C.c_uint64(seed), C.c_int(1 if do_prune else 0)))
+        self._caps.append(cap)
 
     def wait(self):
         """(selected, n_scored, n_voxels) of the oldest frame in flight"""
         nsel = int(self.params.num_selected)
-        cap = self._cap if nsel < 0 else max(1, min(self._cap, nsel))
+        cap0 = self._caps[0] if self._caps else 1   # the capacity of the OLDEST frame, not of the last submit
+        cap = cap0 if nsel < 0 else max(1, min(cap0, nsel))
         if getattr(self, "_sel_buf", None) is None or len(self._sel_buf) < cap:
             self._sel_buf = np.zeros(cap, dtype=HYP_DTYPE)
         ns, na, nv = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
-        self._ck(self.L.ag2_pipe_wait(self.h, _ptr(self._sel_buf), C.c_size_t(cap), C.byref(ns), C.byref(na), C.byref(nv)))
+        rc = self.L.ag2_pipe_wait(self.h, _ptr(self._sel_buf), C.c_size_t(len(self._sel_buf)), C.byref(ns), C.byref(na),
+                                  C.byref(nv))
+        if rc == -3 and ns.value > len(self._sel_buf):   # AG2_ERR_CAPACITY: the frame is kept, wait again with room
+            self._sel_buf = np.zeros(ns.value, dtype=HYP_DTYPE)
+            rc = self.L.ag2_pipe_wait(self.h, _ptr(self._sel_buf), C.c_size_t(len(self._sel_buf)), C.byref(ns),
+                                      C.byref(na), C.byref(nv))
+        self._ck(rc)
+        if self._caps:
+            self._caps.pop(0)
         return self._sel_buf[: ns.value].copy(), na.value, nv.value

@@ -124,7 +124,10 @@ int pin_reserve(ag2_ctx* c, size_t bulk_bytes) {
   c->h_pin_dev = nullptr;
   c->h_pin_bytes = 0;
   const size_t want = need + need / 2 + 65536;
-  AG2_HIP(c, hipHostMalloc(&c->h_pin, want, hipHostMallocDefault));
+  // explicitly coherent (fine-grained, uncached on the device side) and mapped: kernels write results and the
+  // flags the host polls into it, which is only sound while no device cache holds those lines back --
+  // hipHostMallocDefault leaves that to HIP_HOST_COHERENT
+  AG2_HIP(c, hipHostMalloc(&c->h_pin, want, kPinFlags));
   memset(c->h_pin, 0, kPinSmall);  // (the done flag of k_topk starts below every sequence number)
   c->h_pin_bytes = want;
   c->h_pin_dev = nullptr;
@@ -223,6 +226,9 @@ ag2_ctx* ag2_create(const ag2_params* p, int device_id) {
   }
   c->own_stream = true;
   for (auto& e : c->ev) (void)hipEventCreate(&e);
+  // how the host waits (ag2_set_wait_mode changes it per context): AG2_POLL=0 -> the stream; AG2_POLL_SPIN_US
+  if (const char* e = getenv("AG2_POLL")) c->wait_poll = atoi(e) != 0 ? 1 : 0;
+  if (const char* e = getenv("AG2_POLL_SPIN_US")) c->wait_spin_us = std::max(0, atoi(e));
 
   derive_constants(c->p, c->hc);
   if (c->d_stats.reserve(sizeof(DevStats)) != hipSuccess || upload_constants(c) != 0 ||
@@ -247,7 +253,7 @@ void ag2_destroy(ag2_ctx* c) {
                     &c->d_raw, &c->d_raw_nrm, &c->d_pre, &c->d_pflags, &c->d_bitmap, &c->d_wrank,
                     &c->d_first, &c->d_prestats, &c->d_hist, &c->d_samples, &c->d_preframe, &c->d_cand, &c->d_cluster, &c->d_cluster_tmp, &c->d_rlist, &c->net.w1p, &c->net.b1,
                     &c->net.w2p, &c->net.b2, &c->net.w3p, &c->net.b3, &c->net.w4, &c->net.b4,
-                    &c->net.w1x, &c->net.w2x, &c->net.w3x};
+                    &c->net.w1x, &c->net.w2x, &c->net.w3x, &c->d_sweep_prof};
   for (DevBuf* b : bufs) b->release();
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   for (auto& e : c->ev)
@@ -393,6 +399,26 @@ int ag2_set_stage_timing(ag2_ctx* c, int level) {
   c->stage_timing = level;
   memset(&c->times, 0, sizeof(c->times));
   c->grid_pending = false;  // (its events may not exist at the new level)
+  return 0;
+}
+
+int ag2_set_wait_mode(ag2_ctx* c, int poll, int spin_us) {
+  if (!c) return AG2_ERR_ARG;
+  if (poll < 0 || poll > 1 || spin_us < 0) return set_err(c, AG2_ERR_ARG, "wait mode: poll 0 / 1, spin_us >= 0");
+  c->wait_poll = poll;
+  c->wait_spin_us = spin_us;
+  return 0;
+}
+
+int ag2_get_wait_info(ag2_ctx* c, ag2_wait_info* out) {
+  if (!c || !out) return AG2_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  out->poll = c->wait_poll;
+  out->spin_us = c->wait_spin_us;
+  out->poll_fallbacks = c->poll_fallbacks;
+  out->poll_yields = c->poll_yields;
+  out->last_submit_us = c->last_submit_us;
+  out->last_wait_us = c->last_wait_us;
   return 0;
 }
 

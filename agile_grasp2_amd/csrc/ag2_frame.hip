@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <sched.h>
 #include <vector>
 
 #include "ag2_internal.h"
@@ -127,12 +128,15 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
   // Every workgroup reports when its writes into host memory are out; the last one writes the call's sequence
   // number behind them (page-locked memory), which the host may poll instead of waiting for the stream
   // (wait_topk).
-  // (a system-scope fence is a write-back of the L2 on this GPU: only workgroups that wrote something pay for one)
+  // (a system-scope fence is a write-back of the L2 on this GPU: only waves that wrote something pay for one.)
+  // EVERY wave that stored into host memory fences its own stores before the barrier: a workgroup barrier does
+  // not wait for another wave's outstanding stores (no vmcnt(0) at workgroup scope outside tgsplit mode), so a
+  // fence by thread 0 alone would cover wave 0's stores only.
   auto report = [&](bool wrote) {
     if (!done_flag) return;  // uniform
+    if (__any(wrote)) __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (wrote) __threadfence_system();
       if (atomicAdd(&st->topk_blocks, 1u) == gridDim.x - 1u) {
         __threadfence_system();
         *reinterpret_cast<volatile unsigned*>(done_flag) = seq;
@@ -141,7 +145,7 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
   };
   const int base = blockIdx.x * kTopkThreads;
   if (base >= n) {  // uniform
-    report(blockIdx.x == 0);  // (workgroup 0 wrote the statistics)
+    report(blockIdx.x == 0 && threadIdx.x == 0);  // (thread 0 of workgroup 0 wrote the statistics)
     return;
   }
   const int i = base + threadIdx.x;
@@ -167,14 +171,19 @@ __global__ void __launch_bounds__(kTopkThreads) k_topk(const ag2_hypothesis* __r
         rank += (int)(v[u] > si) | ((int)(v[u] == si) & (int)(j0 + t + u < i));
     }
   }
-  if (i < n && rank < k) out[rank] = recs[i];
-  report(true);
+  const bool wrote = i < n && rank < k;
+  if (wrote) out[rank] = recs[i];
+  report(wrote || (blockIdx.x == 0 && threadIdx.x == 0));
 }
 
 // Polling returns ~10 us earlier than the runtime's wait for the kernel's completion signal (the results
 // behind which the flag sits are in host memory by then; two such waits per detect step: 0.713 -> 0.692 ms).
-// After 5 ms of polling the stream is waited for the ordinary way (long runs do not spin on a core); AG2_POLL=0
-// turns the polling off.
+// Cost and bounds: the waiting thread spins on its core for `wait_spin_us` (50 us by default: a detect step's two
+// waits are normally shorter than that by the time the host reaches them), then goes on polling but yields the
+// core between looks (sched_yield: a caller with more contexts than spare cores -- ag2_pipe, one thread per
+// device -- does not hold cores for whole steps), and after 5 ms waits for the stream the ordinary way.
+// ag2_set_wait_mode(c, 0, 0) / AG2_POLL=0 turn the polling off.  After the stream wait the flag MUST hold the
+// sequence number (the kernel that writes it has finished): anything else is reported, not ignored.
 int wait_flag(ag2_ctx* c, size_t flag_off, unsigned want) {
   if (!c->h_pin_dev) {
     AG2_HIP(c, hipStreamSynchronize(c->stream));
@@ -183,23 +192,32 @@ int wait_flag(ag2_ctx* c, size_t flag_off, unsigned want) {
   return wait_flag_at(c, reinterpret_cast<const volatile unsigned*>(pin_small(c) + flag_off), want);
 }
 int wait_flag_at(ag2_ctx* c, const volatile unsigned* flag, unsigned want) {
-  static const bool poll = [] { const char* e = getenv("AG2_POLL"); return !e || atoi(e) != 0; }();
-  if (poll && flag) {
+  if (c->wait_poll && flag) {
     const auto t0 = std::chrono::steady_clock::now();
+    const auto spin_for = std::chrono::microseconds(c->wait_spin_us);
+    bool yielding = false;
     for (;;) {
-      for (int spin = 0; spin < 2048; spin++) {
+      for (int spin = 0; spin < 256; spin++) {
         if (*flag == want) {
           __atomic_thread_fence(__ATOMIC_ACQUIRE);
           return 0;
         }
         __builtin_ia32_pause();
       }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+      const auto dt = std::chrono::steady_clock::now() - t0;
+      if (dt > std::chrono::milliseconds(5)) break;
+      if (yielding || dt > spin_for) {
+        yielding = true;
+        c->poll_yields++;
+        sched_yield();
+      }
     }
-    static const bool dbg = getenv("AG2_POLL_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[ag2] wait_flag: 5 ms without the flag (want %u, have %u): waiting for the stream\n", want, *flag);
+    c->poll_fallbacks++;
   }
   AG2_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->wait_poll && flag && *flag != want)
+    return set_err(c, AG2_ERR_STATE, "the stream is idle but the kernel's flag does not hold the call's sequence number (have " +
+                                         std::to_string(*flag) + ", want " + std::to_string(want) + ")");
   return 0;
 }
 
@@ -236,7 +254,7 @@ int frame_pin_reserve(ag2_ctx* c, ag2_frame_state* f) {
   if (f->h_pin) (void)hipHostFree(f->h_pin);
   f->h_pin = nullptr;
   f->h_pin_bytes = 0;
-  AG2_HIP(c, hipHostMalloc((void**)&f->h_pin, need, hipHostMallocDefault));
+  AG2_HIP(c, hipHostMalloc((void**)&f->h_pin, need, kPinFlags));
   f->h_pin_bytes = need;
   reinterpret_cast<FrameOut*>(f->h_pin + off_out)->done_seq = 0u;
   void* dv = nullptr;
@@ -524,7 +542,7 @@ int run_pending_stepwise(ag2_ctx* c, ag2_frame_state* f) {
 }
 
 // ---- submit: everything of a frame up to (not including) the wait for its results -------------------
-int frame_submit(ag2_ctx* c, const FrameIn& in) {
+int frame_submit_impl(ag2_ctx* c, const FrameIn& in) {
   if (c->p.n_cams != 1) return set_err(c, AG2_ERR_ARG, "frames are single-camera clouds");
   if (in.stride < 12 || in.stride % 4 != 0) return set_err(c, AG2_ERR_ARG, "bad stride");
   if (in.n > (size_t)1 << 30) return set_err(c, AG2_ERR_CAPACITY, "more than 2^30 points");
@@ -636,8 +654,8 @@ int frame_submit(ag2_ctx* c, const FrameIn& in) {
 }
 
 // ---- wait: the results of the submitted frame -------------------------------------------------------
-int frame_wait(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored,
-               size_t* n_voxels) {
+int frame_wait_impl(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored,
+                    size_t* n_voxels) {
   ag2_frame_state* f = c->fm;
   if (!f || !f->pend.active) return set_err(c, AG2_ERR_STATE, "no frame in flight on this context");
   ag2_frame_state::Pending& p = f->pend;
@@ -692,6 +710,9 @@ int frame_wait(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selec
           c->stage_timing = lvl;
           if (e == hipSuccess && rc2 == 0 && g && sig0 == frame_signature(c, f) &&
               hipGraphInstantiate(&f->exec, g, nullptr, nullptr, 0) == hipSuccess) {
+            // (the executable graph's first launch would otherwise carry its upload to the device)
+            (void)hipGraphUpload(f->exec, c->stream);
+            (void)hipStreamSynchronize(c->stream);
             f->graph = g;
             f->graph_valid = true;
             f->sig_at_capture = sig0;
@@ -735,23 +756,53 @@ int frame_wait(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selec
       c->cnt.list_points = (int64_t)fo->st.list_top;
       const size_t k = fo->n_out;
       c->cnt.n_selected = (int64_t)k;
-      p.active = false;
       *n_selected = k;
       if (n_scored) *n_scored = fo->st.n_list;
       if (n_voxels) *n_voxels = n_cloud;
-      if (k > cap) return set_err(c, AG2_ERR_CAPACITY, "detect_frame: output capacity too small");
+      if (k > cap) {
+        // the caller's buffer is too small: the frame stays retrievable (a second wait with more room brings it;
+        // *n_selected says how much) instead of being lost
+        const ag2_hypothesis* r = (const ag2_hypothesis*)(f->h_pin + f->off_rec);
+        p.recs.assign(r, r + k);
+        p.n_selected = k;
+        p.n_scored = fo->st.n_list;
+        p.n_voxels = n_cloud;
+        p.finished = true;
+        return set_err(c, AG2_ERR_CAPACITY, "detect_frame: output capacity too small (the frame is kept: wait again with room for n_selected records)");
+      }
+      p.active = false;
       if (k) memcpy(selected, f->h_pin + f->off_rec, k * sizeof(ag2_hypothesis));
       return 0;
     }
   }
-  // the frame ran step by step (inside the submit, or just now as a fallback): its results were kept
-  p.active = false;
+  // the frame ran step by step (inside the submit, or just now as a fallback), or an earlier wait found the
+  // caller's buffer too small: its results were kept
   *n_selected = p.n_selected;
   if (n_scored) *n_scored = p.n_scored;
   if (n_voxels) *n_voxels = p.n_voxels;
-  if (p.n_selected > cap) return set_err(c, AG2_ERR_CAPACITY, "detect_frame: output capacity too small");
+  if (p.n_selected > cap)
+    return set_err(c, AG2_ERR_CAPACITY, "detect_frame: output capacity too small (the frame is kept: wait again with room for n_selected records)");
+  p.active = false;
   if (p.n_selected) memcpy(selected, p.recs.data(), p.n_selected * sizeof(ag2_hypothesis));
   return 0;
+}
+
+// (host time inside each half, for callers that have to attribute a slow frame: ag2_get_wait_info)
+inline int64_t us_since(std::chrono::steady_clock::time_point t0) {
+  return (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+}
+int frame_submit(ag2_ctx* c, const FrameIn& in) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = frame_submit_impl(c, in);
+  c->last_submit_us = us_since(t0);
+  return rc;
+}
+int frame_wait(ag2_ctx* c, ag2_hypothesis* selected, size_t cap, size_t* n_selected, size_t* n_scored,
+               size_t* n_voxels) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = frame_wait_impl(c, selected, cap, n_selected, n_scored, n_voxels);
+  c->last_wait_us = us_since(t0);
+  return rc;
 }
 
 int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, size_t cap, size_t* n_selected,
@@ -971,9 +1022,10 @@ int ag2_pipe_wait(ag2_pipe* q, ag2_hypothesis* selected, size_t cap, size_t* n_s
   }
   ag2_ctx* c = q->ctx[q->next_wait];
   const int rc = ag2_wait_frame(c, selected, cap, n_selected, n_scored, n_voxels);
+  if (rc) q->err = ag2_last_error(c);
+  if (rc == AG2_ERR_CAPACITY) return rc;  // (the frame is kept: the caller waits again with a larger buffer)
   q->next_wait = (q->next_wait + 1) % q->ctx.size();
   q->in_flight--;
-  if (rc) q->err = ag2_last_error(c);
   return rc;
 }
 

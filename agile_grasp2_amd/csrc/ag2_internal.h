@@ -227,6 +227,7 @@ struct ag2_ctx {
   ag2::DevBuf d_gather;    // one process, several GPUs: the ranks' compact lists on the root's GPU (ag2_gather_begin)
   ag2::DevBuf d_xchg;      // ... and a rank's own list before the peer copy
   size_t gather_world = 0, gather_cap = 0;
+  std::vector<uint8_t> gather_delivered;  // per rank: ag2_gather_selected has completed since ag2_gather_begin
   const void* d_last_sel = nullptr;    // what the last ag2_detect selected from (d_sel or d_cluster) ...
   const unsigned* d_last_nsel = nullptr;  // ... and its count on the device
   ag2::DevBuf d_flags;     // uint32 flags / prefix for slot compaction
@@ -263,6 +264,18 @@ struct ag2_ctx {
   const ag2::FrameArgs* fm_args_dev = nullptr;  // device view of the page-locked per-frame scalars
   struct ag2_frame_state* fm = nullptr;         // owned by ag2_frame.hip
 
+  // hipFuncSetAttribute is per device: which of the large-dynamic-LDS kernels this context has prepared on ITS
+  // device (bits kAttr*); a process-wide flag left devices >= 1 without the attribute
+  unsigned func_attr_done = 0;
+  ag2::DevBuf d_sweep_prof;  // diagnostic only (AG2_SWEEP_PROF): per-phase cycle sums of the sweep kernels
+  // how the host waits for a kernel's flag in page-locked memory (ag2_set_wait_mode): 0 the stream
+  // (hipStreamSynchronize), 1 poll; spin_us: busy polling before the poller starts yielding its core
+  int wait_poll = 1;
+  int wait_spin_us = 50;
+  int64_t poll_fallbacks = 0;   // waits that polled 5 ms without the flag and went on to wait for the stream
+  int64_t poll_yields = 0;      // sched_yield calls of those waits
+  int64_t last_wait_us = 0, last_submit_us = 0;  // host time inside the last frame_wait / frame_submit
+
   ag2::LeNetDev net;
   ag2_counters cnt{};
   ag2_times times{};
@@ -271,6 +284,7 @@ struct ag2_ctx {
 namespace ag2 {
 
 int set_err(ag2_ctx* c, int code, const std::string& msg);
+enum { kAttrRender = 1u, kAttrLenetConv = 2u, kAttrLenetX3 = 4u, kAttrLenetX3b = 8u };
 #define AG2_HIP(c, expr)                                                                  \
   do {                                                                                    \
     hipError_t _e = (expr);                                                               \
@@ -287,6 +301,7 @@ constexpr size_t kPinSmall = 20480;
 // offsets in the small area of the sequence numbers a kernel's last workgroup writes behind its results for the
 // host to poll (wait_flag): k_topk's, k_bounds'
 constexpr size_t kPinDoneFlag = 16384, kPinBoundsFlag = 16384 + 64;  // (the first 16 KB: the extent partials)
+constexpr unsigned kPinFlags = hipHostMallocCoherent | hipHostMallocMapped;  // every block a kernel writes for the host to poll
 int pin_reserve(ag2_ctx* c, size_t bulk_bytes);
 inline char* pin_small(ag2_ctx* c) { return (char*)c->h_pin; }
 inline char* pin_bulk(ag2_ctx* c) { return (char*)c->h_pin + kPinSmall; }

@@ -607,6 +607,12 @@ int ag2_gather_begin(ag2_ctx* root, size_t world, size_t cap_records) {
   const size_t per = 16 + cap_records * sizeof(ag2_hypothesis);
   AG2_HIP(root, hipStreamSynchronize(root->stream));  // (a merge of the previous exchange may still read the buffer)
   AG2_HIP(root, root->d_gather.reserve(world * per));
+  // No rank has delivered yet: the headers say "empty list" and the merge refuses to run while one is missing
+  // (a rank that failed would otherwise leave the previous exchange's records in its place)
+  for (size_t r = 0; r < world; r++)
+    AG2_HIP(root, hipMemsetAsync((char*)root->d_gather.p + r * per, 0, 16, root->stream));
+  AG2_HIP(root, hipStreamSynchronize(root->stream));
+  root->gather_delivered.assign(world, 0);
   root->gather_world = world;
   root->gather_cap = cap_records;
   return 0;
@@ -626,6 +632,7 @@ int ag2_gather_selected(ag2_ctx* root, ag2_ctx* src, size_t rank) {
   else  // over xGMI; the runtime stages through the host when the devices have no peer access
     AG2_HIP(src, hipMemcpyPeerAsync(dst, root->device, src->d_xchg.p, src->device, per, src->stream));
   AG2_HIP(src, hipStreamSynchronize(src->stream));
+  root->gather_delivered[rank] = 1;  // (one byte per rank: the ranks' threads write distinct elements)
   return 0;
 }
 
@@ -633,6 +640,9 @@ int ag2_merge_gathered(ag2_ctx* root, ag2_hypothesis* selected, size_t cap, size
   if (!root || !n_selected) return AG2_ERR_ARG;
   (void)hipSetDevice(root->device);
   if (root->gather_world == 0) return set_err(root, AG2_ERR_STATE, "merge: no ag2_gather_begin");
+  for (size_t r = 0; r < root->gather_world; r++)
+    if (r >= root->gather_delivered.size() || !root->gather_delivered[r])
+      return set_err(root, AG2_ERR_STATE, "merge: rank " + std::to_string(r) + " has not delivered its list (ag2_gather_selected)");
   return merge_selected(root, root->d_gather.p, root->gather_world, root->gather_cap, selected, cap, n_selected, n_total);
 }
 

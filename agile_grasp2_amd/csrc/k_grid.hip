@@ -111,8 +111,15 @@ __global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ x
                                                     GridFromParts fp, int2* __restrict__ key,
                                                     unsigned* __restrict__ cell) {
   __shared__ GridDesc g_sh;
-  if (fp.done_flag && blockIdx.x == 0 && threadIdx.x == 0)  // (k_bounds is complete: tell the polling host)
+  // k_bounds is complete: tell the polling host.  Sound because (a) the partials and the flag live in a block
+  // allocated hipHostMallocCoherent (kPinFlags: fine-grained, not held in any device cache -- a store that has
+  // been acknowledged is in host memory) and (b) this kernel starts only after every store of k_bounds has been
+  // acknowledged (kernels of one stream run in order, a kernel's end waits for its memory operations).  The
+  // fence orders this thread's flag store behind that point at system scope.
+  if (fp.done_flag && blockIdx.x == 0 && threadIdx.x == 0) {
+    __threadfence_system();
     *reinterpret_cast<volatile unsigned*>(fp.done_flag) = fp.done_seq;
+  }
   if (fp.part) {  // frame mode (uniform): the description from the extent partials of k_bounds
     if (wave_id() == 0) {
       const GridDesc gd = grid_from_partials(fp);

@@ -847,14 +847,13 @@ int launch_render(ag2_ctx* c, const double* d_arena, const long long* d_off, con
                   size_t n_img, uint8_t* d_out, int max_p, const unsigned* d_n) {
   if (n_img == 0) return 0;
   const size_t lds = sizeof(ImgShared);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(c->func_attr_done & kAttrRender)) {  // (per context = per device)
     AG2_HIP(c, hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
     AG2_HIP(c, hipFuncSetAttribute((const void*)k_render_sorted<kSortedMaxBig, 14, 1024>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(SortedShared<kSortedMaxBig, 1024>)));
-    attr_set = true;
+    c->func_attr_done |= kAttrRender;
   }
   // images with at most kSparseMax points (nearly all) ...
   hipLaunchKernelGGL(k_render_sparse, dim3((int)std::min<size_t>(n_img, 256 * 6)), dim3(kImgThreads), 0,

@@ -349,11 +349,10 @@ int launch_lenet(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d_logits,
   LeNetDev& d = c->net;
   AG2_HIP(c, c->d_act1.reserve(n * (size_t)kFcK * 4));
   const size_t lds = sizeof(ConvShared);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(c->func_attr_done & kAttrLenetConv)) {
     AG2_HIP(c, hipFuncSetAttribute((const void*)k_lenet_conv,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    c->func_attr_done |= kAttrLenetConv;
   }
   if (d.use_x3) {  // bf16 matrix cores, operands split into three exact bf16 terms (k_lenet_x3.hip)
     const int rc = launch_lenet_conv_x3(c, d_images, n, c->d_act1.as<float>(), d_n);

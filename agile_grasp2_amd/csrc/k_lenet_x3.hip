@@ -769,18 +769,16 @@ int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d
                          const unsigned* d_n) {
   LeNetDev& d = c->net;
   const size_t lds = sizeof(X3Shared);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(c->func_attr_done & kAttrLenetX3)) {
     AG2_HIP(c, hipFuncSetAttribute((const void*)k_lenet_conv_x3,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    c->func_attr_done |= kAttrLenetX3;
   }
   if (d.use_bands) {  // (AG2_LENET_WHOLE=1 at weight load: one workgroup per image, for A/B)
-    static bool battr = false;
-    if (!battr) {
+    if (!(c->func_attr_done & kAttrLenetX3b)) {
       AG2_HIP(c, hipFuncSetAttribute((const void*)k_lenet_conv_x3b,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(X3Band)));
-      battr = true;
+      c->func_attr_done |= kAttrLenetX3b;
     }
     const int gridb = (int)std::min<size_t>(3 * n, 512);
     hipLaunchKernelGGL(k_lenet_conv_x3b, dim3(gridb), dim3(kBThreads), sizeof(X3Band), c->stream, d_images,

@@ -1373,7 +1373,7 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
   A.overflow = c->d_overflow.as<int>();
   A.min_z = c->min_z;
   A.flags = c->p.debug_flags & 1;
-  static DevBuf prof_buf;  // diagnostic only: per-phase cycle sums when AG2_SWEEP_PROF is set
+  DevBuf& prof_buf = c->d_sweep_prof;  // diagnostic only: per-phase cycle sums when AG2_SWEEP_PROF is set
   const bool want_prof = !c->fm_on && getenv("AG2_SWEEP_PROF") != nullptr;
   if (want_prof) {
     AG2_HIP(c, prof_buf.reserve(16 * 8));

@@ -247,6 +247,25 @@ int ag2_detect_frame_raw(ag2_ctx* c, const void* xyz, int xyz_on_device, size_t 
                          size_t* n_selected, size_t* n_scored, size_t* n_voxels);
 int ag2_get_frame_info(ag2_ctx* c, ag2_frame_info* out);
 
+/* How the host waits for results (no counterpart in the reference, which computes on the calling thread).
+ * The last kernel of a step writes its results and then a sequence number into coherent page-locked memory;
+ * the host can POLL that word instead of waiting for the stream, which returns ~10 us earlier per wait (two
+ * waits per detect step, one per frame).  Cost: the waiting thread occupies its core -- it spins for `spin_us`
+ * microseconds (default 50), then keeps polling but yields the core between looks (sched_yield), and after
+ * 5 ms falls back to hipStreamSynchronize.  A caller with more contexts than spare cores (ag2_pipe, one thread
+ * per device) should lower spin_us or turn polling off.
+ *   poll = 1 (default; AG2_POLL=0 in the environment changes the default), spin_us >= 0 (AG2_POLL_SPIN_US).
+ * Results are byte-identical in every mode. */
+int ag2_set_wait_mode(ag2_ctx* c, int poll, int spin_us);
+typedef struct ag2_wait_info {
+  int64_t poll, spin_us;
+  int64_t poll_fallbacks;   /* waits that polled 5 ms without seeing the flag and went on to wait for the stream */
+  int64_t poll_yields;      /* sched_yield calls made while polling */
+  int64_t last_submit_us;   /* host time inside the last ag2_submit_frame* (or the submit half of ag2_detect_frame*) */
+  int64_t last_wait_us;     /* host time inside the last ag2_wait_frame (or the wait half of ag2_detect_frame*) */
+} ag2_wait_info;
+int ag2_get_wait_info(ag2_ctx* c, ag2_wait_info* out);
+
 /* ---- the asynchronous form of the two frame entries (no counterpart in the reference, whose node handles one
  * cloud at a time, grasp_detection_node.cpp:69-95) ----
  * ag2_submit_frame[_raw] = ag2_detect_frame[_raw] up to, and not including, the wait for the results: a cloud
