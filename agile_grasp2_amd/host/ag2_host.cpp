@@ -4,6 +4,7 @@
 // include/agile_grasp2/ for the reference file:line each method mirrors.  No compute happens here
 // beyond preprocessing and glue: normals, frames, hand search, images and LeNet run on the GPU.
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <cmath>
 #include <cstdio>
@@ -755,7 +756,18 @@ Classifier::Classifier(const std::string& model_file, const std::string& trained
   std::string line;
   while (std::getline(l, line)) labels_.push_back(line);
   if (labels_.size() != 2) { err_ = "Number of labels is different from the output layer dimension."; return; }
+  static std::atomic<uint64_t> next_generation{0};
+  generation_ = ++next_generation;
   ok_ = true;
+}
+
+int Classifier::loadInto(ag2::Context& ctx) const {
+  if (!ok_ || !ctx.ok()) return AG2_ERR_STATE;
+  if (ctx.weights_generation == generation_) return 0;  // this context already holds these blobs, packed
+  const int rc = ag2_lenet_load(ctx.get(), blobs_[0].data(), blobs_[1].data(), blobs_[2].data(), blobs_[3].data(),
+                                blobs_[4].data(), blobs_[5].data(), blobs_[6].data(), blobs_[7].data());
+  ctx.weights_generation = rc ? 0 : generation_;
+  return rc;
 }
 
 void Classifier::setContext(std::shared_ptr<ag2::Context> ctx) {
@@ -772,10 +784,7 @@ bool Classifier::ensureLoaded() {
   }
   if (!ctx_->ok()) { err_ = "could not create a GPU context (no CPU fallback)"; return false; }
   if (!uploaded_) {
-    const int rc = ag2_lenet_load(ctx_->get(), blobs_[0].data(), blobs_[1].data(), blobs_[2].data(),
-                                  blobs_[3].data(), blobs_[4].data(), blobs_[5].data(), blobs_[6].data(),
-                                  blobs_[7].data());
-    if (rc) { err_ = ag2_last_error(ctx_->get()); return false; }
+    if (loadInto(*ctx_)) { err_ = ag2_last_error(ctx_->get()); return false; }
     uploaded_ = true;
   }
   return true;
@@ -839,6 +848,12 @@ bool set_param(GraspDetector::Params* p, const std::string& k, const std::string
   if (k == "workspace") { p->workspace = parse_list(v); return true; }
   if (k == "camera_pose") { p->camera_pose = parse_list(v); return true; }
   if (k == "gripper_width_range") { p->gripper_width_range = parse_list(v); return true; }
+  if (k == "tiling") {
+    if (v == "spatial" || v == "1") p->tiling = GraspDetector::Params::TILING_SPATIAL;
+    else if (v == "replicate" || v == "0") p->tiling = GraspDetector::Params::TILING_REPLICATE;
+    else { *err = "tiling must be replicate or spatial"; return false; }
+    return true;
+  }
   if (k == "devices") {
     p->devices.clear();
     for (double d : parse_list(v)) p->devices.push_back((int)d);
@@ -1028,9 +1043,17 @@ std::vector<GraspHypothesis> GraspDetector::detectImpl(const CloudCamera& cloud_
   }
   ag2_ctx* c = ctx->get();
   int rc = 0;
+  // The N-device forms (Params::devices, PREDICTION, index samples): with spatial tiles no device -- the first
+  // included -- holds the whole cloud, so the upload below is left out.
+  const bool index_samples = !samples_xyz && !use_incoming_samples_;
+  const bool spatial = p_.tiling == Params::TILING_SPATIAL && p_.antipodal_mode == PREDICTION && index_samples;
+  const bool multi = p_.devices.size() > 1 && p_.antipodal_mode == PREDICTION && index_samples &&
+                     !cloud_cam.getSampleIndices().empty();
   const bool same_cloud = c == resident_ctx_ && cloud_cam.getCloudProcessed().get() == resident_cloud_ &&
                           cloud_cam.getCloudProcessed()->size() == resident_n_;
-  if (same_cloud && cloud_is_resident && resident_normals_) {
+  if (multi && spatial) {
+    resident_ctx_ = nullptr;  // (the first device will hold its tile, not this cloud)
+  } else if (same_cloud && cloud_is_resident && resident_normals_) {
     // ImportanceSampling re-entry: grid and normals of this cloud are already in the context
   } else if (same_cloud && !cloud_is_resident && !resident_uploaded_here_) {
     // preprocessPointCloud left exactly this cloud (and its grid) in the context
@@ -1048,6 +1071,10 @@ std::vector<GraspHypothesis> GraspDetector::detectImpl(const CloudCamera& cloud_
   const Matrix3Xd& sample_mat = samples_xyz ? *samples_xyz : cloud_cam.getSamples();
   const size_t s = use_samples ? (size_t)sample_mat.cols() : cloud_cam.getSampleIndices().size();
   std::vector<int32_t> idx(cloud_cam.getSampleIndices().begin(), cloud_cam.getSampleIndices().end());
+  if (spatial && !use_samples) {  // the order tiles shard: the same for every number of devices, one included
+    int axis = 0;
+    idx = orderSamplesAlongLongestAxis(cloud_cam, idx, &axis);
+  }
   const int32_t* pidx = use_samples ? nullptr : idx.data();
   const double* pxyz = use_samples ? sample_mat.data() : nullptr;
   const double dummy_xyz[3] = {0.0, 0.0, 0.0};
@@ -1065,12 +1092,10 @@ std::vector<GraspHypothesis> GraspDetector::detectImpl(const CloudCamera& cloud_
                 classifier_ ? classifier_->error().c_str() : "not constructed");
         return out;
       }
-      rc = ag2_lenet_load(c, classifier_->blob(0).data(), classifier_->blob(1).data(), classifier_->blob(2).data(),
-                          classifier_->blob(3).data(), classifier_->blob(4).data(), classifier_->blob(5).data(),
-                          classifier_->blob(6).data(), classifier_->blob(7).data());
+      rc = classifier_->loadInto(*ctx);  // (packed once per context and classifier, not once per call)
       if (!rc) rc = ag2_set_min_inliers(c, min_inliers);  // clustering between threshold and top-k, on the GPU
-      if (!rc && p_.devices.size() > 1 && !use_samples && s > 0) {
-        if (!detectOnDevices(c, cloud_cam, idx, do_prune, min_inliers, &recs, &n)) {
+      if (!rc && multi && s > 0) {
+        if (!detectOnDevices(cloud_cam, idx, do_prune, min_inliers, &recs, &n)) {
           fprintf(stderr, "GraspDetector::detectGraspPoses: %s\n", err_.c_str());
           return out;
         }
@@ -1135,12 +1160,8 @@ std::vector<GraspHypothesis> GraspDetector::detectGraspPosesInFrame(const PointC
   }
   ag2_ctx* c = ctx->get();
   int rc = 0;
-  if (weights_in_ctx_ != c) {  // once per context: packing the weights is host work of milliseconds
-    rc = ag2_lenet_load(c, classifier_->blob(0).data(), classifier_->blob(1).data(), classifier_->blob(2).data(),
-                        classifier_->blob(3).data(), classifier_->blob(4).data(), classifier_->blob(5).data(),
-                        classifier_->blob(6).data(), classifier_->blob(7).data());
-    weights_in_ctx_ = rc ? nullptr : c;
-  }
+  rc = classifier_->loadInto(*ctx);  // once per (context, classifier): the context remembers (a context that
+                                     // contextFor() re-creates starts without weights, whatever its address)
   const int hs_inliers = handle_search_.getMinInliers();
   if (!rc) rc = ag2_set_min_inliers(c, hs_inliers > 0 ? hs_inliers : 0);  // (the clustering is part of the captured sequence)
   const size_t cap = std::max<size_t>(1, (size_t)num_samples_ * (size_t)p_.num_orientations);
@@ -1163,21 +1184,102 @@ std::vector<GraspHypothesis> GraspDetector::detectGraspPosesInFrame(const PointC
   return out;
 }
 
-// Params::devices: the sample list cut into contiguous ranges, one per device; every device holds the whole
-// cloud (a 300 k-point cloud is 4.8 MB) and runs grid, normals and detect for its range with the samples'
-// positions in the WHOLE list as slot base -- so its hypotheses are those of the one-device run
+// ---- Params::devices: N GPUs from the one process of the node ---------------------------------------------------
+// Replicated cloud (TILING_REPLICATE): every device holds the whole cloud (a 300 k-point cloud is 4.8 MB) and takes
+// a contiguous range of the sample list.  Spatial tiles (TILING_SPATIAL, BASELINE configuration 4): the list --
+// already in ascending order along the cloud's longest axis -- is cut into ranges of equal summed neighbour
+// counts and every device holds only the points of its samples' interval +- the halo, binned against the whole
+// cloud's minimum: grid + normals shard as well.  Either way a device runs grid, normals and detect for its range
+// with the samples' positions in the WHOLE list as slot base, so its hypotheses are those of the one-device run
 // (hand_search.cpp:194-228: no state crosses samples; the draws are keyed by the slot).  The ranks leave their
-// scored candidates above the threshold on the first device (ag2_gather_selected) and that device clusters
-// (when min_inliers > 0) and takes the top num_selected over the concatenation, which is in sample order
-// (grasp_detector.cpp:228-252).  `root` (device 0's context) already holds cloud, normals and weights.
-bool GraspDetector::detectOnDevices(ag2_ctx* root, const CloudCamera& cloud_cam, const std::vector<int32_t>& idx,
-                                    bool do_prune, int min_inliers, std::vector<ag2_hypothesis>* recs, size_t* n) {
-  const size_t G = p_.devices.size(), s = idx.size();
+// scored candidates above the threshold on the first device (ag2_gather_selected: peer copies over xGMI) and that
+// device clusters (when min_inliers > 0) and takes the top num_selected over the concatenation, which is in
+// sample order (grasp_detector.cpp:228-252).  LeNet weights are packed into a device's context ONCE
+// (Classifier::loadInto), not once per call.
+namespace {
+
+// float per-axis minimum over the finite points: the unsplit run's grid origin (sharding.cloud_origin)
+bool cloud_extent(const PointCloudRGB& cloud, float mn[3], float mx[3]) {
+  bool any = false;
+  for (const ag2::PointXYZRGBA& p : cloud.points) {
+    if (!(std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z))) continue;
+    const float v[3] = {p.x, p.y, p.z};
+    for (int a = 0; a < 3; a++) {
+      mn[a] = any ? std::min(mn[a], v[a]) : v[a];
+      mx[a] = any ? std::max(mx[a], v[a]) : v[a];
+    }
+    any = true;
+  }
+  return any;
+}
+inline float coord(const ag2::PointXYZRGBA& p, int axis) { return axis == 0 ? p.x : (axis == 1 ? p.y : p.z); }
+
+// sharding.sample_costs + balanced_bounds: G + 1 boundaries of contiguous ranges of the ordered sample list with
+// (nearly) equal summed cost, the cost of a sample being the number of cloud points whose coordinate along the
+// axis lies within nn_radius_hands of its own -- the 1-D marginal of K2, which drives the hand sweep (SURVEY.md
+// section 8e: balance on sum K2, not on the sample count).  Every rank gets a sample while there are enough.
+std::vector<size_t> balanced_bounds(const PointCloudRGB& cloud, const std::vector<int32_t>& ordered, int axis,
+                                    double radius, size_t G) {
+  const size_t n = ordered.size();
+  std::vector<size_t> b(G + 1, 0);
+  if (n == 0) return b;
+  if (n <= G) {
+    for (size_t g = 0; g <= G; g++) b[g] = std::min(g, n);
+    return b;
+  }
+  std::vector<double> xs;
+  xs.reserve(cloud.points.size());
+  for (const ag2::PointXYZRGBA& p : cloud.points) {
+    const double x = (double)coord(p, axis);
+    if (std::isfinite(x)) xs.push_back(x);
+  }
+  std::sort(xs.begin(), xs.end());
+  std::vector<double> cum(n);
+  double run = 0.0;
+  for (size_t i = 0; i < n; i++) {
+    const double sx = (double)coord(cloud.points[(size_t)ordered[i]], axis);
+    const double cost = (double)(std::lower_bound(xs.begin(), xs.end(), sx + radius) -
+                                 std::lower_bound(xs.begin(), xs.end(), sx - radius));
+    run += std::max(cost, 1.0);
+    cum[i] = run;
+  }
+  b[G] = n;
+  for (size_t g = 1; g < G; g++) {
+    const double target = cum[n - 1] * (double)g / (double)G;
+    b[g] = (size_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin()) + 1;
+  }
+  for (size_t g = 1; g < G; g++) b[g] = std::min(std::max(b[g], b[g - 1] + 1), n - (G - g));
+  return b;
+}
+
+}  // namespace
+
+std::vector<int32_t> GraspDetector::orderSamplesAlongLongestAxis(const CloudCamera& cloud_cam,
+                                                                 const std::vector<int32_t>& idx, int* axis) {
+  const PointCloudRGB& cloud = *cloud_cam.getCloudProcessed();
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  *axis = 0;
+  if (cloud_extent(cloud, mn, mx))
+    for (int a = 1; a < 3; a++)
+      if (mx[a] - mn[a] > mx[*axis] - mn[*axis]) *axis = a;
+  std::vector<int32_t> ordered(idx);
+  const int ax = *axis;
+  std::stable_sort(ordered.begin(), ordered.end(), [&](int32_t a, int32_t b) {
+    return coord(cloud.points[(size_t)a], ax) < coord(cloud.points[(size_t)b], ax);
+  });
+  return ordered;
+}
+
+bool GraspDetector::detectOnDevices(const CloudCamera& cloud_cam, const std::vector<int32_t>& idx, bool do_prune,
+                                    int min_inliers, std::vector<ag2_hypothesis>* recs, size_t* n) {
+  const size_t s = idx.size();
+  const bool spatial = p_.tiling == Params::TILING_SPATIAL;
+  const size_t G = std::min(p_.devices.size(), std::max<size_t>(s, 1));  // (fewer samples than devices: the last ones idle)
   const int n_cams = std::max(1, cloud_cam.getCameraSource().rows());
-  if (peers_.size() != G - 1 || peers_cams_ != n_cams) {
+  if (peers_.size() != p_.devices.size() - 1 || peers_cams_ != n_cams) {
     peers_.clear();
     const ag2_params ap = abiParams(n_cams);
-    for (size_t g = 1; g < G; g++) {
+    for (size_t g = 1; g < p_.devices.size(); g++) {
       std::shared_ptr<ag2::Context> pc(new ag2::Context(ap, p_.devices[g]));
       if (!pc->ok()) {
         err_ = "could not create a GPU context on device " + std::to_string(p_.devices[g]) + " (no CPU fallback)";
@@ -1188,37 +1290,95 @@ bool GraspDetector::detectOnDevices(ag2_ctx* root, const CloudCamera& cloud_cam,
     }
     peers_cams_ = n_cams;
   }
-  std::vector<ag2_ctx*> cs(G, root);
-  for (size_t g = 1; g < G; g++) cs[g] = peers_[g - 1]->get();
+  std::vector<ag2::Context*> cx(G, ctx_.get());
+  for (size_t g = 1; g < G; g++) cx[g] = peers_[g - 1].get();
+  ag2_ctx* root = cx[0]->get();
+  const PointCloudRGB& cloud = *cloud_cam.getCloudProcessed();
+  const size_t n_pts = cloud.points.size();
+  const MatrixXi& src = cloud_cam.getCameraSource();
+  const Matrix3Xd& nrm = cloud_cam.getNormals();
+  const bool has_src = src.cols() == (int)n_pts && n_pts > 0;
+  const bool has_n = (size_t)nrm.cols() == n_pts && n_pts > 0;
+  // the ranges of the sample list, and (spatial) the interval of the axis every rank has to hold
   std::vector<size_t> lo(G + 1);
+  int axis = 0;
+  float origin[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  if (spatial) {
+    if (cloud_extent(cloud, origin, mx))
+      for (int a = 1; a < 3; a++)
+        if (mx[a] - origin[a] > mx[axis] - origin[axis]) axis = a;
+    lo = balanced_bounds(cloud, idx, axis, p_.nn_radius_hands, G);
+  } else {
+    for (size_t g = 0; g <= G; g++) lo[g] = s * g / G;
+  }
   size_t longest = 0;
-  for (size_t g = 0; g <= G; g++) lo[g] = s * g / G;
   for (size_t g = 0; g < G; g++) longest = std::max(longest, lo[g + 1] - lo[g]);
   const size_t cap_records = std::max<size_t>(1, longest * (size_t)p_.num_orientations);  // every slot: never cut
   if (ag2_gather_begin(root, G, cap_records)) {
     err_ = ag2_last_error(root);
     return false;
   }
+  // sharding.tile_halo: what a sample reads of the cloud (its hand neighbourhood, those points' normals), plus
+  // the rounding of the f32 coordinate differences the radius tests see
+  const double halo = std::max(p_.nn_radius_hands, p_.nn_radius_taubin) + cx[0]->params().normals_radius + 1e-5;
   std::vector<int> rcs(G, 0);
   std::vector<std::string> msgs(G);
+  tile_points_.assign(G, 0);
   auto run = [&](size_t g) {
-    ag2_ctx* c = cs[g];
+    ag2::Context& ctx = *cx[g];
+    ag2_ctx* c = ctx.get();
     int rc = 0;
-    if (g > 0) {  // (the root was set up by the caller)
-      rc = HandSearch::uploadCloud(c, cloud_cam);
+    const size_t len = lo[g + 1] - lo[g];
+    std::vector<int32_t> local(idx.begin() + (long)lo[g], idx.begin() + (long)lo[g + 1]);
+    if (spatial) {
+      // sharding.tile_points: the points of [min x - halo, max x + halo] of this rank's samples, in their original
+      // relative order (an order-preserving subset keeps the canonical (cell, index) neighbour order)
+      double xlo = 0.0, xhi = 0.0;
+      for (size_t i = 0; i < len; i++) {
+        const double x = (double)coord(cloud.points[(size_t)local[i]], axis);
+        xlo = i ? std::min(xlo, x) : x;
+        xhi = i ? std::max(xhi, x) : x;
+      }
+      xlo -= halo;
+      xhi += halo;
+      std::vector<int32_t> new_index(n_pts, -1);
+      std::vector<float> xyz;
+      std::vector<int32_t> cam;
+      std::vector<double> nn;
+      size_t m = 0;
+      for (size_t i = 0; i < n_pts; i++) {
+        const double x = (double)coord(cloud.points[i], axis);
+        if (!(x >= xlo && x <= xhi)) continue;  // (NaN compares false: dropped, never a neighbour)
+        new_index[i] = (int32_t)m++;
+        xyz.push_back(cloud.points[i].x);
+        xyz.push_back(cloud.points[i].y);
+        xyz.push_back(cloud.points[i].z);
+        if (has_src)
+          for (int k = 0; k < n_cams; k++) cam.push_back(src(k, (int)i));
+        if (has_n)
+          for (int k = 0; k < 3; k++) nn.push_back(nrm(k, (int)i));
+      }
+      for (size_t i = 0; i < len; i++) local[i] = new_index[(size_t)local[i]];
+      tile_points_[g] = m;
+      rc = ag2_set_grid_origin(c, origin);
       if (!rc)
-        rc = ag2_lenet_load(c, classifier_->blob(0).data(), classifier_->blob(1).data(), classifier_->blob(2).data(),
-                            classifier_->blob(3).data(), classifier_->blob(4).data(), classifier_->blob(5).data(),
-                            classifier_->blob(6).data(), classifier_->blob(7).data());
-      if (!rc) rc = ag2_set_min_inliers(c, min_inliers);
+        rc = ag2_set_cloud(c, xyz.data(), m, 12, has_src ? cam.data() : nullptr, n_cams, has_n ? nn.data() : nullptr);
+      if (!rc && !has_n) rc = ag2_compute_normals(c);
+    } else if (g > 0) {  // (replicated cloud: the first device was set up by the caller)
+      tile_points_[g] = n_pts;
+      rc = HandSearch::uploadCloud(c, cloud_cam);
+    } else {
+      tile_points_[g] = n_pts;
     }
+    if (!rc) rc = classifier_->loadInto(ctx);
+    if (!rc) rc = ag2_set_min_inliers(c, min_inliers);
     size_t ns = 0, nsc = 0;
     const int32_t dummy = 0;
-    const size_t len = lo[g + 1] - lo[g];
     if (!rc)  // selected == NULL, cap == 0: no local read-back, the merge selects
-      rc = ag2_detect(c, len ? idx.data() + lo[g] : &dummy, nullptr, len, (uint64_t)lo[g], p_.seed, do_prune ? 1 : 0,
+      rc = ag2_detect(c, len ? local.data() : &dummy, nullptr, len, (uint64_t)lo[g], p_.seed, do_prune ? 1 : 0,
                       nullptr, 0, &ns, nullptr, 0, &nsc);
     if (!rc) rc = ag2_gather_selected(root, c, g);
+    if (spatial) (void)ag2_set_grid_origin(c, nullptr);  // (the context goes back to binning against its own cloud)
     rcs[g] = rc;
     if (rc) msgs[g] = ag2_last_error(c);
   };
@@ -1226,6 +1386,7 @@ bool GraspDetector::detectOnDevices(ag2_ctx* root, const CloudCamera& cloud_cam,
   for (size_t g = 1; g < G; g++) th.emplace_back(run, g);
   run(0);
   for (std::thread& t : th) t.join();
+  if (spatial) resident_ctx_ = nullptr;  // (the first device holds a tile now)
   for (size_t g = 0; g < G; g++)
     if (rcs[g]) {
       err_ = "device " + std::to_string(p_.devices[g]) + " (rank " + std::to_string(g) + "): " + msgs[g];

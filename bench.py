@@ -137,6 +137,57 @@ def cpu_baseline(xyz, ws, idx, R, weights, budget_s=12.0, max_reps=400, threads=
     }
 
 
+def validate_against_unsplit(capi, device, prm, weights, xyz_full, ordered, seed, merged, n_total, scored_per_step):
+    """N > 1 self-validation (untimed, rank 0, after the other ranks have left): the UNSPLIT cloud with all the
+    ranks' samples (the ordered list the tiles were cut from) on this one GPU, against what the last timed step's
+    exchange + merge produced.  hand_search.cpp:194-228 (samples are independent, results concatenate in sample
+    order) and grasp_detector.cpp:228-252 (threshold, top-k) say what must hold:
+      records_byte_equal   every merged record is a scored record of the unsplit run, every field but the score
+                           byte for byte;
+      scores_within_tol    LeNet scores within 2e-4 max|score| + 2e-3 (ip1's split-K follows the batch size: a
+                           tile's scores may differ from the unsplit run's in the last bits);
+      selection_ok         the merged top-k holds every record the unsplit scores demand and none they rule out
+                           (agile_grasp2_amd/selection_check.py: only records within 2 tol of the threshold or of
+                           the cut may differ), in descending score order;
+      counts_ok            the ranks' scored hypotheses sum to the unsplit run's, the merged list's length lies
+                           between the records certainly above and possibly above the threshold.
+    A first hardware record of an N-GPU run therefore says by itself whether its result is the reference's."""
+    import torch
+    from agile_grasp2_amd.selection_check import check_selection
+    du = capi.Detector(device=device, **prm)
+    du.set_stream(torch.cuda.current_stream().cuda_stream)
+    du.lenet_load(weights)
+    du.set_cloud(xyz_full)
+    du.compute_normals()
+    _, uall = du.detect(sample_idx=ordered, seed=seed, do_prune=True)
+    du.close()
+    out = {"unsplit_scored": int(len(uall)), "ranks_scored": int(round(scored_per_step)), "merged_records": int(n_total),
+           "merged_selected": int(len(merged))}
+    tol = 2e-4 * float(np.abs(uall["score"]).max() if len(uall) else 0.0) + 2e-3
+    thr, k = float(prm["min_score_diff"]), int(prm["num_selected"])
+    key = {(int(h["sample_slot"]), int(h["orientation"])): i for i, h in enumerate(uall)}
+    fields = [f for f in uall.dtype.names if f not in ("score", "full_antipodal", "reserved")]
+    same, close = True, True
+    for h in merged:
+        i = key.get((int(h["sample_slot"]), int(h["orientation"])))
+        if i is None:
+            same = False
+            continue
+        same = same and all(np.array_equal(h[f], uall[i][f]) for f in fields)
+        close = close and abs(float(h["score"]) - float(uall[i]["score"])) <= tol
+    out["records_byte_equal"], out["scores_within_tol"] = bool(same), bool(close)
+    try:
+        chk = check_selection(merged, uall, thr, k, tol, max_uncertain=max(12, len(uall) // 100), tag="N > 1 merge")
+        out["selection_ok"], out["selection"] = True, chk
+    except AssertionError as e:
+        out["selection_ok"], out["selection_error"] = False, str(e)[:300]
+    lo, hi = int((uall["score"] >= thr + 2 * tol).sum()), int((uall["score"] >= thr - 2 * tol).sum())
+    out["counts_ok"] = bool(out["ranks_scored"] == len(uall) and lo <= n_total <= hi)
+    out["ok"] = bool(same and close and out["selection_ok"] and out["counts_ok"])
+    out["tol"] = tol
+    return out
+
+
 def stream_legs(seed, n_frames, n_warm, S=None, only=None, host_leg=True):
     """BASELINE.json configuration 5: `n_frames` (+ n_warm untimed) RAW frames of one drifting tabletop scene
     (~765 000 points each, ~300 000 voxels of 3 mm) through ag2_detect_frame_raw -- workspace filter, voxel
@@ -439,7 +490,8 @@ def main():
     from agile_grasp2_amd import sharding
     prm = launch_params(ws, R)
     n_cloud = xyz.shape[0]
-    origin, slot_base, tile_note = None, 0, None
+    xyz_full = xyz
+    origin, slot_base, tile_note, ordered = None, 0, None, None
     if dist_on:
         # spatial tiles: same scene and same N x S samples on every rank, cut by x
         axis = sharding.longest_axis(xyz)
@@ -563,6 +615,9 @@ def main():
     if rank != 0:
         dist.destroy_process_group()
         return
+    if dist_on:
+        per_rank["matches_unsplit"] = validate_against_unsplit(capi, local_rank, prm, weights, xyz_full, ordered, args.seed,
+                                                              xch["merged"], int(xch["n_total"]), total_scored / args.steps)
 
     # Untimed diagnostic pass: the measured path culls stencil rows by the sphere and the crop slab
     # and so never visits all K2 radius neighbours; the roofline's algorithmic bytes are defined on

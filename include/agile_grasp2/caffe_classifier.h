@@ -38,6 +38,10 @@ class Classifier {
   void setContext(std::shared_ptr<ag2::Context> ctx);
   const std::vector<float>& blob(int i) const { return blobs_[i]; }
   const std::vector<std::string>& labels() const { return labels_; }
+  // process-unique id of this object's (immutable) blob set: what a context remembers having packed
+  uint64_t generation() const { return generation_; }
+  // ag2_lenet_load of the blobs into `ctx` unless that context already holds THIS classifier's weights
+  int loadInto(ag2::Context& ctx) const;
 
  private:
   bool ensureLoaded();
@@ -45,6 +49,7 @@ class Classifier {
   std::string err_;
   std::vector<std::string> labels_;
   std::vector<float> blobs_[8];
+  uint64_t generation_ = 0;
   std::shared_ptr<ag2::Context> ctx_;
 };
 

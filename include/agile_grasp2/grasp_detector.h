@@ -58,6 +58,16 @@ class GraspDetector {
     // scored candidates on the first device (peer copies over xGMI) and clusters / selects there
     // (grasp_detector.cpp:228-252).  The same device may appear more than once.  Empty: {device}.
     std::vector<int> devices;
+    // How `devices` share the work.  TILING_REPLICATE (default): every device holds the whole cloud and takes a
+    // contiguous range of the sample list.  TILING_SPATIAL (BASELINE configuration 4, "the cloud shards by
+    // spatial tile"): the sample list is put in ascending order along the cloud's longest axis ONCE -- for any
+    // number of devices, one included, so the result does not depend on it --, cut into contiguous ranges of
+    // equal summed neighbour counts, and every device holds only the points of its samples' interval +- the halo
+    // (nn_radius_hands + normals radius), binned against the whole cloud's minimum (ag2_set_grid_origin): grid
+    // and normals shard too.  The hypotheses are those of one device running the ordered list
+    // (hand_search.cpp:194-228: no state crosses samples).
+    enum { TILING_REPLICATE = 0, TILING_SPATIAL = 1 };
+    int tiling = TILING_REPLICATE;
     // "name=value" lines ('#' comments); vectors as "[a, b, c]".  Unknown names are an error.
     static bool fromKeyValueText(const std::string& text, Params* out, std::string* err);
     // <param name=".." value=".."/> and <rosparam param=".."> [..] </rosparam> of a roslaunch file
@@ -107,6 +117,8 @@ class GraspDetector {
   // not in the reference: the camera poses detectGraspPoses hands to the hand search
   // (grasp_detector.cpp:108-137: the launch file's camera_pose, else the 2-camera Baxter defaults)
   void cameraPoses(ag2::Matrix4d* left, ag2::Matrix4d* right) const;
+  // points every device of the last N-device run held (TILING_SPATIAL: its tile; else the whole cloud)
+  const std::vector<size_t>& lastTilePoints() const { return tile_points_; }
   const ag2_times& lastStageTimes() const { return times_; }
   const ag2_counters& lastCounters() const { return counters_; }
   const std::string& lastError() const { return err_; }
@@ -127,8 +139,11 @@ class GraspDetector {
   std::shared_ptr<ag2::Context> contextFor(int n_cams);
   ag2_params abiParams(int n_cams) const;
   // the multi-GPU form of step 1 - 5 (Params::devices); false: error (err_ says what)
-  bool detectOnDevices(ag2_ctx* root, const CloudCamera& cloud_cam, const std::vector<int32_t>& idx, bool do_prune,
+  bool detectOnDevices(const CloudCamera& cloud_cam, const std::vector<int32_t>& idx, bool do_prune,
                        int min_inliers, std::vector<ag2_hypothesis>* recs, size_t* n);
+  // Params::tiling == TILING_SPATIAL: the sample list in ascending order along `*axis` (the cloud's longest)
+  static std::vector<int32_t> orderSamplesAlongLongestAxis(const CloudCamera& cloud_cam, const std::vector<int32_t>& idx,
+                                                           int* axis);
   bool preprocessOnDevice(CloudCamera& cloud_cam);
 
   Params p_;
@@ -142,8 +157,8 @@ class GraspDetector {
   HandleSearch handle_search_;
   std::shared_ptr<ag2::Context> ctx_;
   int ctx_cams_ = 0;
-  const ag2_ctx* weights_in_ctx_ = nullptr;          // detectGraspPosesInFrame: the context that holds the LeNet weights
   std::vector<std::shared_ptr<ag2::Context>> peers_;  // contexts of Params::devices[1 ...]
+  std::vector<size_t> tile_points_;
   int peers_cams_ = 0;
   // cloud left in the context by preprocessPointCloud: detectGraspPoses does not upload it again
   const void* resident_cloud_ = nullptr;

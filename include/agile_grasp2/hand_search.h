@@ -24,6 +24,9 @@ class Context {
   ag2_ctx* get() const { return c_; }
   bool ok() const { return c_ != nullptr; }
   const ag2_params& params() const { return p_; }
+  // Which Classifier's blobs ag2_lenet_load last packed into this context (Classifier::generation(); 0 = none):
+  // packing is 14.5 MB of host work + H2D, done once per (context, classifier), not once per call.
+  uint64_t weights_generation = 0;
  private:
   ag2_ctx* c_;
   ag2_params p_;

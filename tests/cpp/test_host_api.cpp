@@ -282,11 +282,26 @@ static int run_modes(const char* cloud_path, const char* idx_path, const char* p
   CloudCamera cc = nrm.empty() ? CloudCamera(cloud, (int)cloud->size()) : CloudCamera(cloud_n, (int)cloud_n->size());
   cc.setSampleIndices(std::vector<int>(idx.begin(), idx.end()));
   GraspDetector det(prm);
-  const std::vector<GraspHypothesis> hands = det.detectGraspPoses(cc);
+  std::vector<GraspHypothesis> hands = det.detectGraspPoses(cc);
   if (!det.lastError().empty()) {
     fprintf(stderr, "detect: %s\n", det.lastError().c_str());
     return 3;
   }
+  // a second call on the same detector (contexts, packed weights and peers are reused): the same hands
+  const std::vector<GraspHypothesis> again = det.detectGraspPoses(cc);
+  if (again.size() != hands.size()) {
+    fprintf(stderr, "second call: %zu hands, first %zu\n", again.size(), hands.size());
+    return 4;
+  }
+  for (size_t i = 0; i < hands.size(); i++)
+    if (again[i].getSampleSlot() != hands[i].getSampleSlot() || again[i].getOrientation() != hands[i].getOrientation() ||
+        again[i].getScore() != hands[i].getScore()) {
+      fprintf(stderr, "second call differs at hand %zu\n", i);
+      return 4;
+    }
+  printf("tile_points");
+  for (size_t m : det.lastTilePoints()) printf(" %zu", m);
+  printf("\n");
   std::ofstream out(out_path, std::ios::binary);
   const int64_t n = (int64_t)hands.size();
   put(out, &n, 1);

@@ -266,14 +266,23 @@ def test_cpp_detect_modes_none_and_geometric(tmp_path, mode, min_inliers):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tiling", ["replicate", "spatial"])
 @pytest.mark.parametrize("min_inliers", [0, 1])
-def test_cpp_detect_on_several_devices_equals_one_device(tmp_path, small_scene, min_inliers):
+def test_cpp_detect_on_several_devices_equals_one_device(tmp_path, small_scene, min_inliers, tiling):
     """GraspDetector::Params::devices: the C++ host's own path to N GPUs -- one context and one host thread per
     entry, the sample list cut into contiguous ranges, the ranks' scored candidates gathered on the first device
     (ag2_gather_selected: a device-to-device copy here, a peer copy over xGMI between GPUs), clustering and
     top-k there.  devices = [0, 0, 0] on the one GPU of the box against the one-context run: the same hands,
     field for field; scores within the LeNet tolerance (ip1's split-K follows the batch size, so the last bits
-    of a score may differ between a third of the list and the whole list)."""
+    of a score may differ between a third of the list and the whole list).
+    tiling = spatial (BASELINE configuration 4 from C++): the sample list ordered along the cloud's longest axis
+    -- for one device as for three --, ranges of equal summed neighbour counts, every device holding only its
+    interval + halo, binned against the whole cloud's minimum; additionally against the oracle run on the list
+    sharding.order_samples_by_x gives (the C++ order, cut and tiles are sharding.py's), and every tile smaller
+    than the cloud.  Each run calls detectGraspPoses twice on one detector (packed weights, contexts and peers
+    are reused): identical hands."""
+    from agile_grasp2_amd import sharding
+    from oracle import api
     tmp = str(tmp_path)
     exe = build_driver(tmp)
     xyz, ws, idx = small_scene
@@ -284,15 +293,16 @@ def test_cpp_detect_on_several_devices_equals_one_device(tmp_path, small_scene, 
     xyz.astype("<f4").tofile(os.path.join(tmp, "cloud.f32"))
     idx.astype("<i4").tofile(os.path.join(tmp, "idx.i32"))
     dt = np.dtype([("slot", "<i4"), ("orient", "<i4"), ("full", "<i4"), ("half", "<i4"), ("score", "<f8"), ("bottom", "<f8", 3)])
-    out = {}
+    out, tiles = {}, {}
     for tag, extra in (("one", ""), ("three", "devices = [0, 0, 0]\n")):
         open(os.path.join(tmp, f"params_{tag}.txt"), "w").write(
-            params_text(ws, wpath, lpath, 5) + f"min_inliers = {min_inliers}\n" + extra)
+            params_text(ws, wpath, lpath, 5) + f"min_inliers = {min_inliers}\ntiling = {tiling}\n" + extra)
         outp = os.path.join(tmp, f"out_{tag}.bin")
         r = subprocess.run([exe, "--modes", os.path.join(tmp, "cloud.f32"), os.path.join(tmp, "idx.i32"),
                             os.path.join(tmp, f"params_{tag}.txt"), outp], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         out[tag] = np.frombuffer(open(outp, "rb").read(), dtype=dt, offset=8)
+        tiles[tag] = [int(v) for line in r.stdout.splitlines() if line.startswith("tile_points") for v in line.split()[1:]]
     a, b = out["one"], out["three"]
     assert len(a) == len(b) and len(a) > (5 if min_inliers == 0 else 1)
     ka, kb = np.lexsort((a["orient"], a["slot"])), np.lexsort((b["orient"], b["slot"]))
@@ -301,6 +311,29 @@ def test_cpp_detect_on_several_devices_equals_one_device(tmp_path, small_scene, 
     tol = 1e-4 * np.abs(a["score"]).max() + 2e-3
     assert np.abs(a["score"][ka] - b["score"][kb]).max() <= tol
     assert np.all(np.diff(b["score"]) <= 0)   # the merge's own order: score descending
+    assert len(tiles["three"]) == 3 and tiles["one"] == []
+    if tiling == "replicate":
+        assert tiles["three"] == [xyz.shape[0]] * 3
+        return
+    # spatial tiles: smaller than the cloud, and exactly sharding.py's
+    axis = sharding.longest_axis(xyz)
+    ordered = sharding.order_samples_by_x(xyz, idx, axis)
+    bounds = sharding.balanced_bounds(sharding.sample_costs(xyz, ordered, 0.1, axis), 3)
+    halo = sharding.tile_halo(0.1, 0.01, 0.01)
+    want_tiles = [len(sharding.tile_points(xyz, ordered, r, 3, halo, axis, bounds)[0]) for r in range(3)]
+    assert tiles["three"] == want_tiles and max(want_tiles) < xyz.shape[0]
+    if min_inliers == 0:   # the hands are those of the oracle on the ordered list (slot = position in it)
+        prm = scene_params(ws, min_score_diff=-1e30, num_selected=1000)
+        o = api.Oracle(**dict(prm, num_threads=4))
+        o.set_cloud(xyz)
+        o.compute_normals()
+        o.lenet_load(w)
+        osel, oall = o.detect(sample_idx=ordered, seed=5, do_prune=True)
+        assert len(osel) == len(b)
+        ko = np.lexsort((osel["orientation"], osel["sample_slot"]))
+        assert np.array_equal(osel["sample_slot"][ko], b["slot"][kb]) and np.array_equal(osel["orientation"][ko], b["orient"][kb])
+        assert np.array_equal(osel["bottom"][ko], b["bottom"][kb])
+        assert np.abs(osel["score"][ko] - b["score"][kb]).max() <= 2e-4 * np.abs(osel["score"]).max() + 2e-3
 
 
 @pytest.mark.gpu

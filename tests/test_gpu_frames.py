@@ -413,6 +413,96 @@ def test_pipe_returns_the_bytes_of_the_synchronous_calls(raw):
     sync.close()
 
 
+def test_pipe_frames_of_different_sizes_and_a_short_result_buffer():
+    """(1) the result capacity belongs to the frame that is waited for, not to the last one
+    submitted -- two frames with very different sample counts in flight, everything selected
+    (num_selected = -1), the small one submitted last; (2) a wait with too small a buffer reports
+    AG2_ERR_CAPACITY and KEEPS the frame: a second wait with room brings the same bytes as the synchronous
+    call; the pipe does not advance in between."""
+    import ctypes as C
+    from agile_grasp2_amd import capi
+    clouds, ws = scene.make_stream(83, 15000, 4)
+    prm = scene_params(ws, min_score_diff=-1e30, num_selected=-1)
+    w = make_lenet_weights(7)
+    n_min = min(c.shape[0] for c in clouds)
+    big = scene.draw_samples(5, n_min, 400)
+    small = scene.draw_samples(6, n_min, 3)
+    sync = capi.Detector(**prm)
+    sync.lenet_load(w)
+    want = [sync.detect_frame(clouds[k], (big, small)[k % 2], seed=k) for k in range(4)]
+    assert len(want[0][0]) > 3 * 8 and len(want[0][0]) > len(want[1][0])   # more records than the small frame's capacity
+    pipe = capi.Pipe(depth=2, **prm)
+    pipe.lenet_load(w)
+    got = []
+    pipe.submit(clouds[0], big, seed=0)
+    pipe.submit(clouds[1], small, seed=1)      # (round 3: this overwrote the capacity used for frame 0)
+    got.append(pipe.wait())
+    pipe.submit(clouds[2], big, seed=2)
+    got.append(pipe.wait())
+    pipe.submit(clouds[3], small, seed=3)
+    got.append(pipe.wait())
+    got.append(pipe.wait())
+    for k in range(4):
+        assert got[k][0].tobytes() == want[k][0].tobytes() and got[k][1] == want[k][1], k
+    # a short buffer: the frame stays, the second wait gets it
+    pipe.submit(clouds[0], big, seed=0)
+    buf = np.zeros(len(want[0][0]), dtype=capi.HYP_DTYPE)
+    ns, na, nv = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    rc = pipe.L.ag2_pipe_wait(pipe.h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(2), C.byref(ns), C.byref(na), C.byref(nv))
+    assert rc == -3 and ns.value == len(want[0][0])       # AG2_ERR_CAPACITY, and how much room it takes
+    assert b"kept" in pipe.L.ag2_pipe_last_error(pipe.h)
+    rc = pipe.L.ag2_pipe_wait(pipe.h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(len(buf)), C.byref(ns), C.byref(na),
+                              C.byref(nv))
+    assert rc == 0 and ns.value == len(buf) and buf.tobytes() == want[0][0].tobytes() and na.value == want[0][1]
+    with pytest.raises(RuntimeError, match="pipe empty"):
+        pipe.wait()
+    pipe.close()
+    sync.close()
+
+
+def test_wait_modes_return_the_same_bytes_and_report_their_cost():
+    """ag2_set_wait_mode: polling with the default spin, polling that yields at once
+    (spin_us = 0) and waiting for the stream give the same bytes for frames and for the plain detect step;
+    ag2_get_wait_info reports the host time inside the submit and the wait half of a frame and counts the
+    yields; a wait that is served by polling never falls back to the stream."""
+    from agile_grasp2_amd import capi
+    clouds, ws = scene.make_stream(84, 20000, 5)
+    idx = scene.draw_samples(7, min(c.shape[0] for c in clouds), 150)
+    prm = scene_params(ws, min_score_diff=-1e30, num_selected=25)
+    w = make_lenet_weights(7)
+    out = {}
+    for mode in ("default", "yield", "stream"):
+        d = capi.Detector(**prm)
+        d.lenet_load(w)
+        if mode == "yield":
+            d.set_wait_mode(True, 0)
+        elif mode == "stream":
+            d.set_wait_mode(False, 0)
+        res = []
+        for k, c in enumerate(clouds):
+            sel, n_sc = d.detect_frame(c, idx, seed=k)
+            res.append((sel.tobytes(), n_sc))
+        wi = d.wait_info()
+        assert wi.last_wait_us > 0 and wi.last_submit_us > 0 and wi.poll == (0 if mode == "stream" else 1)
+        assert wi.poll_fallbacks == 0
+        if mode == "stream":
+            assert wi.poll_yields == 0
+        if mode == "yield":
+            assert wi.poll_yields > 0 and wi.spin_us == 0
+        for k in range(3):   # the step-by-step calls poll the same way (extent read-back, results)
+            d.set_cloud(clouds[k])
+            d.compute_normals()
+            sel, n_sc = d.detect(sample_idx=idx, seed=k, want_all=False)
+            res.append((sel.tobytes(), n_sc))
+        assert d.wait_info().poll_fallbacks == 0
+        out[mode] = res
+        with pytest.raises(RuntimeError):
+            d.set_wait_mode(True, -1)
+        d.close()
+    assert out["default"] == out["yield"] == out["stream"]
+    assert sum(n for _, n in out["default"]) > 50
+
+
 def test_raw_frames_that_are_empty_or_fully_filtered():
     """A raw frame with no points, one whose points all lie outside the workspace, and an ordinary one in
     between: no error, nothing selected, and the stream goes on (the reference returns an empty list for

@@ -106,11 +106,14 @@ def test_detect_small_scene(small_scene):
     assert len(gs) == len(ws_) == len(wa)
     key_g = list(zip(gs["sample_slot"], gs["orientation"]))
     key_w = list(zip(ws_["sample_slot"], ws_["orientation"]))
-    gaps = np.abs(np.diff(np.sort(wa["score"])))
-    if len(gaps) == 0 or gaps.min() > 4 * tol(wa["score"]):
-        assert key_g == key_w
-    else:
-        assert sorted(key_g) == sorted(key_w)
+    assert sorted(key_g) == sorted(key_w)
+    # the ORDER is always checked: the two lists may differ only by swaps of records whose oracle scores lie
+    # within 2 tol of each other (never degraded to a set compare)
+    from agile_grasp2_amd.selection_check import check_selection
+    check_selection(gs, wa, -1e30, 1000, tol(wa["score"]), tag="small scene")
+    score_of = {k: float(s) for k, s in zip(zip(wa["sample_slot"], wa["orientation"]), wa["score"])}
+    for a, b in zip(key_g, key_w):
+        assert a == b or abs(score_of[a] - score_of[b]) <= 2 * tol(wa["score"]), (a, b)
     assert gs["full_antipodal"].all()
     d.close()
 
@@ -124,9 +127,10 @@ def test_detect_threshold_and_topk(small_scene):
     d, o, gs, ga, ws_, wa = _detect_pair(xyz, ws, idx, 6, False, min_score_diff=thr, num_selected=10)
     _check_scored(ga, wa)
     assert len(ws_) == min(10, int((wa["score"] >= thr).sum()))
-    if margin > 4 * tol(wa["score"]):
+    from agile_grasp2_amd.selection_check import check_selection
+    chk = check_selection(gs, wa, thr, 10, tol(wa["score"]), max_uncertain=4, tag="threshold + top-10")
+    if margin > 4 * tol(wa["score"]):   # (the threshold is the median: one record sits on it by construction)
         assert len(gs) == len(ws_)
-        assert sorted(zip(gs["sample_slot"], gs["orientation"])) == sorted(zip(ws_["sample_slot"], ws_["orientation"]))
     c = d.counters()
     assert c.n_scored == len(wa) and c.n_selected == len(gs)
     t = d.times()
