@@ -573,6 +573,12 @@ int lenet_pack_weights_x3(ag2_ctx* c, const float* c1w, const float* c2w) {
 // c + 2 -- the conversion, the LDS writes and every request are issued in the shadow of the MFMAs,
 // and a chunk costs one barrier.  (Staging, then MFMAs, two barriers per chunk: matrix pipes 49 %
 // busy.)
+// (AG2_EXP_FCABL: timing-only ablations of k_lenet_fc1_x3 -- wrong results -- for tools/ab_build.sh: 1 half of the
+//  A-fragment LDS reads, 2 no B-fragment loads in the loop, 4 no conversion / LDS writes, 8 no activation
+//  loads in the loop, 16 no MFMAs)
+#ifndef AG2_EXP_FCABL
+#define AG2_EXP_FCABL 0
+#endif
 constexpr int kFxBM = 128;
 constexpr int kFxKC = 32;              // k per chunk: 7200 = 225 chunks of two 16-k blocks
 constexpr int kFxPitch = 40;           // bf16 per staged row
@@ -644,6 +650,9 @@ k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restric
   const int nkb = chunks_per_split * 2;
   uint4 B[4][3];
   auto load_b = [&](int kb, uint4(&d)[3]) {
+#if AG2_EXP_FCABL & 2
+    if (kb > 1) return;
+#endif
     const uint4* wn = wl + (size_t)min(kb, nkb - 1) * (16 * 3 * 64);
     d[0] = wn[0];
     d[1] = wn[64];
@@ -652,13 +661,20 @@ k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restric
   // A fragments of two image tiles (t0, t0 + 1) for k-block kb of the chunk in buffer buf
   auto load_a = [&](int buf, int kbl, int t0, uint4(&d)[2][3]) {
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < ((AG2_EXP_FCABL & 1) ? 1 : 2); t++)
 #pragma unroll
       for (int s = 0; s < 3; s++)
         d[t][s] = *reinterpret_cast<const uint4*>(&S.a[buf][s][32 * (t0 + t) + r][16 * kbl + 8 * h]);
+#if AG2_EXP_FCABL & 1
+    for (int s = 0; s < 3; s++) d[1][s] = d[0][s];
+#endif
   };
   auto mma2 = [&](int t0, const uint4(&a)[2][3], const uint4(&bb)[3]) {
     constexpr int ia[6] = {0, 2, 1, 0, 1, 0}, ib[6] = {2, 0, 1, 1, 0, 0};  // hl, lh, mm, hm, mh, hh
+#if AG2_EXP_FCABL & 16
+    acc[t0][0] += __uint_as_float(a[0][0].x ^ a[1][1].y ^ a[0][2].z ^ a[1][0].w ^ bb[0].x ^ bb[1].y ^ bb[2].z);
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 6; k++)
 #pragma unroll
@@ -689,7 +705,9 @@ k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restric
       if (hs == 2) load_b(2 * ci + 3, B[(2 * PAR + 3) & 3]);
       // next half-step's A fragments (the first of the next chunk come after the barrier)
       if (hs < 3) load_a(buf, (hs + 1) >> 1, 2 * ((hs + 1) & 1), A[(hs + 1) & 1]);
+#if !(AG2_EXP_FCABL & 4)
       lstore4(nbuf, hs, R[hs]);
+#endif
       mma2(t0, A[hs & 1], B[(2 * PAR + kbl) & 3]);
 #pragma unroll
       for (int i = 0; i < 12; i++) {
@@ -701,7 +719,9 @@ k_lenet_fc1_x3(const float* __restrict__ x, int n_img, const unsigned* __restric
       }
       x3_fence();
     }
+#if !(AG2_EXP_FCABL & 8)
     gload(ci + 3, R);  // (in flight for a chunk and a half)
+#endif
     __syncthreads();   // chunk ci + 1 is staged; every reader of this chunk's buffer is done
     load_a(nbuf, 0, 0, A[0]);
   };

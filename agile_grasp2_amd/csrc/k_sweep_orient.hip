@@ -37,6 +37,10 @@ struct OrientShared {
   int next_w[2];
   long long arena_off;
   double smp[3];                   // the sample (for the record, which one thread writes at the very end)
+  // what only the record needs of the passes' results: parked here by thread 0 as soon as it is known, so that
+  // 256 lanes do not carry twelve registers of it through pass D (they were the kernel's scratch: 11 spilled
+  // VGPRs = 48 B per lane = 26 MB of writes per cfg2 step)
+  double rec_surface, rec_top, rec_bottom, rec_center, rec_width;
   struct {
     struct {
       float px[kOStage], py[kOStage], pz[kOStage];  // the staged chunk: centred coordinates ...
@@ -213,7 +217,12 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     // closing region, finger_hand.cpp:137-180
     const double left = fl0 + hc.finger_width;
     const double right = fr0;
-    const double center = 0.5 * (left + right);
+    if (tid == 0) {  // (for the record; S.rec_*'s reader of the previous pair is behind the barrier of next_work)
+      S.rec_surface = surface;
+      S.rec_top = top;
+      S.rec_bottom = bottom;
+      S.rec_center = 0.5 * (left + right);
+    }
     // pass C: members of the closing region.  Inside a chunk every wave takes a contiguous quarter, so
     // that (chunk, wave, lane) order is list order; the membership ballots of a chunk are kept in LDS.
     auto seg_of = [&](int clen, int& jb, int& je) {
@@ -276,6 +285,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
     if (P == 0) continue;                                         // hand_search.cpp:377-381
     const int slot = t * R + oi;
     if (tid == 0) {
+      S.rec_width = mxx - mnx;                                    // hand_search.cpp:397
       long long off = -1;
       if (A.emit_lists) {
         off = (long long)atomicAdd(&A.st->arena_top, (unsigned long long)P);
@@ -452,7 +462,8 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
       }
       ag2_hypothesis h;
       const double smp[3] = {S.smp[0], S.smp[1], S.smp[2]};
-      const double ys[3] = {surface, bottom, top};
+      const double ys[3] = {S.rec_surface, S.rec_bottom, S.rec_top};
+      const double center = S.rec_center;
       double* dstv[3] = {h.surface, h.bottom, h.top};
       for (int k = 0; k < 3; k++)                                   // finger_hand.cpp:189-199
         for (int a = 0; a < 3; a++)
@@ -462,7 +473,7 @@ __global__ void __launch_bounds__(kOThreads, 4) k_sweep_orient(SweepArgs A) {
         h.approach[a] = Fr[a][1];
         h.axis[a] = Fr[a][2];
       }
-      h.width = mxx - mnx;                                          // hand_search.cpp:397
+      h.width = S.rec_width;
       h.score = 0.0;
       h.sample_slot = slot_base + t;
       h.orientation = oi;
