@@ -33,6 +33,11 @@ SYMBOLS = [
 ]
 
 
+class RetryStep(RuntimeError):
+    """ag2_merge_* returned AG2_ERR_RETRY: nothing was merged; every rank repeats its step (detect, export, exchange,
+    merge) -- each rank's next detect runs step by step and learns its shapes again."""
+
+
 class Params(C.Structure):
     _fields_ = [
         ("finger_width", C.c_double), ("hand_outer_diameter", C.c_double),
@@ -176,6 +181,8 @@ class Detector:
             pass
 
     def _ck(self, rc):
+        if rc == -5:   # AG2_ERR_RETRY: every rank repeats the step (a rank's one-trip detect did not hold its shapes)
+            raise RetryStep(f"libag2hip (rc={rc}): " + self.L.ag2_last_error(self.h).decode())
         if rc != 0:
             raise RuntimeError(f"libag2hip (rc={rc}): " + self.L.ag2_last_error(self.h).decode())
 
@@ -349,6 +356,7 @@ class Detector:
             self._ck(self.L.ag2_detect(self.h, _ptr(si), _ptr(sx), C.c_size_t(s), C.c_uint64(slot_base),
                                        C.c_uint64(seed), C.c_int(1 if do_prune else 0), None, C.c_size_t(0),
                                        C.byref(ns), None, C.c_size_t(0), C.byref(na)))
+            # (na is 0 when the call ran in one trip: the count is known after the merge -- counters().n_scored)
             return np.zeros(0, dtype=HYP_DTYPE), na.value
         cap = max(1, s * int(self.params.num_orientations))
         # the selection is at most num_selected records (when that is >= 0): a buffer of that size, kept

@@ -440,6 +440,7 @@ int ag2_set_grid_origin(ag2_ctx* c, const float* origin3) {
 int ag2_get_counters(ag2_ctx* c, ag2_counters* out) {
   if (!c || !out) return AG2_ERR_ARG;
   (void)hipSetDevice(c->device);
+  (void)rank_spec_collect(c, /*stream_is_idle=*/false);
   (void)collect_normals_stats(c);
   *out = c->cnt;
   out->detect_one_trip = c->spec_runs;
@@ -450,6 +451,7 @@ int ag2_get_counters(ag2_ctx* c, ag2_counters* out) {
 int ag2_get_stage_times(ag2_ctx* c, ag2_times* out) {
   if (!c || !out) return AG2_ERR_ARG;
   (void)hipSetDevice(c->device);
+  (void)rank_spec_collect(c, /*stream_is_idle=*/false);
   (void)collect_normals_stats(c);
   *out = c->times;
   return 0;

@@ -211,6 +211,18 @@ struct ag2_ctx {
   unsigned bounds_seq = 0;   // ... of the last extent pass whose follower raises the flag in the small area
   bool bounds_flag_armed = false;
   unsigned topk_seq = 0;     // sequence number of the last k_topk launch (the done flag in the page-locked small area)
+  // A rank of a multi-GPU job (ag2_detect without a result buffer: the merge selects) in ONE host round trip --
+  // none at all inside the detect: the tail is launched at the shapes the previous call left, and whether they
+  // held travels in the header of the exported list (k_export_selected), where EVERY rank sees it after the
+  // exchange and takes the same decision (ag2_merge_*: AG2_ERR_RETRY).  The statistics come back in page-locked
+  // memory with the export and are taken up at the next point that synchronises anyway (rank_spec_collect).
+  struct RankSpec {
+    bool pending = false;      // a one-trip rank detect whose statistics have not been taken up yet
+    unsigned cap_img = 0;      // images its tail was launched for
+    int render_cap = 0;        // in-box points its renderers take
+    int stage1_skipped = 0;    // its sweep left the long-list stage out
+    size_t s = 0;
+  } rank_spec;
   int sweep_no_overflow_runs = 0;   // consecutive runs that handed no sample to the long-list stage
   bool sweep_may_skip_stage1 = false;  // set by the one-round-trip detect around its sweep: it checks and repeats
   bool sweep_stage1_skipped = false;   // the last sweep did not launch the long-list stage
@@ -301,6 +313,9 @@ constexpr size_t kPinSmall = 20480;
 // offsets in the small area of the sequence numbers a kernel's last workgroup writes behind its results for the
 // host to poll (wait_flag): k_topk's, k_bounds'
 constexpr size_t kPinDoneFlag = 16384, kPinBoundsFlag = 16384 + 64;  // (the first 16 KB: the extent partials)
+// ... and where k_export_selected leaves the statistics of a rank's one-trip detect (RankSpec below)
+constexpr size_t kPinRankStats = 16384 + 128;
+static_assert(kPinRankStats + sizeof(ag2::DevStats) <= kPinSmall, "pin_small: room for the rank statistics");
 constexpr unsigned kPinFlags = hipHostMallocCoherent | hipHostMallocMapped;  // every block a kernel writes for the host to poll
 int pin_reserve(ag2_ctx* c, size_t bulk_bytes);
 inline char* pin_small(ag2_ctx* c) { return (char*)c->h_pin; }
@@ -392,6 +407,7 @@ int gather_records(ag2_ctx* c, const int* d_list, size_t n, std::vector<ag2_hypo
                    std::vector<int64_t>* offs, std::vector<uint8_t>* keep);
 int export_candidates_compact(ag2_ctx* c, void* d_dst, size_t cap_records);
 int export_selected_compact(ag2_ctx* c, void* d_dst, size_t cap_records);
+int rank_spec_collect(ag2_ctx* c, bool stream_is_idle);  // ag2_pipeline.hip
 int merge_selected(ag2_ctx* c, const void* d_gathered, size_t world, size_t cap_records, ag2_hypothesis* selected,
                    size_t cap, size_t* n_selected, size_t* n_total);
 int make_image_descs(ag2_ctx* c, const int* d_list, size_t n);

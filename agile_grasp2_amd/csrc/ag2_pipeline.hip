@@ -167,11 +167,12 @@ int run_hypotheses(ag2_ctx* c, const int32_t* sample_idx, const double* sample_x
 constexpr int kSpecRedo = 1;
 int detect_speculative(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, size_t s,
                        uint64_t slot_base, uint64_t seed, int do_prune, ag2_hypothesis* selected, size_t cap,
-                       size_t* n_selected, size_t* n_scored) {
+                       size_t* n_selected, size_t* n_scored, bool rank_mode) {
   const size_t n_slots = s * (size_t)c->p.num_orientations;
   const size_t cap_img = std::min(c->spec_cap_img, n_slots);
   const size_t k_cap = (c->p.num_selected >= 0) ? std::min<size_t>((size_t)c->p.num_selected, cap_img) : cap_img;
-  if (k_cap > cap) return kSpecRedo;  // (the step-by-step form reports the caller's short buffer)
+  if (!rank_mode && k_cap > cap) return kSpecRedo;  // (the step-by-step form reports the caller's short buffer)
+  if (rank_mode && !c->h_pin_dev) return kSpecRedo;
   c->sweep_may_skip_stage1 = true;
   int rc = run_hypotheses(c, sample_idx, sample_xyz, s, slot_base, seed, true, do_prune ? 1 : 0, /*defer_read=*/true);
   c->sweep_may_skip_stage1 = false;
@@ -202,6 +203,20 @@ int detect_speculative(ag2_ctx* c, const int32_t* sample_idx, const double* samp
   if (rc) return rc;
   c->d_last_sel = c->d_sel.p;  // for ag2_export_selected_compact_device
   c->d_last_nsel = &st->n_sel;
+  if (rank_mode) {
+    // A rank that only feeds the merge: no clustering, no top-k, no read-back -- and NO wait.  Whether the shapes
+    // held is decided on the device when the list is exported (k_export_selected), read by every rank after the
+    // exchange (ag2_merge_*: AG2_ERR_RETRY); the statistics are taken up there as well (rank_spec_collect).
+    AG2_HIP(c, stage_event(c, 7));
+    c->rank_spec.pending = true;
+    c->rank_spec.cap_img = (unsigned)cap_img;
+    c->rank_spec.render_cap = render_capacity_for(c->spec_max_p);
+    c->rank_spec.stage1_skipped = c->sweep_stage1_skipped ? 1 : 0;
+    c->rank_spec.s = s;
+    *n_selected = 0;
+    if (n_scored) *n_scored = 0;  // (not known yet: ag2_get_counters after the merge / gather)
+    return 0;
+  }
   const ag2_hypothesis* d_res = c->d_sel.as<ag2_hypothesis>();
   const unsigned* d_nres = &st->n_sel;
   if (c->min_inliers > 0) {  // grasp clusters between the threshold and the top-k (grasp_detector.cpp:228-236)
@@ -252,6 +267,42 @@ int detect_speculative(ag2_ctx* c, const int32_t* sample_idx, const double* samp
 }
 
 }  // namespace
+
+namespace ag2 {
+// Takes up what a rank's one-trip detect left: the statistics k_export_selected copied into page-locked memory
+// (counters, stage times, the shapes the next call is launched at).  Called where the stream has been waited
+// for anyway (merge, gather); elsewhere (stream_is_idle == false) it waits itself.
+int rank_spec_collect(ag2_ctx* c, bool stream_is_idle) {
+  if (!c->rank_spec.pending) return 0;
+  if (!stream_is_idle) AG2_HIP(c, hipStreamSynchronize(c->stream));
+  c->rank_spec.pending = false;
+  DevStats hs;
+  memcpy(&hs, pin_small(c) + kPinRankStats, sizeof(hs));
+  const bool bad = (hs.err_flags & (1u | 2u | 8u)) != 0u || hs.n_list > c->rank_spec.cap_img ||
+                   (int)hs.max_p > c->rank_spec.render_cap || (c->rank_spec.stage1_skipped && hs.n_overflow > 0u);
+  if (bad) {
+    c->spec_fallbacks++;
+    c->sweep_no_overflow_runs = 0;
+    c->spec_cap_img = 0;  // the next call runs step by step and learns the shapes again
+    return 0;
+  }
+  note_sweep(c, c->rank_spec.s, hs, 1);
+  const size_t n_img = hs.n_list;
+  c->cnt.n_pruned = (int64_t)n_img;
+  c->cnt.n_scored = (int64_t)n_img;
+  c->cnt.n_selected = 0;
+  stage_elapsed(c, &c->times.compact_ms, 11, 3);
+  stage_elapsed(c, &c->times.render_ms, 3, 4);
+  stage_elapsed(c, &c->times.lenet_conv_ms, 4, 5);
+  stage_elapsed(c, &c->times.lenet_fc_ms, 5, 6);
+  stage_elapsed(c, &c->times.select_ms, 6, 7);
+  stage_elapsed(c, &c->times.total_ms, 8, 7);
+  c->spec_cap_img = std::max(c->spec_cap_img, ((n_img + n_img / 4 + 256 + 255) / 256) * 256);
+  c->spec_max_p = std::max(c->spec_max_p, (int)hs.max_p);
+  c->spec_runs++;
+  return 0;
+}
+}  // namespace ag2
 
 extern "C" {
 
@@ -431,12 +482,16 @@ int ag2_detect(ag2_ctx* c, const int32_t* sample_idx, const double* sample_xyz, 
   // for the step-by-step one (all scored records, the multi-GPU export without read-back,
   // the f32-input LeNet kernels, AG2_DETECT_STEPWISE=1 for A/B).
   static const bool spec_off = getenv("AG2_DETECT_STEPWISE") != nullptr;
-  const bool spec = !spec_off && selected && !(scored_all && cap_all) && c->net.use_x3 &&
+  rc = rank_spec_collect(c, /*stream_is_idle=*/false);  // (a rank's previous call nobody merged or gathered)
+  if (rc) return rc;
+  // (selected == NULL and cap == 0: a rank of a multi-GPU job -- the caller exports the list and the merge selects)
+  const bool rank_mode = !selected && cap == 0 && !(scored_all && cap_all);
+  const bool spec = !spec_off && (selected || rank_mode) && !(scored_all && cap_all) && c->net.use_x3 &&
                     !c->fm_on && c->spec_cap_img > 0 && c->spec_s == s && c->spec_prune == (do_prune ? 1 : 0) &&
                     n_slots > 0 && n_slots <= 65536;
   if (spec) {
     rc = detect_speculative(c, sample_idx, sample_xyz, s, slot_base, seed, do_prune, selected, cap, n_selected,
-                            n_scored);
+                            n_scored, rank_mode);
     if (rc != kSpecRedo) return rc;
     c->spec_fallbacks++;
     AG2_HIP(c, stage_event(c, 8));
@@ -632,6 +687,10 @@ int ag2_gather_selected(ag2_ctx* root, ag2_ctx* src, size_t rank) {
   else  // over xGMI; the runtime stages through the host when the devices have no peer access
     AG2_HIP(src, hipMemcpyPeerAsync(dst, root->device, src->d_xchg.p, src->device, per, src->stream));
   AG2_HIP(src, hipStreamSynchronize(src->stream));
+  {  // (the stream is idle: what a one-trip rank detect left is taken up here)
+    const int rcc = rank_spec_collect(src, /*stream_is_idle=*/true);
+    if (rcc) return rcc;
+  }
   root->gather_delivered[rank] = 1;  // (one byte per rank: the ranks' threads write distinct elements)
   return 0;
 }

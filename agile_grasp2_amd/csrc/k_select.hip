@@ -454,20 +454,51 @@ int export_candidates_compact(ag2_ctx* c, void* d_dst, size_t cap_records) {
 
 // ---- multi-GPU merge: every rank's selected list travels (compact form), every rank ranks them all ----
 // header (16 B): {count, cap, 0, 0}; then min(count, cap) records in list order
+// Header of a rank's list: {count, cap, status, images scored}.  status bit 0: the rank ran its detect at shapes
+// learned from its previous call (ag2_ctx::RankSpec) and they did not hold -- more images than the tail was
+// launched for, a longer in-box list than its renderers take, a sweep buffer too small, a sample for the
+// long-list stage that was left out: its list is then void (count 0) and every rank repeats the step.
+struct ExportSpec {
+  const DevStats* st;        // NULL: no statistics to report (header {count, cap, 0, 0})
+  DevStats* st_host;         // page-locked copy of the statistics for the rank's host (or NULL)
+  unsigned check;            // 1: the shapes below are to be checked against *st
+  unsigned cap_img;
+  int render_cap;
+  int stage1_skipped;
+};
 __global__ void k_export_selected(const uint4* __restrict__ recs, const unsigned* __restrict__ d_count,
-                                  unsigned cap, uint4* __restrict__ dst) {
+                                  unsigned cap, uint4* __restrict__ dst, ExportSpec es) {
   constexpr unsigned kPer = (unsigned)(sizeof(ag2_hypothesis) / 16);
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned count = *d_count;
+  unsigned status = 0u, n_scored = 0u;
+  if (es.st) {  // (uniform)
+    n_scored = es.st->n_list;
+    if (es.check)
+      status = ((es.st->err_flags & (1u | 2u | 8u)) != 0u || n_scored > es.cap_img || (int)es.st->max_p > es.render_cap ||
+                (es.stage1_skipped && es.st->n_overflow > 0u)) ? 1u : 0u;
+  }
+  const unsigned count = status ? 0u : *d_count;
   const unsigned n = count < cap ? count : cap;
-  if (i == 0) dst[0] = make_uint4(count, cap, 0u, 0u);
+  if (i == 0) {
+    dst[0] = make_uint4(count, cap, status, n_scored);
+    if (es.st && es.st_host) *es.st_host = *es.st;
+  }
   if (i / kPer < n) dst[1 + i] = recs[i];
 }
 
 int export_selected_compact(ag2_ctx* c, void* d_dst, size_t cap_records) {
   const size_t threads = std::max<size_t>(cap_records, 1) * (sizeof(ag2_hypothesis) / 16);
+  ExportSpec es{};
+  if (c->rank_spec.pending && c->h_pin_dev) {
+    es.st = c->d_stats.as<DevStats>();
+    es.st_host = reinterpret_cast<DevStats*>(pin_small_dev(c) + kPinRankStats);
+    es.check = 1u;
+    es.cap_img = c->rank_spec.cap_img;
+    es.render_cap = c->rank_spec.render_cap;
+    es.stage1_skipped = c->rank_spec.stage1_skipped;
+  }
   hipLaunchKernelGGL(k_export_selected, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
-                     (const uint4*)c->d_last_sel, c->d_last_nsel, (unsigned)cap_records, (uint4*)d_dst);
+                     (const uint4*)c->d_last_sel, c->d_last_nsel, (unsigned)cap_records, (uint4*)d_dst, es);
   AG2_HIP(c, hipGetLastError());
   return 0;
 }
@@ -482,9 +513,11 @@ __global__ void __launch_bounds__(256) k_merge_flatten(const unsigned char* __re
   const int r = blockIdx.y;
   unsigned off = 0, mine = 0, cut = 0;
   for (int k = 0; k <= r; k++) {  // (a few ranks: every thread adds up the counts before its rank)
-    const unsigned hdr = *reinterpret_cast<const unsigned*>(g + (size_t)k * per);
+    const unsigned* hp = reinterpret_cast<const unsigned*>(g + (size_t)k * per);
+    const unsigned hdr = hp[0];
     const unsigned cnt = min(hdr, cap);
     cut |= (hdr > cap) ? 1u : 0u;  // a rank's list was cut at the exchange capacity: the merge is void
+    cut |= (hp[2] & 1u) << 1;      // a rank's one-trip detect did not hold its shapes: every rank repeats the step
     if (k < r) off += cnt; else mine = cnt;
   }
   if (r == world - 1 && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -571,7 +604,17 @@ int merge_selected(ag2_ctx* c, const void* d_gathered, size_t world, size_t cap_
   __builtin_memcpy(kn, pin_bulk(c) + k_cap * sizeof(ag2_hypothesis), 16);
   *n_selected = kn[0];
   if (n_total) *n_total = kn[2];  // records that took part (before the clustering)
-  if (kn[3])
+  {  // (the stream is idle: this rank's own one-trip detect, if any, has left its statistics)
+    const int rcc = rank_spec_collect(c, /*stream_is_idle=*/true);
+    if (rcc) return rcc;
+  }
+  if (kn[3] & 2u) {
+    *n_selected = 0;
+    c->spec_cap_img = 0;  // this rank's next ag2_detect runs step by step (and learns its shapes again)
+    return set_err(c, AG2_ERR_RETRY, "merge: a rank's detect ran at shapes that did not hold (its header says so): "
+                                     "nothing was merged; every rank repeats the step");
+  }
+  if (kn[3] & 1u)
     return set_err(c, AG2_ERR_CAPACITY, "merge: a rank's list is longer than the exchange capacity (header count > "
                                         "cap_records): the global top-k would be wrong; exchange with a larger capacity");
   if (kn[0] > cap) return set_err(c, AG2_ERR_CAPACITY, "merge: output capacity too small");

@@ -1314,6 +1314,10 @@ bool GraspDetector::detectOnDevices(const CloudCamera& cloud_cam, const std::vec
   size_t longest = 0;
   for (size_t g = 0; g < G; g++) longest = std::max(longest, lo[g + 1] - lo[g]);
   const size_t cap_records = std::max<size_t>(1, longest * (size_t)p_.num_orientations);  // every slot: never cut
+  // (A device's detect runs in one trip from its second call on, at the shapes its previous call left; when they
+  // did not hold -- the merge reads that from the gathered headers: AG2_ERR_RETRY -- the whole step is repeated
+  // once more, step by step.)
+  for (int attempt = 0; attempt < 3; attempt++) {
   if (ag2_gather_begin(root, G, cap_records)) {
     err_ = ag2_last_error(root);
     return false;
@@ -1395,11 +1399,16 @@ bool GraspDetector::detectOnDevices(const CloudCamera& cloud_cam, const std::vec
   const size_t k_cap = (p_.num_selected >= 0) ? std::min<size_t>((size_t)p_.num_selected, G * cap_records) : G * cap_records;
   recs->resize(std::max<size_t>(1, k_cap));
   size_t n_total = 0;
-  if (ag2_merge_gathered(root, recs->data(), recs->size(), n, &n_total)) {
+  const int mrc = ag2_merge_gathered(root, recs->data(), recs->size(), n, &n_total);
+  if (mrc == AG2_ERR_RETRY) continue;
+  if (mrc) {
     err_ = ag2_last_error(root);
     return false;
   }
   return true;
+  }
+  err_ = "the devices' shapes did not settle in three attempts";
+  return false;
 }
 
 // Steps 1-2 (+ the uniform draw of step 3) on the GPU through ag2_preprocess_cloud; the processed

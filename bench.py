@@ -538,19 +538,34 @@ def main():
                                  want_all=False, local_select=local_select)
         return n_scored
 
+    import ctypes
+    cnt_rec = capi.Counters()
+    get_cnt, cnt_ref = d.L.ag2_get_counters, ctypes.byref(cnt_rec)
+
     def step():
-        n_scored = local_step(local_select=not dist_on)
-        if dist_on:
-            # the path's one exchange step: every rank's scored candidates above the threshold (compact
-            # form), RCCL all-gather over xGMI; then every rank merges -- the lists concatenated in rank
-            # (= sample) order, top num_selected by score (grasp_detector.cpp:239-252) -- on the device
+        if not dist_on:
+            return local_step(local_select=True)
+        # A rank's detect waits for nothing (from its second call on: the tail is launched at the shapes the
+        # previous call left, and whether they held travels in the exported header).  Then the path's one exchange
+        # step: every rank's scored candidates above the threshold (compact form), RCCL all-gather over xGMI; every
+        # rank merges -- the lists concatenated in rank (= sample) order, top num_selected by score
+        # (grasp_detector.cpp:239-252) -- on the device.  AG2_ERR_RETRY (every rank reads the same headers, so every
+        # rank gets it): some rank's shapes did not hold; all repeat the step, inside the timed region.
+        for attempt in range(3):
+            local_step(local_select=False)
             d.export_selected_compact_device(xch["buf"].data_ptr(), xch["buf"].numel(), xch["cap"])
             if rehearsal:
                 xch["out"] = sharding.all_gather_tables(xch["buf"].cpu(), world).cuda()
             else:
                 xch["out"] = sharding.all_gather_tables(xch["buf"], world)
-            xch["merged"], xch["n_total"] = d.merge_selected_device(xch["out"].data_ptr(), world, xch["cap"])
-        return n_scored
+            try:
+                xch["merged"], xch["n_total"] = d.merge_selected_device(xch["out"].data_ptr(), world, xch["cap"])
+            except capi.RetryStep:
+                xch["retries"] = xch.get("retries", 0) + 1
+                continue
+            get_cnt(d.h, cnt_ref)   # (the count is known once the merge has waited for the stream; bare C call)
+            return int(cnt_rec.n_scored)
+        raise SystemExit("a rank's shapes did not settle in three attempts")
 
     def sync():
         if dist_on:
@@ -610,7 +625,9 @@ def main():
                     "halo_duplication": float(tt[3]) / n_cloud,   # sum of the tiles' points / cloud points
                     "samples_max": int(tmax[4]), "samples_min": int(tmin[4]),
                     "sweep_ms_max": float(tmax[5]), "sweep_ms_mean": float(tt[5]) / world,
-                    "merged_records": int(xch.get("n_total", 0)), "merged_selected": int(len(xch.get("merged", [])))}
+                    "merged_records": int(xch.get("n_total", 0)), "merged_selected": int(len(xch.get("merged", []))),
+                    "steps_repeated_rank0": int(xch.get("retries", 0)),
+                    "rank0_detect_one_trip": int(c.detect_one_trip), "rank0_detect_redone": int(c.detect_redone)}
     total_scored = float(tt[1])
     if rank != 0:
         dist.destroy_process_group()

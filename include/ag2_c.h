@@ -33,7 +33,11 @@ enum {
   AG2_ERR_ARG = -1,       /* bad argument / call order */
   AG2_ERR_HIP = -2,       /* HIP runtime error */
   AG2_ERR_CAPACITY = -3,  /* an output or internal buffer is too small (message says which) */
-  AG2_ERR_STATE = -4      /* missing cloud / normals / weights */
+  AG2_ERR_STATE = -4,     /* missing cloud / normals / weights */
+  AG2_ERR_RETRY = -5      /* ag2_merge_*: a rank ran its detect at shapes learned from its previous call and they
+                             did not hold (its exported header says so, every rank reads it): nothing was merged;
+                             EVERY rank repeats the step -- its next ag2_detect runs step by step and learns the
+                             new shapes */
 };
 
 typedef struct ag2_ctx ag2_ctx;

@@ -241,6 +241,7 @@ def test_cfg4_eight_tiles_of_the_cfg2_cloud_match_the_unsplit_oracle(min_inliers
         d.detect(sample_idx=local, slot_base=base, seed=1, do_prune=True, want_all=False, local_select=False)
         d.export_selected_compact_device(dbuf.value + rank * per, per, cap)
     assert pos == len(oall)
+    assert hip.hipDeviceSynchronize() == 0
     got, n_total = d.merge_selected_device(dbuf.value, world, cap)
     thr = float(prm["min_score_diff"])
     k = int(prm["num_selected"])

@@ -37,3 +37,26 @@ def test_parity_under_switch(switch):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_bench_two_rank_rehearsal_validates_its_merge_against_the_unsplit_run():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), rehearsed on the
+    one GPU of the box (AG2_BENCH_REHEARSAL=1: both ranks on GPU 0, the all-gather over gloo -- RCCL refuses two
+    ranks on one device): spatial tiles, compact exchange, merge on every rank, and then rank 0's self-validation
+    (bench.validate_against_unsplit): the merged top-k against ONE unsplit run over all the ranks' samples --
+    records byte-equal apart from the score, scores within tolerance, selection and counts consistent
+    (hand_search.cpp:194-228, grasp_detector.cpp:228-252).  What the first N-GPU hardware record will carry."""
+    import json
+    env = dict(os.environ, AG2_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--no-cpu"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    v = out["config"]["per_rank"]["matches_unsplit"]
+    assert v["ok"] and v["records_byte_equal"] and v["scores_within_tol"] and v["selection_ok"] and v["counts_ok"], v
+    assert v["merged_selected"] == 30 and v["unsplit_scored"] == v["ranks_scored"] > 1000
+    assert out["config"]["per_rank"]["halo_duplication"] < 1.3

@@ -227,6 +227,7 @@ def test_merge_of_the_ranks_selected_lists_on_the_gpu(world, min_inliers):
         d.detect(sample_idx=local, slot_base=base, seed=3, do_prune=False, want_all=False, local_select=rank == 0)
         d.export_selected_compact_device(dbuf.value + rank * per, per, cap)
         dets.append(d)
+    hip.hipDeviceSynchronize()   # (every rank's export -- on its own stream -- before anyone reads the buffer)
     raw = np.zeros(per * world, dtype=np.uint8)
     assert hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), dbuf, per * world, 2) == 0
     flat, cut = sharding.unpack_compact(raw, world, cap, capi.HYP_DTYPE)
@@ -323,3 +324,99 @@ def test_cost_balanced_bounds():
         assert max(sums) <= costs.sum() / world + 100
     assert list(sharding.balanced_bounds(np.ones(3), 8))[:4] == [0, 1, 2, 3]
     assert list(sharding.balanced_bounds(np.zeros(0), 4)) == [0, 0, 0, 0, 0]
+
+
+@pytest.mark.gpu
+def test_a_rank_detects_in_one_trip_and_a_shape_that_does_not_hold_makes_every_rank_repeat():
+    """A rank of a multi-GPU job (ag2_detect without a result buffer) waits for NOTHING from its second call on:
+    the tail is launched at the shapes its previous call left, the exported header says whether they held
+    ({count, cap, status, images scored}), and the merge -- which every rank runs on the same gathered bytes --
+    answers AG2_ERR_RETRY when some rank's did not, so that all repeat the step (round 4).
+    Two ranks on the one GPU: (1) repeated steps return the bytes of the first, step-by-step one, the second and
+    third in one trip (counters); (2) rank 1 then meets a cloud with far more hypotheses than its shapes hold:
+    its header carries status 1 and no records, the merge raises RetryStep on EVERY rank, and the repeated step
+    gives the bytes two fresh contexts give."""
+    import ctypes as C
+    from agile_grasp2_amd import capi
+    from agile_grasp2_amd.weights import make_lenet_weights
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    w = make_lenet_weights(7)
+    bare, ws1 = scene.make_scene(seed=21, n_target=60000, kind="plane")
+    busy, ws2 = scene.make_scene(seed=22, n_target=60000, kind="tabletop")
+    wsu = [min(ws1[0], ws2[0]), max(ws1[1], ws2[1]), min(ws1[2], ws2[2]), max(ws1[3], ws2[3]),
+           min(ws1[4], ws2[4]), max(ws1[5], ws2[5])]
+    prm = scene_params(wsu, num_selected=20, min_score_diff=-1e30)
+    s = 2500
+    lo, hi = bare.min(axis=0), bare.max(axis=0)
+    inner = np.flatnonzero((bare[:, 0] > lo[0] + 0.2) & (bare[:, 0] < hi[0] - 0.2) &
+                           (bare[:, 1] > lo[1] + 0.2) & (bare[:, 1] < hi[1] - 0.2)).astype(np.int32)
+    i_bare = inner[scene.draw_samples(1, len(inner), s)]     # no hand finds anything to close around
+    i_busy = scene.draw_samples(2, busy.shape[0], s)
+    cap = s * 8
+    per = sharding.compact_bytes(cap)
+    dbuf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dbuf), per * 2) == 0
+
+    def make():
+        d = capi.Detector(**prm)
+        d.lenet_load(w)
+        return d
+
+    def step(dets, clouds, idxs):
+        """one step of both ranks: detect (no local selection), export, 'all-gather' (adjacent buffers), merge on both"""
+        for r, d in enumerate(dets):
+            d.set_cloud(clouds[r])
+            d.compute_normals()
+            d.detect(sample_idx=idxs[r], slot_base=r * s, seed=4, do_prune=False, want_all=False, local_select=False)
+            d.export_selected_compact_device(dbuf.value + r * per, per, cap)
+        assert hip.hipDeviceSynchronize() == 0   # (what the all-gather orders: every rank's export before any merge)
+        return [d.merge_selected_device(dbuf.value, 2, cap) for d in dets]
+
+    def headers():
+        raw = np.zeros(per * 2, dtype=np.uint8)
+        assert hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), dbuf, per * 2, 2) == 0
+        return raw.reshape(2, per)[:, :16].copy().view(np.uint32)
+
+    dets = [make(), make()]
+    # (1) rank 0 on the busy cloud, rank 1 on the bare table, three times
+    first = step(dets, [busy, bare], [i_busy, i_bare])
+    n0 = int(dets[0].counters().n_scored)
+    assert n0 > 600 and len(first[0][0]) == 20 and first[0][0].tobytes() == first[1][0].tobytes()
+    assert [int(d.counters().detect_one_trip) for d in dets] == [0, 0]
+    for rep in range(2):
+        again = step(dets, [busy, bare], [i_busy, i_bare])
+        for r in range(2):
+            assert again[r][0].tobytes() == first[0][0].tobytes() and again[r][1] == first[0][1], (rep, r)
+        h = headers()
+        assert h[0, 2] == 0 and h[1, 2] == 0 and h[0, 3] == n0 and h[1, 3] == 0 and h[0, 0] == n0 and h[1, 0] == 0
+        assert int(dets[0].counters().n_scored) == n0 and int(dets[1].counters().n_scored) == 0
+        assert dets[0].times().total_ms > 0
+    assert [int(d.counters().detect_one_trip) for d in dets] == [2, 2]
+    assert [int(d.counters().detect_redone) for d in dets] == [0, 0]
+    # (2) rank 1 now gets the busy cloud too: 256 images of room, hundreds of hypotheses
+    for r, d in enumerate(dets):
+        d.set_cloud(busy)
+        d.compute_normals()
+        d.detect(sample_idx=i_busy, slot_base=r * s, seed=4, do_prune=False, want_all=False, local_select=False)
+        d.export_selected_compact_device(dbuf.value + r * per, per, cap)
+    assert hip.hipDeviceSynchronize() == 0
+    for d in dets:                       # every rank takes the same decision from the same bytes
+        with pytest.raises(capi.RetryStep, match="every rank repeats"):
+            d.merge_selected_device(dbuf.value, 2, cap)
+    h = headers()                        # (read after the merges: they waited for the ranks' streams)
+    assert h[0, 2] == 0 and h[0, 0] == n0 and h[1, 2] == 1 and h[1, 0] == 0 and h[1, 3] > 256
+    assert int(dets[1].counters().detect_redone) == 1 and int(dets[0].counters().detect_redone) == 0
+    redo = step(dets, [busy, busy], [i_busy, i_busy])
+    fresh = [make(), make()]
+    want = step(fresh, [busy, busy], [i_busy, i_busy])
+    for r in range(2):
+        assert redo[r][0].tobytes() == want[0][0].tobytes() and redo[r][1] == want[0][1] > n0
+    settled = step(dets, [busy, busy], [i_busy, i_busy])           # and the next one is one trip again
+    assert settled[0][0].tobytes() == want[0][0].tobytes()
+    assert int(dets[1].counters().detect_one_trip) == 3 and int(dets[0].counters().detect_one_trip) == 4
+    for d in dets + fresh:
+        d.close()
+    hip.hipFree(dbuf)
