@@ -1070,8 +1070,11 @@ k_sweep(SweepArgs A) {
       const int n_it = (K + NT - 1) / NT;
       auto jof = [&](int sidx) { return sidx * NT + tid; };
       ldp(min(jof(0), K - 1), qx, qy, qz);
+      if (A.prof && lane == 0) atomicAdd(&A.prof[6], (unsigned long long)(n_it * R));
       for (int sidx = 0; sidx < n_it; sidx++) {
         alive = (unsigned)__builtin_amdgcn_readfirstlane((int)(alive & ~S.dead));
+        // (diagnostic build: orientation-steps done / possible, summed over waves -- how early orientations retire)
+        if (A.prof && lane == 0) atomicAdd(&A.prof[4], (unsigned long long)__popc(alive));
         if (alive == 0u) break;
         const int j = jof(sidx);
         const bool valid = j < K;
@@ -1405,8 +1408,8 @@ int launch_sweep(ag2_ctx* c, size_t s, uint64_t slot_base, bool emit_lists, bool
     AG2_HIP(c, hipStreamSynchronize(c->stream));
     AG2_HIP(c, hipMemcpy(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[ag2 sweep prof, stage 0, cycles summed over workgroups] rows %llu crop1 %llu "
-            "crop2 %llu passA %llu deepen %llu passC %llu passD %llu other %llu\n",
-            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+            "crop2 %llu passA %llu other %llu | pass A orientation-steps done %llu of %llu\n",
+            h[0], h[1], h[2], h[3], h[7], h[4], h[6]);
     AG2_HIP(c, hipMemsetAsync(prof_buf.p, 0, 16 * 8, c->stream));
   }
   // Samples whose cropped list exceeds stage 0 were queued on the device; the second stage is always
