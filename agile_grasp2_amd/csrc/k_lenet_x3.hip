@@ -35,6 +35,13 @@
 namespace ag2 {
 
 // ablation switches for tools/ab_build.sh (timing only, wrong results): 1 no conv1, 2 no conv2, 4 / 8 no A / B requests in conv2
+// Wave priority during conv1 of the banded kernel (s_setprio; 0 = leave it alone, for A/B).  The two workgroups of a
+// CU share every SIMD; conv2 of one saturates the matrix pipe by itself (round 4: conv2 alone is as fast with one
+// workgroup per CU as with two), so the other's conv1 -- few MFMAs, much vector work -- is the phase that should
+// win the arbitration: 0.1915 -> 0.188 ms at 934 images (same bits: scheduling only).
+#ifndef AG2_CONV1_PRIO
+#define AG2_CONV1_PRIO 2
+#endif
 #ifndef AG2_EXP_ABL
 #define AG2_EXP_ABL 0
 #endif
@@ -496,6 +503,9 @@ k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsi
       x3_conv1_weights(w1x, ln, W);
       if (u + (int)gridDim.x < units) fetch(u + gridDim.x);  // (after the weights: waiting for those does not wait for these)
 #if !(AG2_EXP_ABL & 1)
+#if AG2_CONV1_PRIO
+      __builtin_amdgcn_s_setprio(AG2_CONV1_PRIO);
+#endif
       x3_conv1<X3Band, 4, kBWaves>(S, W, bias1, wid, ln, S.imgb);
       x3_conv1<X3Band, 4, kBWaves>(S, W, bias1, wid + 16, ln, S.imgb);
       // (tiles wid + 32, + 36 and, for waves 0 and 1, + 40: three tiles at once rather than a single
@@ -510,6 +520,9 @@ k_lenet_conv_x3b(const unsigned char* __restrict__ images, int n_img, const unsi
     {
       int ln = lane;
       asm volatile("" : "+v"(ln));
+#if AG2_CONV1_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
 #if !(AG2_EXP_ABL & 2)
       x3_conv2<X3Band, 3, 2>(S, w2x, pooled2 + (size_t)im * 7200 + band * (48 * 50), bias2, nh, mgrp, ln);
 #endif
@@ -800,7 +813,9 @@ int launch_lenet_conv_x3(ag2_ctx* c, const uint8_t* d_images, size_t n, float* d
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(X3Band)));
       c->func_attr_done |= kAttrLenetX3b;
     }
-    const int gridb = (int)std::min<size_t>(3 * n, 512);
+    // (AG2_EXP_CONV_GRID: experiment -- another number of workgroups, e.g. 256 = one per CU)
+    static const int exp_grid = [] { const char* e = getenv("AG2_EXP_CONV_GRID"); return e ? atoi(e) : 0; }();
+    const int gridb = (int)std::min<size_t>(3 * n, exp_grid > 0 ? (size_t)exp_grid : 512);
     hipLaunchKernelGGL(k_lenet_conv_x3b, dim3(gridb), dim3(kBThreads), sizeof(X3Band), c->stream, d_images,
                        (int)n, d_n, d.w1x.as<uint4>(), d.b1.as<float>(), d.w2x.as<uint4>(), d.b2.as<float>(),
                        d_pooled2);
