@@ -339,6 +339,11 @@ __global__ void __launch_bounds__(64) k_frames_finish(const HandConst* __restric
 // K3: hand sweep
 // ---------------------------------------------------------------------------------------------
 // phase stamps for the diagnostic build of the launch (thread 0 of each workgroup)
+// AG2_SWEEP_DIAG=1 (compile time, tools/ab_build.sh): pass A also counts its orientation-steps -- a branch per step
+// that costs the product kernel 2 us, so it is not compiled in by default
+#ifndef AG2_SWEEP_DIAG
+#define AG2_SWEEP_DIAG 0
+#endif
 #define AG2_PROF(i)                                                    \
   do {                                                                 \
     if (A.prof && tid == 0) {                                          \
@@ -1070,11 +1075,14 @@ k_sweep(SweepArgs A) {
       const int n_it = (K + NT - 1) / NT;
       auto jof = [&](int sidx) { return sidx * NT + tid; };
       ldp(min(jof(0), K - 1), qx, qy, qz);
+#if AG2_SWEEP_DIAG
       if (A.prof && lane == 0) atomicAdd(&A.prof[6], (unsigned long long)(n_it * R));
+#endif
       for (int sidx = 0; sidx < n_it; sidx++) {
         alive = (unsigned)__builtin_amdgcn_readfirstlane((int)(alive & ~S.dead));
-        // (diagnostic build: orientation-steps done / possible, summed over waves -- how early orientations retire)
+#if AG2_SWEEP_DIAG  // (orientation-steps done / possible, summed over waves: how early orientations retire)
         if (A.prof && lane == 0) atomicAdd(&A.prof[4], (unsigned long long)__popc(alive));
+#endif
         if (alive == 0u) break;
         const int j = jof(sidx);
         const bool valid = j < K;
