@@ -1270,6 +1270,47 @@ std::vector<int32_t> GraspDetector::orderSamplesAlongLongestAxis(const CloudCame
   return ordered;
 }
 
+// Host-only view of the tile plan (no GPU is touched): what TILING_SPATIAL does with a cloud and a sample list --
+// the ordered list, the ranges of equal summed neighbour counts, and per rank the points its tile holds.  Used by the
+// CPU tests to hold this port against agile_grasp2_amd/sharding.py; a site can use it to size its devices.
+extern "C" int ag2host_tile_plan(const float* xyz, size_t n, const int32_t* idx, size_t s, int world, double radius_hands,
+                                 double halo, int32_t* ordered_out, int64_t* bounds_out, int64_t* tile_points_out,
+                                 int32_t* axis_out) {
+  if (!xyz || !idx || world < 1 || !ordered_out || !bounds_out) return -1;
+  PointCloudRGB::Ptr cloud(new PointCloudRGB);
+  cloud->points.resize(n);
+  for (size_t i = 0; i < n; i++) {
+    cloud->points[i].x = xyz[3 * i];
+    cloud->points[i].y = xyz[3 * i + 1];
+    cloud->points[i].z = xyz[3 * i + 2];
+  }
+  CloudCamera cc(cloud, (int)n);
+  int axis = 0;
+  const std::vector<int32_t> ordered = GraspDetector::orderSamplesAlongLongestAxis(cc, std::vector<int32_t>(idx, idx + s), &axis);
+  std::copy(ordered.begin(), ordered.end(), ordered_out);
+  const std::vector<size_t> b = balanced_bounds(*cloud, ordered, axis, radius_hands, (size_t)world);
+  for (int g = 0; g <= world; g++) bounds_out[g] = (int64_t)b[(size_t)g];
+  if (axis_out) *axis_out = axis;
+  if (tile_points_out)
+    for (int g = 0; g < world; g++) {
+      int64_t m = 0;
+      if (b[(size_t)g + 1] > b[(size_t)g]) {
+        double xlo = 0.0, xhi = 0.0;
+        for (size_t i = b[(size_t)g]; i < b[(size_t)g + 1]; i++) {
+          const double x = (double)coord(cloud->points[(size_t)ordered[i]], axis);
+          xlo = (i == b[(size_t)g]) ? x : std::min(xlo, x);
+          xhi = (i == b[(size_t)g]) ? x : std::max(xhi, x);
+        }
+        for (size_t i = 0; i < n; i++) {
+          const double x = (double)coord(cloud->points[i], axis);
+          if (x >= xlo - halo && x <= xhi + halo) m++;
+        }
+      }
+      tile_points_out[g] = m;
+    }
+  return 0;
+}
+
 bool GraspDetector::detectOnDevices(const CloudCamera& cloud_cam, const std::vector<int32_t>& idx, bool do_prune,
                                     int min_inliers, std::vector<ag2_hypothesis>* recs, size_t* n) {
   const size_t s = idx.size();

@@ -117,6 +117,10 @@ class GraspDetector {
   // not in the reference: the camera poses detectGraspPoses hands to the hand search
   // (grasp_detector.cpp:108-137: the launch file's camera_pose, else the 2-camera Baxter defaults)
   void cameraPoses(ag2::Matrix4d* left, ag2::Matrix4d* right) const;
+  // Params::tiling == TILING_SPATIAL: the sample list in ascending order along `*axis` (the cloud's longest extent),
+  // stable -- the order every number of devices shards (agile_grasp2_amd/sharding.py: order_samples_by_x)
+  static std::vector<int32_t> orderSamplesAlongLongestAxis(const CloudCamera& cloud_cam, const std::vector<int32_t>& idx,
+                                                           int* axis);
   // points every device of the last N-device run held (TILING_SPATIAL: its tile; else the whole cloud)
   const std::vector<size_t>& lastTilePoints() const { return tile_points_; }
   const ag2_times& lastStageTimes() const { return times_; }
@@ -141,9 +145,7 @@ class GraspDetector {
   // the multi-GPU form of step 1 - 5 (Params::devices); false: error (err_ says what)
   bool detectOnDevices(const CloudCamera& cloud_cam, const std::vector<int32_t>& idx, bool do_prune,
                        int min_inliers, std::vector<ag2_hypothesis>* recs, size_t* n);
-  // Params::tiling == TILING_SPATIAL: the sample list in ascending order along `*axis` (the cloud's longest)
-  static std::vector<int32_t> orderSamplesAlongLongestAxis(const CloudCamera& cloud_cam, const std::vector<int32_t>& idx,
-                                                           int* axis);
+
   bool preprocessOnDevice(CloudCamera& cloud_cam);
 
   Params p_;

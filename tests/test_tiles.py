@@ -420,3 +420,48 @@ def test_a_rank_detects_in_one_trip_and_a_shape_that_does_not_hold_makes_every_r
     for d in dets + fresh:
         d.close()
     hip.hipFree(dbuf)
+
+
+def test_cpp_tile_plan_equals_sharding_py():
+    """GraspDetector's spatial tiling (Params::tiling = spatial, agile_grasp2_amd/host/ag2_host.cpp) is a port of
+    sharding.py: the sample order along the longest axis, the cost-balanced bounds and the tiles' sizes must be the
+    same for any cloud -- held against each other on the CPU (ag2host_tile_plan touches no GPU), over random clouds
+    with non-finite points, duplicate coordinates, more ranks than samples."""
+    import ctypes as C
+    import subprocess
+    host_dir = os.path.join(ROOT, "agile_grasp2_amd", "host")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "agile_grasp2_amd", "csrc"), "-s", "-j", "8"])
+    subprocess.check_call(["make", "-C", host_dir, "-s"])
+    lib = C.CDLL(os.path.join(host_dir, "libag2host.so"))
+    lib.ag2host_tile_plan.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_double,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(3)
+    for case in range(12):
+        n = int(rng.integers(50, 4000))
+        scale = np.float32([1.0, 1.0, 1.0])
+        scale[case % 3] = 3.0                       # the longest axis varies
+        xyz = (rng.uniform(-0.3, 0.3, size=(n, 3)).astype(np.float32) * scale).astype(np.float32)
+        if case % 2:
+            xyz[:, case % 3] = np.round(xyz[:, case % 3], 2)     # many equal coordinates along the tiling axis: ties
+        bad = rng.choice(n, 3, replace=False)
+        xyz[bad[0]] = np.nan
+        xyz[bad[1], 1] = np.inf
+        s = int(rng.integers(1, 60))
+        good = np.setdiff1d(np.arange(n), bad)
+        idx = np.sort(rng.choice(good, s, replace=False)).astype(np.int32)
+        for world in (1, 2, 3, 8, 64):
+            axis = sharding.longest_axis(xyz)
+            ordered = sharding.order_samples_by_x(xyz, idx, axis)
+            bounds = sharding.balanced_bounds(sharding.sample_costs(xyz, ordered, 0.1, axis), world)
+            halo = sharding.tile_halo(0.1, 0.01, 0.01)
+            tiles = [len(sharding.tile_points(xyz, ordered, r, world, halo, axis, bounds)[0]) for r in range(world)]
+            o = np.zeros(s, np.int32)
+            b = np.zeros(world + 1, np.int64)
+            t = np.zeros(world, np.int64)
+            ax = C.c_int32(-1)
+            rc = lib.ag2host_tile_plan(xyz.ctypes.data, n, idx.ctypes.data, s, world, 0.1, halo, o.ctypes.data,
+                                       b.ctypes.data, t.ctypes.data, C.byref(ax))
+            assert rc == 0 and ax.value == axis, (case, world)
+            assert np.array_equal(o, ordered), (case, world)
+            assert np.array_equal(b, bounds), (case, world, b, bounds)
+            assert list(t) == tiles, (case, world)
