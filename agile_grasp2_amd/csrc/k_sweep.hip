@@ -377,6 +377,9 @@ struct SweepShared {
   double cosd[kMaxOrient], sind[kMaxOrient];    // hand angles, f64 (exact path)
   float cosf_t[kMaxOrient], sinf_t[kMaxOrient]; // and rounded to f32 (classification)
   unsigned res_a[NW][kMaxOrient][2];            // pass A per wave: slot mask, flags
+  unsigned exact_a[NW][kMaxOrient][2];          // pass A, exact path (a few points per thousand): slot bits, flags,
+                                                // ORed here by the lanes that take it instead of living in 2 x RMAX
+                                                // registers per lane (RMAX = 16: they were the kernel's scratch)
   Red<NW> red;
   int wave_cnt[NW + 1];
   long long arena_off;
@@ -982,6 +985,7 @@ k_sweep(SweepArgs A) {
       if (K == 0) continue;
       L = A.lists + S.arena_off;
     }
+    for (int e = tid; e < NW * kMaxOrient * 2; e += NT) (&S.exact_a[0][0][0])[e] = 0u;  // (read behind the barrier below)
     __syncthreads();
     AG2_PROF(2);
 
@@ -1039,13 +1043,9 @@ k_sweep(SweepArgs A) {
     // Fast path: raw_acc holds bit (position + 2) of the clamped slot lattice, converted once at the
     // end; its two flags are wave-uniform (ballots), kept per orientation in the scalars s_below /
     // s_behind -- the loop body below is what the kernel's VALU time goes to, so it is kept short.
-    unsigned blk_acc[RMAX], flg_acc[RMAX], raw_acc[RMAX];
+    unsigned raw_acc[RMAX];
 #pragma unroll
-    for (int i = 0; i < RMAX; i++) {
-      blk_acc[i] = 0;
-      flg_acc[i] = 0;
-      raw_acc[i] = 0;
-    }
+    for (int i = 0; i < RMAX; i++) raw_acc[i] = 0;
     unsigned s_below = 0, s_behind = 0;
     {
       const float n0 = (float)F[0][0], n1 = (float)F[1][0], n2 = (float)F[2][0];
@@ -1137,11 +1137,8 @@ k_sweep(SweepArgs A) {
           need_exact &= need_exact - 1u;
           unsigned flg = 0, bits = 0;
           exact_A(ie, px, py, pz, flg, bits);
-#pragma unroll
-          for (int i = 0; i < RMAX; i++) {
-            flg_acc[i] |= (i == ie) ? flg : 0u;
-            blk_acc[i] |= (i == ie) ? bits : 0u;
-          }
+          if (bits) atomicOr(&S.exact_a[wid][ie][0], bits);
+          if (flg) atomicOr(&S.exact_a[wid][ie][1], flg);
         }
         // Long lists: every eighth step, an orientation whose finger slots are already so occupied --
         // by the points THIS wave has seen -- that no hand placement is left (the gates below:
@@ -1156,7 +1153,7 @@ k_sweep(SweepArgs A) {
           for (int i = 0; i < RMAX; i++) {
             if (i < R && ((alive >> i) & 1u)) {  // wave-uniform
               const unsigned pm = (raw_acc[i] >> 2) & 0x7FFFFu;
-              const unsigned cbw = wave_or_u(blk_acc[i] | (pm & 0x3FFu) | ((pm >> 9) << 10));
+              const unsigned cbw = wave_or_u((pm & 0x3FFu) | ((pm >> 9) << 10)) | S.exact_a[wid][i][0];
               const unsigned fr = (~cbw) & 0xFFFFFu;
               if ((fr & (fr >> 10) & 0x3FFu) == 0u || __popc(fr) <= 2) full |= 1u << i;
             }
@@ -1175,8 +1172,9 @@ k_sweep(SweepArgs A) {
     for (int i = 0; i < RMAX; i++) {
       if (i < R) {
         const unsigned pm = (raw_acc[i] >> 2) & 0x7FFFFu;  // the 19 positions -9 .. 9
-        const unsigned bsum = wave_or_u(blk_acc[i] | (pm & 0x3FFu) | ((pm >> 9) << 10));
-        const unsigned fsum = wave_or_u(flg_acc[i]) | ((s_below >> i) & 1u) | (((s_behind >> i) & 1u) ? 3u : 0u);
+        // (the exact path's bits of this wave: its lanes' LDS atomics are complete -- same wave, program order)
+        const unsigned bsum = wave_or_u((pm & 0x3FFu) | ((pm >> 9) << 10)) | S.exact_a[wid][i][0];
+        const unsigned fsum = S.exact_a[wid][i][1] | ((s_below >> i) & 1u) | (((s_behind >> i) & 1u) ? 3u : 0u);
         if (lane == 0) {
           S.res_a[wid][i][0] = bsum;
           S.res_a[wid][i][1] = fsum;
