@@ -809,7 +809,11 @@ int detect_frame_impl(ag2_ctx* c, const FrameIn& in, ag2_hypothesis* selected, s
                       size_t* n_scored, size_t* n_voxels) {
   const int rc = frame_submit(c, in);
   if (rc) return rc;
-  return frame_wait(c, selected, cap, n_selected, n_scored, n_voxels);
+  const int rw = frame_wait(c, selected, cap, n_selected, n_scored, n_voxels);
+  // (the synchronous call has no second half to come back to: a frame the wait kept for a caller with a larger
+  //  buffer -- AG2_ERR_CAPACITY, *n_selected says how large -- is dropped, the next call starts a new one)
+  if (rw && c->fm) c->fm->pend.active = false;
+  return rw;
 }
 
 }  // namespace

@@ -662,11 +662,9 @@ int ag2_gather_begin(ag2_ctx* root, size_t world, size_t cap_records) {
   const size_t per = 16 + cap_records * sizeof(ag2_hypothesis);
   AG2_HIP(root, hipStreamSynchronize(root->stream));  // (a merge of the previous exchange may still read the buffer)
   AG2_HIP(root, root->d_gather.reserve(world * per));
-  // No rank has delivered yet: the headers say "empty list" and the merge refuses to run while one is missing
-  // (a rank that failed would otherwise leave the previous exchange's records in its place)
-  for (size_t r = 0; r < world; r++)
-    AG2_HIP(root, hipMemsetAsync((char*)root->d_gather.p + r * per, 0, 16, root->stream));
-  AG2_HIP(root, hipStreamSynchronize(root->stream));
+  // No rank has delivered yet, and the merge refuses to run while one is missing: a rank that failed can no longer
+  // leave the previous exchange's records in its place.  (Clearing the headers as well would cost a
+  // fill and a wait per step; the delivery marks make stale headers unreachable.)
   root->gather_delivered.assign(world, 0);
   root->gather_world = world;
   root->gather_cap = cap_records;

@@ -425,7 +425,7 @@ def test_pipe_frames_of_different_sizes_and_a_short_result_buffer():
     prm = scene_params(ws, min_score_diff=-1e30, num_selected=-1)
     w = make_lenet_weights(7)
     n_min = min(c.shape[0] for c in clouds)
-    big = scene.draw_samples(5, n_min, 400)
+    big = np.ascontiguousarray(scene.draw_samples(5, n_min, 400), dtype=np.int32)
     small = scene.draw_samples(6, n_min, 3)
     sync = capi.Detector(**prm)
     sync.lenet_load(w)
@@ -457,6 +457,16 @@ def test_pipe_frames_of_different_sizes_and_a_short_result_buffer():
     with pytest.raises(RuntimeError, match="pipe empty"):
         pipe.wait()
     pipe.close()
+    # the SYNCHRONOUS call with a short buffer: AG2_ERR_CAPACITY, *n_selected = the room it needs, and the context
+    # is free for the next call (a kept frame would block it: "a frame is in flight")
+    xyz0 = np.ascontiguousarray(clouds[0], dtype=np.float32)
+    ns, na = C.c_size_t(0), C.c_size_t(0)
+    rc = sync.L.ag2_detect_frame(sync.h, xyz0.ctypes.data_as(C.c_void_p), C.c_int(0), C.c_size_t(xyz0.shape[0]),
+                                 C.c_size_t(12), big.ctypes.data_as(C.c_void_p), C.c_size_t(len(big)), C.c_uint64(0),
+                                 C.c_int(1), buf.ctypes.data_as(C.c_void_p), C.c_size_t(2), C.byref(ns), C.byref(na))
+    assert rc == -3 and ns.value == len(want[0][0])
+    again = sync.detect_frame(clouds[0], big, seed=0)
+    assert again[0].tobytes() == want[0][0].tobytes()
     sync.close()
 
 
