@@ -46,11 +46,13 @@ def compact_table(tab: np.ndarray) -> np.ndarray:
     return tab[tab["n_points"] > 0]
 
 
-def all_gather_tables(local_tab_u8, world: int):
-    """all_gather_into_tensor of equal-sized uint8 tables (torch tensors on the backend's device)."""
+def all_gather_tables(local_tab_u8, world: int, out=None):
+    """all_gather_into_tensor of equal-sized uint8 tables (torch tensors on the backend's device).  `out`: a
+    preallocated result tensor of world x the table's size (a caller that exchanges every step keeps one)."""
     import torch
     import torch.distributed as dist
-    out = torch.empty(local_tab_u8.numel() * world, dtype=torch.uint8, device=local_tab_u8.device)
+    if out is None or out.numel() != local_tab_u8.numel() * world or out.device != local_tab_u8.device:
+        out = torch.empty(local_tab_u8.numel() * world, dtype=torch.uint8, device=local_tab_u8.device)
     dist.all_gather_into_tensor(out, local_tab_u8)
     return out
 

@@ -557,7 +557,7 @@ def main():
             if rehearsal:
                 xch["out"] = sharding.all_gather_tables(xch["buf"].cpu(), world).cuda()
             else:
-                xch["out"] = sharding.all_gather_tables(xch["buf"], world)
+                xch["out"] = sharding.all_gather_tables(xch["buf"], world, out=xch.get("out"))
             try:
                 xch["merged"], xch["n_total"] = d.merge_selected_device(xch["out"].data_ptr(), world, xch["cap"])
             except capi.RetryStep:
